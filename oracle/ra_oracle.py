@@ -1,0 +1,689 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU (torch fp32) restatement of RelightableAvatar's per-ray render hot path, written from the
+reference's behaviour, each function citing the reference file:line it follows (paths relative to
+/root/reference).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module, and only as the checker.  The product path (relightableavatar_amd/) never imports it.
+
+Parity pin: the reference has no tests or golden vectors for this path, so this
+oracle is pinned against outputs of the reference itself, generated in the build container by
+tests/golden/make_golden.py (imports /root/reference with third-party stubs) and committed as
+tests/golden/*.npz.  tests/test_oracle_golden.py checks every stage against those fixtures.
+The one third-party op on the path, pytorch3d.ops.knn_points (un-vendored, version unpinned), is
+restated as exact brute-force squared-L2 3-NN, ascending (its documented contract); tie order is
+unpinned.
+
+Compaction (batch_aware_indexing + multi_gather/multi_scatter, net_utils.py:381-461) is restated
+with boolean masks: at B=1 topk(S) of the metric selects exactly the mask-true elements and results
+are scattered back, so outputs are order-free.
+All tensors here are un-batched (leading B=1 squeezed) unless stated.
+"""
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+class odict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+# ----------------------------------------------------------------------------- operators
+
+def positional_encoding(x: torch.Tensor, L: int) -> torch.Tensor:
+    """lib/networks/embedder.py:26-37: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]."""
+    fb = 2.0 ** torch.linspace(0.0, L - 1, steps=L, dtype=x.dtype)
+    xf = x[..., None, None, :] * fb[:, None, None]              # (..., L, 1, 3)
+    enc = torch.cat([torch.sin(xf), torch.cos(xf)], dim=-2)     # (..., L, 2, 3)
+    return torch.cat([x, enc.reshape(*x.shape[:-1], L * 6)], dim=-1)
+
+
+def fold_weight_norm(g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """nn.utils.weight_norm(dim=0): W = g * v / ||v||_row (net_utils.py:1326-1327, base_network.py:145-149)."""
+    return v * (g / v.norm(dim=1, keepdim=True))
+
+
+def softplus100(x):
+    return F.softplus(x, beta=100)
+
+
+def normalize(x: torch.Tensor, eps: float = 1e-8):
+    """net_utils.py:1626-1628."""
+    return x / (x.norm(dim=-1, keepdim=True) + eps)
+
+
+def inverse_3x3(R: torch.Tensor, EPS=1e-8):
+    """Closed-form adjugate / (det + 1e-8), blend_utils.py:125-165."""
+    r00, r01, r02 = R[..., 0, 0], R[..., 0, 1], R[..., 0, 2]
+    r10, r11, r12 = R[..., 1, 0], R[..., 1, 1], R[..., 1, 2]
+    r20, r21, r22 = R[..., 2, 0], R[..., 2, 1], R[..., 2, 2]
+    M = torch.empty_like(R)
+    M[..., 0, 0] = r11 * r22 - r21 * r12
+    M[..., 1, 0] = -r10 * r22 + r20 * r12
+    M[..., 2, 0] = r10 * r21 - r20 * r11
+    M[..., 0, 1] = -r01 * r22 + r21 * r02
+    M[..., 1, 1] = r00 * r22 - r20 * r02
+    M[..., 2, 1] = -r00 * r21 + r20 * r01
+    M[..., 0, 2] = r01 * r12 - r11 * r02
+    M[..., 1, 2] = -r00 * r12 + r10 * r02
+    M[..., 2, 2] = r00 * r11 - r10 * r01
+    D = r00 * M[..., 0, 0] + r01 * M[..., 1, 0] + r02 * M[..., 2, 0]
+    return M / (D[..., None, None] + EPS)
+
+
+def sdf_to_sigma(sdf: torch.Tensor, beta: torch.Tensor):
+    """Laplace-CDF density, net_utils.py:874-893."""
+    x = -sdf
+    ind0 = x <= 0
+    ind1 = ~ind0
+    val0 = 1 / beta * (0.5 * (x * ind0 / beta).exp()) * ind0
+    val1 = 1 / beta * (1 - 0.5 * (-x * ind1 / beta).exp()) * ind1
+    return val0 + val1
+
+
+def sdf_to_occ(sdf, beta, dists=0.005):
+    """net_utils.py:852-870: occ = 1 - exp(-relu(sigma) * 0.005); sample spacing is ignored (quirk 3)."""
+    return 1.0 - torch.exp(-F.relu(sdf_to_sigma(sdf, beta)) * dists)
+
+
+def volume_rendering(rgb, alpha, eps=1e-8, bg_brightness=0.0):
+    """net_utils.py:970-999. rgb (P,S,C), alpha (P,S) -> weights (P,S), map (P,C), acc (P)."""
+    expanded = torch.cat([alpha.new_ones(*alpha.shape[:-1], 1), 1.0 - alpha + eps], dim=-1)
+    weights = alpha * torch.cumprod(expanded, dim=-1)[..., :-1]
+    rgb_map = torch.sum(weights[..., None] * rgb, dim=-2)
+    acc_map = torch.sum(weights, -1)
+    rgb_map = rgb_map + (1.0 - acc_map[..., None]) * bg_brightness
+    return weights, rgb_map, acc_map
+
+
+def linear2srgb(linear):
+    """relight_utils.py:179-192."""
+    linear = linear.clip(0.0, 1.0)
+    lin = linear * 12.92
+    non = 1.055 * torch.pow(linear + 1e-7, 1 / 2.4) - (1.055 - 1)
+    return torch.where(linear <= 0.0031308, lin, non)
+
+
+def gen_light_xyz(env_h, env_w, env_r):
+    """relight_utils.py:423-465 (+ sph2cart :370-395)."""
+    lat_half = math.pi / env_h / 2
+    lng_half = 2 * math.pi / env_w / 2
+    lats = torch.linspace(math.pi / 2 - lat_half, -math.pi / 2 + lat_half, env_h)
+    lngs = torch.linspace(math.pi - lng_half, -math.pi + lng_half, env_w)
+    lngs, lats = torch.meshgrid(lngs, lats, indexing='xy')
+    z = env_r * torch.sin(lats)
+    x = env_r * torch.cos(lats) * torch.cos(lngs)
+    y = env_r * torch.cos(lats) * torch.sin(lngs)
+    xyz = torch.stack((x, y, z), dim=-1)
+    sin_colat = torch.sin(math.pi / 2 - lats)
+    area = 4 * math.pi * sin_colat / torch.sum(sin_colat)
+    return xyz, area
+
+
+def sample_envmap_image(image: torch.Tensor, ray_d: torch.Tensor):
+    """relight_utils.py:106-127: equirect bilinear, align_corners=False, border padding. image (H,W,C)."""
+    sh = ray_d.shape
+    if image.ndim == 4:
+        image = image[0]
+    d = ray_d.reshape(-1, 3)
+    img = image.permute(2, 0, 1).unsqueeze(0)
+    theta = torch.arccos(d[:, 2]) - 1e-6
+    phi = torch.atan2(d[:, 1], d[:, 0])
+    qy = (theta / math.pi) * 2 - 1
+    qx = -phi / math.pi
+    grid = torch.stack((qx, qy), dim=-1)[None, None]
+    rgb = F.grid_sample(img, grid, align_corners=False, padding_mode='border')
+    return rgb[0, :, 0].permute(1, 0).reshape(sh)
+
+
+def safe_divide(a, b, eps=1e-8):
+    """relight_utils.py:618-633 — mutates its arguments IN PLACE exactly like the reference."""
+    a[(a < eps) & (a >= 0)] = eps
+    a[(a > -eps) & (a <= 0)] = -eps
+    b[(b < eps) & (b >= 0)] = eps
+    b[(b > -eps) & (b <= 0)] = -eps
+    div = a / b
+    div[div != div] = 0.0
+    div[(div == math.inf) | (div == -math.inf)] = 0.0
+    return div.clip(-1e10, 1e10)
+
+
+def microfacet_brdf(pts2l, pts2c, normal, albedo, rough, f0=0.02, lambert_only=False, glossy_only=False):
+    """Microfacet.__call__ relight_utils.py:484-577 with cancel_cosine=True (default :475).
+    pts2l (N,L,3), pts2c (N,3), normal (N,3), albedo (N,3), rough (N,1) -> (N,L,3).
+    The in-place aliasing of safe_divide's arguments (cos_theta_m_sq, cos_theta_v) is reproduced."""
+    pts2l = F.normalize(pts2l, p=2, dim=-1, eps=1e-7)
+    pts2c = F.normalize(pts2c, p=2, dim=-1, eps=1e-7)
+    normal = F.normalize(normal, p=2, dim=-1, eps=1e-7)
+    l_dot_n = torch.einsum('ijk,ik->ij', pts2l, normal).clip(1e-4, 1)
+    v_dot_n = torch.einsum('ij,ij->i', pts2c, normal).clip(1e-4, 1)
+    brdf_lambert = albedo[:, None, :].repeat(1, pts2l.shape[1], 1) / math.pi
+    brdf_lambert = brdf_lambert * l_dot_n[:, :, None]
+    h = F.normalize(pts2l + pts2c[:, None, :], p=2, dim=-1, eps=1e-7)
+    # _get_f :610-615
+    f = f0 + (1 - f0) * (1 - torch.einsum('ijk,ijk->ij', pts2l, h)) ** 5
+    alpha = rough ** 2
+    # _get_d :598-608
+    cos_m = torch.einsum('ijk,ik->ij', h, normal)
+    chi = torch.where(cos_m > 0, 1.0, 0.0)
+    cos_m_sq = torch.square(cos_m)
+    tan_m_sq = safe_divide(1 - cos_m_sq, cos_m_sq)          # clamps cos_m_sq in place
+    denom = math.pi * torch.square(cos_m_sq) * torch.square(alpha ** 2 + tan_m_sq)
+    d = safe_divide(alpha ** 2 * chi, denom)
+    # _get_g :580-595
+    cos_v = torch.einsum('ij,ij->i', normal, pts2c)
+    cos_t = torch.einsum('ijk,ik->ij', h, pts2c)
+    div = safe_divide(cos_t, cos_v[:, None])                 # clamps cos_v in place (view)
+    chi = torch.where(div > 0, 1.0, 0.0)
+    cos_v_sq = torch.clip(torch.square(cos_v), 0.0, 1.0)
+    tan_v_sq = safe_divide(1 - cos_v_sq, cos_v_sq)
+    tan_v_sq = torch.clip(tan_v_sq, 0.0, 1e10)
+    denom = 1 + torch.sqrt(1 + alpha ** 2 * tan_v_sq[:, None])
+    g = safe_divide(chi * 2, denom)
+    l_dot_n = torch.ones_like(l_dot_n)
+    denom = 4 * torch.abs(l_dot_n) * torch.abs(v_dot_n)[:, None]
+    micro = safe_divide(f * g * d, denom)
+    brdf_glossy = micro[:, :, None].repeat(1, 1, 3)
+    if lambert_only:
+        return brdf_lambert
+    if glossy_only:
+        return brdf_glossy
+    return brdf_glossy + brdf_lambert
+
+
+def get_near_far_aabb(bounds, ray_o, ray_d, epsilon=1e-8):
+    """net_utils.py:1683-1712 (return_raw=True path). bounds (2,3); ray_d is modified on a copy here
+    (the reference mutates a gathered temporary, so the caller-visible rays are untouched)."""
+    ray_d = ray_d.clone()
+    ray_d[(ray_d < epsilon) & (ray_d > -epsilon ** 2)] = epsilon
+    ray_d[(ray_d > -epsilon ** 2) & (ray_d < epsilon)] = -epsilon   # matches nothing after the line above
+    tmin = (bounds[:1] - ray_o) / ray_d
+    tmax = (bounds[1:] - ray_o) / ray_d
+    near = torch.minimum(tmin, tmax).max(dim=-1)[0]
+    far = torch.maximum(tmin, tmax).min(dim=-1)[0]
+    return near, far
+
+
+def knn3(p1: torch.Tensor, p2: torch.Tensor, K: int = 3, chunk: int = 65536):
+    """pytorch3d.ops.knn_points contract: exact squared-L2 K-NN, ascending. p1 (P,3), p2 (N,3).
+    Distances are formed as sum((p-v)^2) (not the |p|^2-2pv+|v|^2 expansion) so near-zero values stay exact."""
+    d2s, idxs = [], []
+    for i in range(0, max(p1.shape[0], 1), chunk):
+        q = p1[i:i + chunk]
+        d = ((q[:, None, :] - p2[None, :, :]) ** 2).sum(-1) if q.shape[0] <= 8192 else \
+            torch.cat([((q[j:j + 4096, None, :] - p2[None]) ** 2).sum(-1) for j in range(0, q.shape[0], 4096)])
+        d2, idx = d.topk(K, dim=-1, largest=False, sorted=True)
+        d2s.append(d2)
+        idxs.append(idx)
+    return torch.cat(d2s), torch.cat(idxs)
+
+
+def geodesic_knn(pts, verts, norm, tverts, K, th):
+    """lib/utils/sample_utils.py:103-162.  Returns full-set (sdf_batch, nn_batch), the fine mask
+    (d2_min < th^2, :133) and the per-point geodesically filtered (d2, nn) (valid where mask)."""
+    d2, nn = knn3(pts, verts, K)
+    dist = d2.sqrt()
+    dot = ((pts[:, None, :] - verts[nn]) * norm[nn]).sum(-1)
+    sdf_batch = dist * dot.sign()
+    mask = d2[:, 0] < th ** 2
+    tv = tverts[nn]
+    msk = (tv - tv[:, :1]).pow(2).sum(-1) < th ** 2
+    d2f = torch.where(msk, d2, d2[:, :1])
+    nnf = torch.where(msk, nn, nn[:, :1])
+    sdf_batch = torch.where(msk, sdf_batch, sdf_batch[:, :1])
+    nn_batch = nnf
+    return sdf_batch, nn_batch, mask, d2f, nnf
+
+
+# ----------------------------------------------------------------------------- networks
+
+class OracleNet:
+    """Plain-weight view of the reference state_dict + frame-independent ops."""
+
+    def __init__(self, sd: dict, cfg):
+        self.cfg = cfg
+        f = lambda k: sd[k].detach().float().clone()
+        self.resd = [(f(f'residual_deformation_network.mlp.linears.{i}.weight'),
+                      f(f'residual_deformation_network.mlp.linears.{i}.bias')) for i in range(9)]
+        p = 'signed_distance_network.mlp.lin'
+        self.sdf = [(fold_weight_norm(f(f'{p}{l}.weight_g'), f(f'{p}{l}.weight_v')), f(f'{p}{l}.bias')) for l in range(9)]
+        self._beta = f('signed_distance_network._beta')
+        self.color = [(fold_weight_norm(f(f'render_network.l{i}.weight_g'), f(f'render_network.l{i}.weight_v')),
+                       f(f'render_network.l{i}.bias')) for i in range(5)]
+        self.relight = 'albedo_network.linears.0.weight' in sd
+        if self.relight:
+            self.albedo = [(f(f'albedo_network.linears.{i}.weight'), f(f'albedo_network.linears.{i}.bias')) for i in range(3)]
+            self.rough = [(f(f'roughness_network.linears.{i}.weight'), f(f'roughness_network.linears.{i}.bias')) for i in range(3)]
+            self.global_env_map_ = f('global_env_map_')
+            self.light_xyz = f('light_xyz_')
+            self.light_area = f('light_area')
+            self.light_sharp = f('light_sharp')
+
+    @property
+    def beta(self):
+        return self._beta.clamp(1e-9, 1e6)    # base_network.py:74-76
+
+    @property
+    def global_env_map(self):
+        g = self.global_env_map_
+        return F.softplus(g.expand(*g.shape[:2], 3))   # relight_network.py:86-89
+
+    def residuals(self, bpts, cond):
+        """base_network.py:34-42 + MLP net_utils.py:1263-1273 (ReLU, skip at 4 as cat([x, input]))."""
+        inp = torch.cat([positional_encoding(bpts, self.cfg.xyz_res), cond.expand(bpts.shape[0], -1)], dim=-1)
+        x = inp
+        for i, (w, b) in enumerate(self.resd):
+            if i == 4:
+                x = torch.cat([x, inp], dim=-1)
+            x = F.linear(x, w, b)
+            if i < 8:
+                x = F.relu(x)
+        return torch.tanh(x) * self.cfg.resd_limit
+
+    def sdf_feat(self, cpts):
+        """base_network.py:78-87 + SphereSignedDistanceField.forward net_utils.py:1337-1352."""
+        inp = positional_encoding(cpts, self.cfg.sdf_res)
+        x = inp
+        for l, (w, b) in enumerate(self.sdf):
+            if l == 4:
+                x = torch.cat([x, inp], dim=-1) / math.sqrt(2)
+            x = F.linear(x, w, b)
+            if l < 8:
+                x = softplus100(x)
+        return x[..., :1], x[..., 1:]
+
+    def color_net(self, view, grad, feat, cond):
+        """RenderNetwork.forward base_network.py:152-171."""
+        net = torch.cat([positional_encoding(view, self.cfg.view_res), grad, feat], dim=-1)
+        for i in range(3):
+            net = F.relu(F.linear(net, *self.color[i]))
+        net = torch.cat([net, cond.expand(net.shape[0], -1)], dim=-1)
+        net = F.relu(F.linear(net, *self.color[3]))
+        return torch.sigmoid(F.linear(net, *self.color[4]))
+
+    def material(self, feat):
+        """relight_network.py:45-47,97-98: 256->128->128->{3,1}, Softplus(100), slope*sigmoid+bias."""
+        def run(layers, slope, bias):
+            x = feat
+            for i, (w, b) in enumerate(layers):
+                x = F.linear(x, w, b)
+                if i < len(layers) - 1:
+                    x = softplus100(x)
+            return slope * torch.sigmoid(x) + bias
+        c = self.cfg
+        return run(self.albedo, c.albedo_slope, c.albedo_bias), run(self.rough, c.roughness_slope, c.roughness_bias)
+
+
+def _frame(batch):
+    """squeeze the B=1 batch dim of the §8b frame-state keys."""
+    f = odict()
+    for k in ('R', 'Th', 'weights', 'A', 'big_A', 'pverts', 'pnorm', 'tverts', 'tnorm'):
+        f[k] = batch[k][0].float()
+    f.Th = f.Th.reshape(1, 3)
+    f.cond = batch['poses'].reshape(1, -1).float()
+    if 'train_motion' in batch:
+        f.train_poses = batch['train_motion']['poses'][0].float()
+    return f
+
+
+def world_to_bigpose(net: OracleNet, x, fr, dist_th, v=None):
+    """Network.world_to_bigpose base_network.py:238-336 (forward, transform, filtering)."""
+    c = net.cfg
+    ppts_all = (x - fr.Th) @ fr.R                                   # blend_utils.py:252-261
+    sdf_batch, nn_batch, mask, d2, nn = geodesic_knn(ppts_all, fr.pverts, fr.pnorm, fr.tverts, c.sample_vert_cnt, dist_th)
+    ppts, d2, nn = ppts_all[mask], d2[mask], nn[mask]
+    bw = fr.weights[nn]                                            # (S,K,J)  :287
+    w = (-d2 / (2 * c.blend_radius ** 2)).exp()
+    w = w / (w.sum(dim=-1, keepdim=True) + torch.finfo(w.dtype).eps)
+    bw = (w[..., None] * bw).sum(dim=-2)                           # (S,J)
+    big_A_bw = (bw[:, :, None, None] * fr.big_A[None]).sum(dim=1)  # blend_transform blend_utils.py:212-218
+    big_R_inv = inverse_3x3(big_A_bw[:, :3, :3])
+    A_bw = (bw[:, :, None, None] * fr.A[None]).sum(dim=1)
+    R_inv = inverse_3x3(A_bw[:, :3, :3])
+    tpts = torch.sum(R_inv * (ppts - A_bw[:, :3, 3])[:, None, :], dim=-1)          # :290-300
+    bpts = torch.sum(big_A_bw[:, :3, :3] * tpts[:, None, :], dim=-1) + big_A_bw[:, :3, 3]   # :303-313
+    ret = odict(tpts=tpts, bpts=bpts, d2=d2, nn=nn, mask=mask, nn_batch=nn_batch, sdf_batch=sdf_batch,
+                A_bw=A_bw, R_inv=R_inv, big_A_bw=big_A_bw, big_R_inv=big_R_inv, ppts=ppts)
+    if v is not None:
+        pvds = (v @ fr.R)[mask]                                     # world_dirs_to_pose_dirs :225-231
+        tvds = torch.sum(A_bw[:, :3, :3].mT * pvds[:, None, :], dim=-1)            # pose_dirs_to_tpose_dirs :276-287
+        bvds = torch.sum(big_R_inv.mT * tvds[:, None, :], dim=-1)                 # tpose_dirs_to_pose_dirs :316-329
+        ret.pvds, ret.tvds, ret.bvds = pvds, tvds, bvds
+    return ret
+
+
+def hdq_sdf(net: OracleNet, x, fr, dist_th=None, smooth_transition=True, return_parts=False):
+    """Network.inference_world_distance_field base_network.py:365-387 (HDQ). x (P,3) -> (P,1)."""
+    dist_th = net.cfg.dist_th if dist_th is None else dist_th
+    ret = world_to_bigpose(net, x, fr, dist_th)
+    cpts = ret.bpts + net.residuals(ret.bpts, fr.cond)
+    net_sdf = net.sdf_feat(cpts)[0]
+    smpl_sdf = ret.sdf_batch.mean(dim=-1, keepdim=True)
+    smpl_sdf = torch.where(smpl_sdf < -dist_th, smpl_sdf, smpl_sdf.abs())
+    if smooth_transition:
+        d1 = smpl_sdf[ret.mask]
+        r = (net_sdf.abs() / dist_th).clip(0, 1)
+        net_sdf = d1 * r + net_sdf * (1 - r)
+    sdf = smpl_sdf.clone()
+    sdf[ret.mask] = net_sdf
+    if return_parts:
+        ret.sdf = sdf
+        ret.smpl_sdf = smpl_sdf
+        return ret
+    return sdf
+
+
+def forward_geometry(net: OracleNet, x, v, fr, dist_th=None):
+    """Network.forward_geometry base_network.py:456-494 (eval). Normals via autograd (net_utils.py:1215-1239)."""
+    dist_th = net.cfg.dist_th if dist_th is None else dist_th
+    out = world_to_bigpose(net, x, fr, dist_th, v)
+    bpts = out.bpts.detach().requires_grad_(True)
+    with torch.enable_grad():
+        resd = net.residuals(bpts, fr.cond)
+        cpts = bpts + resd
+        sdf, feat = net.sdf_feat(cpts)
+        occ = sdf_to_occ(sdf, net.beta)
+        ograd = torch.autograd.grad(sdf, bpts, torch.ones_like(sdf))[0]
+    norm = normalize(ograd)
+    norm = torch.sum(out.big_A_bw[:, :3, :3].mT * norm[:, None, :], dim=-1)   # pose_dirs_to_tpose_dirs(big)
+    norm = torch.sum(out.R_inv.mT * norm[:, None, :], dim=-1)                 # tpose_dirs_to_pose_dirs(A)
+    norm = norm @ fr.R.mT                                                     # pose_dirs_to_world_dirs
+    norm = normalize(norm)
+    out.bpts, out.cpts, out.resd = bpts.detach(), cpts.detach(), resd.detach()
+    out.sdf, out.occ, out.feat, out.norm, out.ograd = sdf.detach(), occ.detach(), feat.detach(), norm.detach(), ograd.detach()
+    return out
+
+
+def network_forward(net: OracleNet, x, v, fr, dist_th=None):
+    """eval-mode Network.forward: relight (relight_network.py:91-104) -> raw 17 ch
+    [cpts,bpts,resd,albedo,roughness,norm,occ]; AniSDF (base_network.py:496-515) -> raw 16 ch
+    [cpts,bpts,resd,norm,rgb,occ].  Zeros for points outside dist_th."""
+    c = net.cfg
+    if net.relight:
+        out = forward_geometry(net, x, None, fr, dist_th)
+        albedo, rough = net.material(out.feat)
+        raw = torch.cat([out.cpts, out.bpts, out.resd, albedo, rough, out.norm, out.occ], dim=-1)
+    else:
+        out = forward_geometry(net, x, v, fr, dist_th)
+        cond = fr.cond
+        if c.fix_material >= 0 or c.always_fix_material:
+            cond = fr.train_poses[c.fix_material].reshape(1, -1)    # base_network.py:501-503
+        rgb = net.color_net(out.bvds, out.norm, out.feat, cond)
+        raw = torch.cat([out.cpts, out.bpts, out.resd, out.norm, rgb, out.occ], dim=-1)
+    full = raw.new_zeros(x.shape[0], raw.shape[-1])
+    full[out.mask] = raw
+    return full, out
+
+
+# ----------------------------------------------------------------------------- tracing
+
+def sphere_tracing(ray_o, ray_d, near, far, sdf_fn: Callable, iter=16, tan_i=1000.0, relax=0.0, offset=0.02,
+                   eps=1e-8, shadow_skip_iter=1, clay_book=True, soft_shadow=False, tan_i_multiplier=1.0,
+                   hard_tan_i=1000.0):
+    """sphere_tracing sphere_tracing_renderer.py:103-216 (mode 'hdq'). near/far/tan_i (P,1) or scalars."""
+    P = ray_o.shape[0]
+    tan_i = hard_tan_i if not soft_shadow else tan_i_multiplier * tan_i
+    ones = torch.ones(P, 1)
+    near = ones * near
+    far = ones * far
+    tan = ones / tan_i
+    off = ones * offset
+    rlx = ones * relax
+    occ = ones
+    d0 = ones * 1e9
+    d1 = ones * 1e9
+    cd = ones * 1e9
+    dt = ones * 1e9
+    st = far
+    ot = far
+    t = near
+    for i in range(iter):
+        d1 = sdf_fn(ray_o + t * ray_d)
+        if soft_shadow and clay_book and i >= shadow_skip_iter:
+            dx0 = d0 + rlx * d0 + off
+            dx1 = d1 + rlx * d1 + off
+            dy = (dx1 ** 2) / (2 * dx0)
+            dx = ((dx1 ** 2 - dy ** 2).sqrt() - off) / (1 + rlx)
+            cls = dx.clip(0) / (t - dy).clip(near).clip(eps) / (tan * 2)
+            msk = (cls < occ) & (dy < t) & (dx1 > 0) & (dx0 > 0) & (dx > 0) & (dy > 0) & (dy < dx0)
+            ot = torch.where(msk, t - dy, ot)
+            occ = torch.where(msk, cls, occ)
+        if i >= shadow_skip_iter:
+            cls = d1.clip(0) / t.clip(near).clip(eps) / (tan * 2)
+            msk = cls < occ
+            ot = torch.where(msk, t, ot)
+            occ = torch.where(msk, cls, occ)
+        if not soft_shadow:
+            d1u, d0u = d1.abs(), d0.abs()
+            msk = d0.sign() != d1.sign()
+            st = torch.where(msk, t - dt * (d1u / (d0u + d1u + eps)).clip(0, 1), st)
+            off = torch.where(msk, 0.0, off)
+            rlx = torch.where(msk, 0.0, rlx)
+            msk = d1u < cd
+            cd = torch.where(msk, d1u, cd)
+            st = torch.where(msk, t, st)
+        dt = d1 + rlx * d1 + off
+        t = t + dt
+        t = torch.minimum(t, far)
+        t = torch.maximum(t, near)
+        d0 = d1
+    return ray_o + st * ray_d, ray_o + ot * ray_d, occ, st, ot
+
+
+def light_visibility(net: OracleNet, surf, norm, acc, fr, bbox, lvis_cfg, sdf_fn_factory):
+    """light_visibility sphere_tracing_renderer.py:265-344. surf,norm (P,3), acc (P) -> lvis, ldot (L,P)."""
+    c = net.cfg
+    xyz = net.light_xyz.reshape(-1, 3)
+    sharp = net.light_sharp.reshape(-1)
+    L, P = xyz.shape[0], surf.shape[0]
+    ray_d_l = normalize(xyz)                                           # directional (quirk 10)
+    ldot = ray_d_l @ norm.T                                            # (L,P)
+    if c.no_visibility:
+        return torch.ones_like(ldot), ldot
+    if c.local_visibility:
+        return (ldot > 0).float(), ldot
+    lfrt = (ldot > 0) & (acc > 0)[None]
+    li, pi = torch.nonzero(lfrt, as_tuple=True)
+    ro, rd = surf[pi], ray_d_l[li]
+    near_offset = lvis_cfg['near_offset']
+    n, f = get_near_far_aabb(bbox, ro, rd)
+    n, f = n.clip(near_offset), f.clip(near_offset)
+    box = n < f
+    lbox = torch.zeros_like(lfrt)
+    lbox[li, pi] = box
+    li, pi, ro, rd, n, f = li[box], pi[box], ro[box], rd[box], n[box], f[box]
+    sdf_fn = sdf_fn_factory(lvis_cfg['dist_th'])
+    _, _, occ, _, _ = sphere_tracing(ro, rd, n[:, None], f[:, None], sdf_fn, iter=lvis_cfg['iter'],
+                                     tan_i=sharp[li][:, None], relax=lvis_cfg['relax'], offset=lvis_cfg['offset'],
+                                     eps=c.sphere_tracing.eps, shadow_skip_iter=c.sphere_tracing.shadow_skip_iter,
+                                     clay_book=not c.no_claybook, soft_shadow=not c.no_dfss,
+                                     tan_i_multiplier=c.sphere_tracing.tan_i_multiplier, hard_tan_i=c.sphere_tracing.tan_i)
+    lvis = torch.zeros_like(ldot)
+    lvis[li, pi] = occ[:, 0]
+    lvis = lvis * lbox + 1 * ~lbox
+    lvis = lvis * lfrt + 0 * ~lfrt
+    return lvis, ldot
+
+
+def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, ldot, want_spec=False):
+    """Shading block sphere_tracing_renderer.py:715-755 / novel_light_sphere_tracing.py:21-66.
+    probe (H,W,3); per-pixel tensors (P,*); lvis/ldot (L,P). Returns rgb (sRGB), shade, spec (or None)."""
+    c = net.cfg
+    xyz = net.light_xyz.reshape(-1, 3)
+    area = net.light_area.reshape(-1)
+    surf2light = normalize(xyz[:, None] - surf[None])                 # (L,P,3)
+    surf2cam = normalize(ray_o - surf)
+    light = sample_envmap_image(probe, surf2light)                    # (L,P,3)
+    ones = torch.ones_like(ldot)
+    shade = lvis[..., None] * ones[..., None] * area[:, None, None] * light
+    p2l = surf2light.permute(1, 0, 2)
+    brdf = microfacet_brdf(p2l, surf2cam, norm, albedo, rough, f0=c.fresnel_f0,
+                           lambert_only=c.lambert_only, glossy_only=c.glossy_only).permute(1, 0, 2)
+    rgb = (brdf * shade).sum(0)
+    if c.tonemapping_rendering:
+        rgb = linear2srgb(rgb)
+    spec = None
+    if want_spec:
+        sb = microfacet_brdf(p2l, surf2cam, norm, torch.zeros_like(albedo), rough, f0=c.fresnel_f0,
+                             lambert_only=c.lambert_only, glossy_only=c.glossy_only).permute(1, 0, 2)
+        sl = 1 / (torch.abs(ones) + 1e-8)
+        spec = (sb * (ones[..., None] * sl[..., None] * area[:, None, None] * light)).sum(0)
+    shade_map = (lvis[..., None] * ldot[..., None] * area[:, None, None] * light).sum(0) * c.shading_albedo / math.pi
+    return rgb, shade_map, spec
+
+
+# ----------------------------------------------------------------------------- renderers
+
+def _chunks(total, chunk):
+    """chunkify's size rule net_utils.py:323."""
+    if total == 0:
+        return [(0, 0)]
+    actual = math.ceil(total / math.ceil(total / chunk))
+    return [(i, min(i + actual, total)) for i in range(0, total, actual)]
+
+
+def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
+    """render_human sphere_tracing_renderer.py:551-784, eval mode, one chunk. Returns full-ray maps."""
+    c = net.cfg
+    P = ray_o.shape[0]
+    st_cfg = c.sphere_tracing
+    surf_all, edge, occ, st, ot = sphere_tracing(
+        ray_o, ray_d, near[:, None], far[:, None], lambda x: hdq_sdf(net, x, fr, c.dist_th, True),
+        iter=st_cfg.iter, relax=st_cfg.relax, offset=st_cfg.offset, eps=st_cfg.eps,
+        shadow_skip_iter=st_cfg.shadow_skip_iter, clay_book=not c.no_claybook, soft_shadow=False, hard_tan_i=st_cfg.tan_i)
+    depth_all = (surf_all[:, 0] - ray_o[:, 0]) / ray_d[:, 0]          # quirk 4
+    acc_all = 1 - occ[:, 0]
+    hit = acc_all > 0
+    acc, surf, view, ro, depth = acc_all[hit], surf_all[hit], ray_d[hit], ray_o[hit], depth_all[hit]
+    S = c.n_samples
+    zval = torch.full((1,), 0.5) if S == 1 else torch.linspace(0.0, 1.0, steps=S)
+    net_zval = zval * (2 * c.surf_sample_range) - c.surf_sample_range
+    net_view = view[:, None, :].expand(-1, S, -1)
+    net_surf = surf[:, None, :] + net_zval[None, :, None] * net_view
+    raw, _ = network_forward(net, net_surf.reshape(-1, 3), net_view.reshape(-1, 3), fr, c.dist_th)
+    raw = raw.view(surf.shape[0], S, -1)
+    raw, o = raw[..., :-1], raw[..., -1]
+    _, raw, o = volume_rendering(raw, o, bg_brightness=c.bg_brightness)
+    raw = raw / (o[..., None] + 1e-8)
+    ret = odict(acc_map=acc, ray_o=ro, surf_map=surf, depth_map=depth)
+    if net.relight:
+        cpts, bpts, resd, albedo, rough, norm = raw.split([3, 3, 3, 3, 1, 3], dim=-1)
+    else:
+        cpts, bpts, resd, norm, rgb = raw.split([3, 3, 3, 3, 3], dim=-1)
+    norm = torch.where(norm.sum(dim=-1, keepdim=True) == 0, torch.ones_like(norm), norm)
+    norm = normalize(norm)
+    ret.cpts_map, ret.bpts_map, ret.resd_map, ret.norm_map = cpts, bpts, resd, norm
+    if net.relight:
+        albedo = albedo.clip(c.albedo_bias, c.albedo_bias + c.albedo_slope)
+        rough = rough.clip(c.roughness_bias, c.roughness_bias + c.roughness_slope)
+        ret.volume_albedo, ret.volume_roughness = albedo, rough
+        if c.albedo_multiplier > 0:
+            albedo = albedo * c.albedo_multiplier
+        ret.albedo_map, ret.roughness_map = albedo, rough[:, 0]
+    if c.relighting:
+        lvis, ldot = light_visibility(net, surf, norm, acc, fr, bbox, c.obj_lvis,
+                                      lambda th: (lambda x: hdq_sdf(net, x, fr, th, True)))
+        rgb, shade, spec = shade_pixels(net, probe, ro, surf, norm, albedo, rough, lvis, ldot, want_spec=c.vis_specular_map)
+        ret.rgb_map, ret.shade_map = rgb, shade
+        if spec is not None:
+            ret.spec_map = spec
+        if c.vis_novel_light:
+            ret.lvis_map, ret.ldot_map = lvis.T.contiguous(), ldot.T.contiguous()     # (P,512)
+    else:
+        ret.rgb_map = rgb
+    full = odict()
+    for k, vv in ret.items():
+        if k in ('volume_albedo', 'volume_roughness'):
+            full[k] = vv
+            continue
+        z = vv.new_zeros(P, *vv.shape[1:])
+        z[hit] = vv
+        full[k] = z
+    full.hit = hit
+    return full
+
+
+BLEND_KEYS = ['rgb_map', 'rfl_map', 'surf_map', 'albedo_map', 'roughness_map', 'norm_map', 'cpts_map', 'bpts_map',
+              'spec_map', 'depth_map', 'lvis_map', 'ldot_map', 'brdf_map', 'shade_map']
+
+
+def render_sphere_tracing(net: OracleNet, batch, probe=None, mutate_bounds=True):
+    """Renderer.render sphere_tracing_renderer.py:1066-1115 (no ground pass): chunk rays, grow bbox
+    IN PLACE per chunk (quirk 1), render_human, premultiply by acc (alpha_output_ :454-460).
+    Returns batched (1,P,...) maps like the reference."""
+    c = net.cfg
+    fr = _frame(batch)
+    if probe is None and net.relight:
+        probe = net.global_env_map
+    ray_o, ray_d, near, far = (batch[k][0].float() for k in ('ray_o', 'ray_d', 'near', 'far'))
+    wb = batch['wbounds'] if mutate_bounds else batch['wbounds'].clone()
+    outs = []
+    for (a, b) in _chunks(ray_o.shape[0], c.render_chunk_size):
+        wb[:, 0] -= c.env_lvis.bbox_margin
+        wb[:, 1] += c.env_lvis.bbox_margin
+        outs.append(render_human(net, ray_o[a:b], ray_d[a:b], near[a:b], far[a:b], probe, fr, wb[0].float()))
+    ret = odict()
+    for k in outs[0]:
+        ret[k] = torch.cat([o[k] for o in outs], dim=0)
+    acc = ret.acc_map
+    for k in BLEND_KEYS:
+        if k in ret:
+            v = ret[k]
+            ret[k] = v * (acc[:, None] if v.ndim == 2 else acc)
+    return odict({k: v[None] for k, v in ret.items()})
+
+
+def render_volume(net: OracleNet, batch):
+    """base_renderer.Renderer.render base_renderer.py:115-129 + get_pixel_value :53-113 (eval)."""
+    c = net.cfg
+    fr = _frame(batch)
+    ray_o, ray_d = batch['ray_o'][0].float(), batch['ray_d'][0].float()
+    near = batch['near'][0].float().clip(min=c.clip_near)
+    far = batch['far'][0].float().clip(max=c.clip_far)
+    S = c.n_samples
+    t_vals = torch.linspace(0.0, 1.0, steps=S)
+    outs = []
+    for (a, b) in _chunks(ray_o.shape[0], c.render_chunk_size):
+        z_vals = near[a:b, None] * (1.0 - t_vals) + far[a:b, None] * t_vals
+        pts = ray_o[a:b, None] + ray_d[a:b, None] * z_vals[..., None]
+        P = pts.shape[0]
+        view = ray_d[a:b, None].expand(-1, S, -1)
+        raw, _ = network_forward(net, pts.reshape(-1, 3), view.reshape(-1, 3), fr, c.dist_th)
+        raw = raw.view(P, S, -1)
+        weights, raw_map, acc_map = volume_rendering(raw[..., :-1], raw[..., -1], bg_brightness=c.bg_brightness)
+        depth = torch.sum(weights * z_vals, dim=-1)
+        outs.append(odict(depth_map=depth, cpts_map=raw_map[:, 0:3], bpts_map=raw_map[:, 3:6], resd_map=raw_map[:, 6:9],
+                          norm_map=raw_map[:, 9:12], rgb_map=raw_map[:, 12:15], acc_map=acc_map))
+    return odict({k: torch.cat([o[k] for o in outs])[None] for k in outs[0]})
+
+
+def render_novel_light(net: OracleNet, batch):
+    """novel_light_sphere_tracing.Renderer.render :103-221 with vis_ground_shading False (quirk 9:
+    re-shading consumes maps already premultiplied by acc)."""
+    c = net.cfg
+    main = render_sphere_tracing(net, batch)
+    relight = odict()
+    visual = ['rgb_map', 'acc_map', 'norm_map', 'surf_map', 'bpts_map', 'cpts_map', 'spec_map', 'shade_map',
+              'depth_map', 'albedo_map', 'roughness_map']
+    if 'main' in c.test_light:
+        relight.main = odict({k: main[k] for k in visual if k in main})
+    for name, env in batch['novel_lights'].items():
+        probe = env['probe'][0].float()
+        rgbs, shades, specs = [], [], []
+        P = main.ray_o.shape[1]
+        for (a, b) in _chunks(P, c.render_chunk_size):
+            rgb, shade, spec = shade_pixels(net, probe, main.ray_o[0, a:b], main.surf_map[0, a:b], main.norm_map[0, a:b],
+                                            main.albedo_map[0, a:b], main.roughness_map[0, a:b, None],
+                                            main.lvis_map[0, a:b].T, main.ldot_map[0, a:b].T, want_spec=True)
+            rgbs.append(rgb), shades.append(shade), specs.append(spec)
+        relight[name] = odict(rgb_map=torch.cat(rgbs)[None], shade_map=torch.cat(shades)[None], spec_map=torch.cat(specs)[None])
+    relight._main_full = main
+    return relight
+
+
+def psnr(a, b):
+    """lib/evaluators/base_evaluator.py:26-29."""
+    mse = torch.mean((a - b) ** 2)
+    return float(-10 * torch.log10(mse)) if mse > 0 else float('inf')

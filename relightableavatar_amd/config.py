@@ -1,0 +1,118 @@
+"""Resolved hot-path constants.
+
+The reference reads a global yacs tree (lib/config/config.py:34-425 + configs/base.yaml +
+configs/mobile_stage/xuzhen_12v_geo.yaml, merged by update_cfg config.py:487-519).  The
+config *system* is out of scope; what the hot path consumes is the
+flat set of keys below, with the reference's key names and default values.  ``make_cfg``
+reproduces the mode merges for the BASELINE experiments.
+"""
+from .base_utils import dotdict
+
+
+def default_cfg() -> dotdict:
+    c = dotdict()
+    # plugin selection (lib/networks/make_network.py:4-7, renderer/make_renderer.py:5-8)
+    c.network_module = 'relightableavatar_amd.networks.deform.base_network'
+    c.renderer_module = 'relightableavatar_amd.renderer.base_renderer'
+    # network shape (configs/base.yaml:47-49, config.py:224-231,441,465-466)
+    c.n_bones = 52
+    c.cond_dim = 156
+    c.xyz_res = 10
+    c.sdf_res = 8
+    c.view_res = 4
+    c.feat_dim = 256
+    c.resd_limit = 0.05
+    c.sdf_beta_init_value = 0.1
+    c.blend_radius = 0.075       # config.py:191
+    c.sample_vert_cnt = 3        # config.py:192
+    c.use_geodesic_filter = True
+    c.lambertian = False
+    # thresholds / sampling (base.yaml:77-97)
+    c.dist_th = 0.1
+    c.n_samples = 128
+    c.perturb = 1.0
+    c.clip_near = 0.02
+    c.clip_far = 10.0
+    c.bg_brightness = 0.0
+    c.render_chunk_size = 8192
+    c.network_chunk_size = 262144
+    c.fix_material = 0           # xuzhen_12v_geo.yaml:25
+    c.always_fix_material = True
+    # sphere tracing (config.py:116-124)
+    c.sphere_tracing = dotdict(iter=16, tan_i=1000.0, relax=0.0, offset=0.02, eps=1e-8,
+                               near_offset=0.01, shadow_skip_iter=1, tan_i_multiplier=1.0)
+    c.obj_lvis = dotdict(iter=4, offset=0.01, relax=0.0, near_offset=0.02, dist_th=0.05)   # config.py:127-132
+    c.env_lvis = dotdict(iter=16, offset=0.01, relax=0.0, near_offset=0.02, bbox_margin=0.25, dist_th=0.005)
+    c.no_claybook = False
+    c.no_dfss = False
+    c.no_visibility = False
+    c.local_visibility = False
+    c.surf_sample_range = 0.005  # config.py:76
+    # relighting (config.py:84-113,405-419)
+    c.relighting = False
+    c.achro_light = False
+    c.envmap_upscale = 2
+    c.envmap_init_intensity = 0.2
+    c.env_h = 16
+    c.env_w = 32
+    c.env_r = 10.0
+    c.fresnel_f0 = 0.02
+    c.lambert_only = False
+    c.glossy_only = False
+    c.albedo_slope = 1.0
+    c.albedo_bias = 0.0
+    c.roughness_slope = 0.90
+    c.roughness_bias = 0.09
+    c.relight_network_width = 128
+    c.relight_network_depth = 2
+    c.albedo_multiplier = 1.0
+    c.shading_albedo = 0.8
+    c.tonemapping_rendering = True
+    c.only_visibility = False
+    c.rgb_as_albedo = False
+    # visualisation switches that change what render() returns
+    c.vis_rendering_map = True
+    c.vis_shading_map = False
+    c.vis_specular_map = False
+    c.vis_novel_light = False
+    c.vis_ground_shading = False
+    c.vis_lvis_map = False
+    c.vis_ldot_map = False
+    c.replace_light = ''
+    c.test_light = ['main']
+    c.vis_rotate_light = False
+    # build-side knobs (not in the reference)
+    c.mlp_dtype = 'bf16'         # arithmetic type of the fused MLP kernels
+    return c
+
+
+def make_cfg(mode: str = 'anisdf', **overrides) -> dotdict:
+    """mode: 'anisdf' (volume), 'sphere_tracing', 'relight', 'novel_light'.
+
+    Mirrors update_cfg (config.py:487-519): sphere_tracing_cfg (base.yaml:132-136),
+    relighting_cfg (base.yaml:138-201 + xuzhen_12v_geo.yaml:46-58), novel_light_cfg
+    (base.yaml:193-195).
+    """
+    c = default_cfg()
+    if mode in ('sphere_tracing', 'relight', 'novel_light'):
+        c.n_samples = 3
+        c.render_chunk_size = 65536
+        c.network_chunk_size = 1048576
+        c.renderer_module = 'relightableavatar_amd.renderer.sphere_tracing_renderer'
+    if mode in ('relight', 'novel_light'):
+        c.relighting = True
+        c.dist_th = 0.125
+        c.obj_lvis.dist_th = 0.125
+        c.achro_light = True
+        c.network_module = 'relightableavatar_amd.networks.relight.relight_network'
+    if mode == 'novel_light':
+        c.vis_novel_light = True
+        c.renderer_module = 'relightableavatar_amd.renderer.novel_light_sphere_tracing'
+    elif mode not in ('anisdf', 'sphere_tracing', 'relight'):
+        raise ValueError(f'unknown mode {mode}')
+    for k, v in overrides.items():
+        if isinstance(v, dict) and isinstance(c.get(k), dict):
+            c[k].update(v)
+        else:
+            c[k] = v
+    return c

@@ -1,0 +1,304 @@
+"""Build-owned deterministic synthetic inputs (SURVEY.md §8d "synthetic inputs").
+
+Nothing here comes from the reference: there is no network for datasets or checkpoints, so
+bench.py, smoke() and the tests render a synthetic avatar:
+
+* weights: numpy PCG64 streams keyed by (seed, tensor name); shapes and key names are the
+  reference's state_dict (SURVEY.md §8b "weights on disk"), statistics follow its initialisers
+  (SDF geometric init net_utils.py:1303-1324; nn.Linear default U(+-1/sqrt(fan_in)); kaiming
+  normal for the material heads relight_network.py:46-47) so the zero level set is a blob of
+  radius ~0.4-0.5 in big-pose space.
+* body: N=6890 Fibonacci-sphere "SMPL" vertices, J=52 random rigid bone transforms.
+* camera: pinhole at (0,0,-2), focal 0.8*H; rays clipped to the body AABB the way
+  lib/utils/data_utils.py:827-875,925-938 does (restated, numpy).
+* envmaps: lognormal HDR-like 16x32 probes + one OLAT-style probe.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+from .base_utils import dotdict
+
+N_VERTS = 6890
+N_BONES = 52
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def _uniform(seed, name, shape, bound):
+    return torch.from_numpy(_rng(seed, name).uniform(-bound, bound, size=shape).astype(np.float32))
+
+
+def _normal(seed, name, shape, mean, std):
+    return torch.from_numpy((_rng(seed, name).standard_normal(size=shape) * std + mean).astype(np.float32))
+
+
+def _linear(sd, seed, prefix, fan_in, fan_out, kind='uniform'):
+    if kind == 'uniform':  # nn.Linear default
+        b = 1.0 / math.sqrt(fan_in)
+        sd[prefix + '.weight'] = _uniform(seed, prefix + '.weight', (fan_out, fan_in), b)
+    elif kind == 'kaiming':  # kaiming_normal_, fan_in, gain sqrt(2)
+        sd[prefix + '.weight'] = _normal(seed, prefix + '.weight', (fan_out, fan_in), 0.0, math.sqrt(2.0 / fan_in))
+    sd[prefix + '.bias'] = _uniform(seed, prefix + '.bias', (fan_out,), 1.0 / math.sqrt(fan_in))
+
+
+def _weight_norm(sd, seed, prefix, w: torch.Tensor, bias: torch.Tensor, jitter=0.05):
+    """store W as (weight_g, weight_v) with g != |v| so the fold is exercised."""
+    v = w
+    g = v.norm(dim=1, keepdim=True) * (1.0 + _uniform(seed, prefix + '.g', (w.shape[0], 1), jitter))
+    sd[prefix + '.weight_g'] = g
+    sd[prefix + '.weight_v'] = v
+    sd[prefix + '.bias'] = bias
+
+
+def freq_bands(multires: int) -> torch.Tensor:
+    fb = 2.0 ** torch.linspace(0.0, multires - 1, steps=multires)
+    return fb[:, None, None].expand(multires, 2, 1).clone()
+
+
+def make_state_dict(seed: int = 0, relight: bool = True, cfg=None) -> dict:
+    """state_dict with the reference's key names."""
+    from .config import default_cfg
+    cfg = cfg or default_cfg()
+    sd = {}
+    xyz_dim = 3 + 6 * cfg.xyz_res        # 63
+    sdf_dim = 3 + 6 * cfg.sdf_res        # 51
+    view_dim = 3 + 6 * cfg.view_res      # 27
+    W = 256
+    # residual deformation MLP (base_network.py:14-42): 9 plain linears, skip at 4 (x first)
+    p = 'residual_deformation_network'
+    sd[p + '.embedder.freq_bands'] = freq_bands(cfg.xyz_res)
+    in_ch = xyz_dim + cfg.cond_dim
+    for i in range(9):
+        I = in_ch if i == 0 else (W + in_ch if i == 4 else W)
+        O = 3 if i == 8 else W
+        _linear(sd, seed, f'{p}.mlp.linears.{i}', I, O)
+    sd[f'{p}.mlp.linears.8.bias'] = torch.zeros(3)
+    # signed distance net (net_utils.py:1276-1352), geometric init, weight-normed
+    p = 'signed_distance_network'
+    sd[p + '._beta'] = torch.tensor(float(cfg.sdf_beta_init_value))
+    sd[p + '.embedder.freq_bands'] = freq_bands(cfg.sdf_res)
+    dims = [sdf_dim] + [W] * 8 + [1 + cfg.feat_dim]
+    for l in range(9):
+        out_dim = dims[l + 1] - dims[0] if l + 1 == 4 else dims[l + 1]
+        name = f'{p}.mlp.lin{l}'
+        if l == 8:
+            w = _normal(seed, name + '.w', (out_dim, dims[l]), math.sqrt(math.pi) / math.sqrt(dims[l]), 1e-4)
+            # feature rows: small random so feat is not a copy of sdf
+            w[1:] = _normal(seed, name + '.wf', (out_dim - 1, dims[l]), 0.0, 1.0 / math.sqrt(dims[l]))
+            b = torch.full((out_dim,), -0.5)
+            b[1:] = _uniform(seed, name + '.bf', (out_dim - 1,), 0.1)
+        elif l == 0:
+            w = torch.zeros(out_dim, dims[l])
+            w[:, :3] = _normal(seed, name + '.w', (out_dim, 3), 0.0, math.sqrt(2) / math.sqrt(out_dim))
+            # a little energy on the encoded inputs so the PE path is exercised
+            w[:, 3:] = _normal(seed, name + '.wpe', (out_dim, dims[l] - 3), 0.0, 0.02 / math.sqrt(out_dim))
+            b = torch.zeros(out_dim)
+        elif l == 4:
+            w = _normal(seed, name + '.w', (out_dim, dims[l]), 0.0, math.sqrt(2) / math.sqrt(out_dim))
+            w[:, -(dims[0] - 3):] = _normal(seed, name + '.wpe', (out_dim, dims[0] - 3), 0.0, 0.02 / math.sqrt(out_dim))
+            b = torch.zeros(out_dim)
+        else:
+            w = _normal(seed, name + '.w', (out_dim, dims[l]), 0.0, math.sqrt(2) / math.sqrt(out_dim))
+            b = torch.zeros(out_dim)
+        _weight_norm(sd, seed, name, w, b, jitter=0.02)
+    # colour net (base_network.py:132-171), weight-normed
+    p = 'render_network'
+    sd[p + '.embedder.freq_bands'] = freq_bands(cfg.view_res)
+    shapes = [(view_dim + 3 + cfg.feat_dim, W), (W, W), (W, W), (W + cfg.n_bones * 3, W), (W, 3)]
+    for i, (I, O) in enumerate(shapes):
+        name = f'{p}.l{i}'
+        b = 1.0 / math.sqrt(I)
+        _weight_norm(sd, seed, name, _uniform(seed, name + '.w', (O, I), b), _uniform(seed, name + '.b', (O,), b))
+    if relight:
+        for net, out in (('albedo_network', 3), ('roughness_network', 1)):
+            Wm = cfg.relight_network_width
+            for i in range(cfg.relight_network_depth + 1):
+                I = cfg.feat_dim if i == 0 else Wm
+                O = out if i == cfg.relight_network_depth else Wm
+                _linear(sd, seed, f'{net}.linears.{i}', I, O, kind='kaiming')
+        ch = 1 if cfg.achro_light else 3
+        eh, ew = cfg.env_h * cfg.envmap_upscale, cfg.env_w * cfg.envmap_upscale
+        # learned probe is softplus(param); give it lobes so shading is not flat
+        r = _rng(seed, 'global_env_map_')
+        base = r.uniform(0, 1, size=(eh, ew, ch)) * cfg.envmap_init_intensity
+        yy, xx = np.mgrid[0:eh, 0:ew]
+        for (cy, cx, amp) in ((eh * 0.3, ew * 0.25, 4.0), (eh * 0.45, ew * 0.7, 2.0)):
+            base += amp * np.exp(-(((yy - cy) / 3.0) ** 2 + ((xx - cx) / 4.0) ** 2))[..., None]
+        sd['global_env_map_'] = torch.from_numpy(base.astype(np.float32))
+        xyz, area = gen_light_xyz(cfg.env_h, cfg.env_w, cfg.env_r)
+        sd['light_xyz_'] = xyz
+        sd['light_area'] = area
+        sd['light_sharp'] = 1.0 / (area / math.pi).sqrt()
+        sd['xyz_embedder.freq_bands'] = freq_bands(10)
+        sd['view_embedder.freq_bands'] = freq_bands(4)
+    return sd
+
+
+def gen_light_xyz(env_h: int, env_w: int, env_r: float):
+    """Light-probe geometry; restates lib/utils/relight_utils.py:423-465 (lat/long cell centres)."""
+    lat_half = math.pi / env_h / 2
+    lng_half = 2 * math.pi / env_w / 2
+    lats = torch.linspace(math.pi / 2 - lat_half, -math.pi / 2 + lat_half, env_h)
+    lngs = torch.linspace(math.pi - lng_half, -math.pi + lng_half, env_w)
+    lngs, lats = torch.meshgrid(lngs, lats, indexing='xy')  # (eH, eW)
+    z = env_r * torch.sin(lats)
+    x = env_r * torch.cos(lats) * torch.cos(lngs)
+    y = env_r * torch.cos(lats) * torch.sin(lngs)
+    xyz = torch.stack((x, y, z), dim=-1)
+    sin_colat = torch.sin(math.pi / 2 - lats)
+    area = 4 * math.pi * sin_colat / torch.sum(sin_colat)
+    return xyz, area
+
+
+def _rodrigues(rvec: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(rvec)
+    if th < 1e-12:
+        return np.eye(3)
+    k = rvec / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+
+
+def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4) -> dotdict:
+    """SMPL-shaped frame state with the §8b batch keys (leading batch dim 1)."""
+    i = np.arange(N_VERTS, dtype=np.float64) + 0.5
+    phi = np.arccos(1 - 2 * i / N_VERTS)
+    theta = math.pi * (1 + 5 ** 0.5) * i
+    nrm = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], -1)
+    # squash into a capsule-ish blob so the bbox is not a cube
+    scale = np.array([0.8, 0.7, 1.1])
+    tverts = nrm * radius * scale
+    tnorm = nrm / scale
+    tnorm /= np.linalg.norm(tnorm, axis=-1, keepdims=True)
+    r = _rng(seed, 'body')
+    weights = r.standard_normal((N_VERTS, N_BONES)) * 4.0
+    # smooth the skinning field a little: weight depends on position through random planes
+    planes = r.standard_normal((N_BONES, 3))
+    weights = 6.0 * (nrm @ planes.T) + 0.5 * weights
+    weights = np.exp(weights - weights.max(-1, keepdims=True))
+    weights /= weights.sum(-1, keepdims=True)
+    A = np.tile(np.eye(4), (N_BONES, 1, 1))
+    big_A = np.tile(np.eye(4), (N_BONES, 1, 1))
+    if posed:
+        for j in range(N_BONES):
+            A[j, :3, :3] = _rodrigues(r.uniform(-1, 1, 3) * 0.3 / math.sqrt(3))
+            A[j, :3, 3] = r.uniform(-0.05, 0.05, 3)
+            big_A[j, :3, :3] = _rodrigues(r.uniform(-1, 1, 3) * 0.2 / math.sqrt(3))
+            big_A[j, :3, 3] = r.uniform(-0.03, 0.03, 3)
+    # posed verts / normals by forward LBS of the T-pose mesh (what the dataset does on CPU)
+    Av = np.einsum('nj,jab->nab', weights, A)
+    pverts = np.einsum('nab,nb->na', Av[:, :3, :3], tverts) + Av[:, :3, 3]
+    pnorm = np.einsum('nab,nb->na', Av[:, :3, :3], tnorm)
+    pnorm /= np.linalg.norm(pnorm, axis=-1, keepdims=True)
+    if posed:
+        R = _rodrigues(np.array([0.1, -0.2, 0.15]))
+        Th = np.array([[0.03, -0.02, 0.05]])
+    else:
+        R = np.eye(3)
+        Th = np.zeros((1, 3))
+    wverts = pverts @ R.T + Th
+    margin = 0.05
+    wbounds = np.stack([wverts.min(0) - margin, wverts.max(0) + margin])
+    poses = r.standard_normal((N_BONES, 3)) * 0.1
+    train_poses = r.standard_normal((4, N_BONES * 3)) * 0.1
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None]
+    b = dotdict()
+    b.R, b.Th = f(R), f(Th)
+    b.poses = f(poses)
+    b.weights = f(weights)
+    b.A, b.big_A = f(A), f(big_A)
+    b.pverts, b.pnorm, b.tverts, b.tnorm = f(pverts), f(pnorm), f(tverts), f(tnorm)
+    b.wbounds = f(wbounds)
+    b.train_motion = dotdict(poses=f(train_poses))
+    return b
+
+
+def make_camera(H: int, W: int, origin=(0.0, 0.0, -2.0), focal_ratio: float = 0.8):
+    """pinhole looking down +z; K, R (world->cam), T."""
+    K = np.array([[focal_ratio * H, 0, W / 2], [0, focal_ratio * H, H / 2], [0, 0, 1]], dtype=np.float64)
+    R = np.eye(3)
+    T = -R @ np.asarray(origin, dtype=np.float64).reshape(3, 1)
+    return K, R, T
+
+
+def rays_within_bounds(H, W, K, R, T, bounds: np.ndarray):
+    """Restates lib/utils/data_utils.py:827-845 (get_rays), :860-875 (get_full_near_far),
+    :925-938 (get_rays_within_bounds) in numpy: unit directions, AABB near/far, box mask."""
+    ray_o = -(R.T @ T).ravel()
+    i, j = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    xy1 = np.stack([j, i, np.ones_like(i)], axis=2)
+    pixel_camera = xy1 @ np.linalg.inv(K).T
+    pixel_world = (pixel_camera - T.ravel()) @ R
+    ray_d = pixel_world - ray_o[None, None]
+    ray_d = ray_d / np.linalg.norm(ray_d, axis=2, keepdims=True)
+    ray_o = np.broadcast_to(ray_o, ray_d.shape)
+    ray_o = ray_o.reshape(-1, 3).astype(np.float32)
+    ray_d = ray_d.reshape(-1, 3).astype(np.float32)
+    norm_d = np.linalg.norm(ray_d, axis=-1, keepdims=True)
+    viewdir = ray_d / norm_d
+    viewdir[(viewdir < 1e-5) & (viewdir > -1e-10)] = 1e-5
+    viewdir[(viewdir > -1e-5) & (viewdir < 1e-10)] = -1e-5
+    tmin = (bounds[:1] - ray_o[:1]) / viewdir
+    tmax = (bounds[1:2] - ray_o[:1]) / viewdir
+    t1, t2 = np.minimum(tmin, tmax), np.maximum(tmin, tmax)
+    near, far = np.max(t1, axis=-1), np.min(t2, axis=-1)
+    mask = near < far
+    near = (near / norm_d[..., 0])[mask] / norm_d[mask, 0]
+    far = (far / norm_d[..., 0])[mask] / norm_d[mask, 0]
+    return ray_o[mask], ray_d[mask], near.astype(np.float32), far.astype(np.float32), mask.reshape(H, W)
+
+
+def make_batch(H: int, W: int, seed: int = 0, posed: bool = True, n_novel_lights: int = 0,
+               crop: int = 0) -> dotdict:
+    """Full §8b batch on CPU. ``crop``>0 keeps only a centred crop x crop window of pixels."""
+    b = make_body(seed, posed)
+    K, R, T = make_camera(H, W)
+    ro, rd, near, far, mask = rays_within_bounds(H, W, K, R, T, b.wbounds[0].numpy().astype(np.float64))
+    if crop:
+        win = np.zeros((H, W), dtype=bool)
+        y0, x0 = (H - crop) // 2, (W - crop) // 2
+        win[y0:y0 + crop, x0:x0 + crop] = True
+        keep = win[mask]
+        ro, rd, near, far = ro[keep], rd[keep], near[keep], far[keep]
+        mask = mask & win
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None]
+    b.ray_o, b.ray_d, b.near, b.far = f(ro), f(rd), f(near), f(far)
+    b.mask_at_box = torch.from_numpy(mask.reshape(1, -1))
+    b.meta = dotdict(H=torch.tensor([H]), W=torch.tensor([W]), frame_index=torch.tensor([0]), view_index=torch.tensor([0]))
+    b.cam_K, b.cam_R, b.cam_T = f(K.astype(np.float32)), f(R.astype(np.float32)), f(T.astype(np.float32))
+    if n_novel_lights:
+        b.novel_lights = make_novel_lights(n_novel_lights, seed)
+    return b
+
+
+def make_novel_lights(n: int, seed: int = 0, env_h: int = 16, env_w: int = 32) -> dotdict:
+    lights = dotdict()
+    for k in range(n):
+        r = _rng(seed, f'light{k}')
+        if k == n - 1 and n > 1:  # OLAT-style: one hot * 100 + ambient 0.25
+            probe = np.full((env_h, env_w, 3), 0.25, dtype=np.float32)
+            probe[4, 13] = 100.0
+        else:
+            probe = np.exp(r.standard_normal((env_h, env_w, 1)) * 1.0 - 1.0) * (0.5 + r.uniform(0, 1, (1, 1, 3)))
+            probe = probe.astype(np.float32)
+        lights[f'probe{k:02d}'] = dotdict(probe=torch.from_numpy(probe)[None])
+    return lights
+
+
+def to_device(batch, device):
+    out = dotdict()
+    for k, v in batch.items():
+        if k == 'meta':
+            out[k] = v
+        elif isinstance(v, torch.Tensor):
+            out[k] = v.to(device)
+        elif isinstance(v, dict):
+            out[k] = to_device(v, device)
+        else:
+            out[k] = v
+    return out

@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --mode {ops,anisdf,sphere,relight,novel}
+
+Imports /root/reference's hot-path modules on CPU with a stub import-finder for the third-party
+packages the image lacks (SURVEY.md §8c recipe), loads the build-owned synthetic weights
+(relightableavatar_amd.synthetic) into the reference nets with load_state_dict, runs the reference
+functions on build-owned synthetic inputs and stores inputs-by-seed + reference outputs as small
+.npz fixtures next to this script.  The reference never travels: only these fixtures are committed.
+One process per mode, because the reference binds cfg values as default arguments at import time
+(SURVEY.md §5 "config / flags" gotcha).
+"""
+import argparse
+import os
+import sys
+import types
+import importlib.abc
+import importlib.machinery
+from unittest.mock import MagicMock
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+ROOTS = ['cv2', 'termcolor', 'pdbr', 'easymocap', 'smplx', 'pytorch3d', 'h5py', 'imageio', 'mcubes', 'trimesh',
+         'torch_scatter', 'easyvolcap', 'lpips', 'skimage', 'open3d', 'pyntcloud', 'ujson', 'ruamel', 'kornia']
+
+
+class _Mod(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        m = MagicMock(name=f'{self.__name__}.{name}')
+        setattr(self, name, m)
+        return m
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+
+    def create_module(self, spec):
+        m = _Mod(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_reference():
+    sys.meta_path.insert(0, _Finder())
+    import termcolor
+    termcolor.colored = lambda x, *a, **k: str(x)
+    import pytorch3d.ops
+
+    def knn_points(p1, p2, K=1, return_nn=False, return_sorted=True, **kw):
+        # pytorch3d contract: exact squared-L2 K-NN, ascending.  (p-v)^2 form, chunked.
+        ds, ids = [], []
+        for i in range(0, p1.shape[1], 4096):
+            d = ((p1[:, i:i + 4096, None, :] - p2[:, None, :, :]) ** 2).sum(-1)
+            dd, ii = d.topk(K, dim=-1, largest=False, sorted=True)
+            ds.append(dd), ids.append(ii)
+        if not ds:
+            return p1.new_zeros(*p1.shape[:2], K), torch.zeros(*p1.shape[:2], K, dtype=torch.long), None
+        return torch.cat(ds, 1), torch.cat(ids, 1), None
+    pytorch3d.ops.knn_points = knn_points
+    torch.cuda.synchronize = lambda *a, **k: None
+    sys.path.insert(0, '/root/reference')
+    os.chdir('/root/reference')
+    from lib.config import cfg
+    return cfg
+
+
+def set_cfg(cfg, mode):
+    cfg.n_bones = 52
+    cfg.cond_dim = 156
+    cfg.xyz_res, cfg.sdf_res, cfg.view_res = 10, 8, 4
+    cfg.fix_material = 0
+    cfg.vis_rendering_map = True
+    cfg.geometry_pretrain = '/nonexistent'
+    if mode in ('ops', 'relight', 'novel'):
+        cfg.relighting = True
+        cfg.n_samples = 3
+        cfg.render_chunk_size = 65536
+        cfg.network_chunk_size = 65536
+        cfg.dist_th = 0.125
+        cfg.obj_lvis.dist_th = 0.125
+        cfg.achro_light = True
+    elif mode == 'sphere':
+        cfg.n_samples = 3
+        cfg.render_chunk_size = 65536
+        cfg.network_chunk_size = 65536
+        cfg.dist_th = 0.1
+    elif mode == 'anisdf':
+        cfg.n_samples = 64
+        cfg.render_chunk_size = 8192
+        cfg.dist_th = 0.1
+    if mode == 'novel':
+        cfg.vis_novel_light = True
+        cfg.test_light = ['main']
+
+
+def to_ref_batch(b):
+    from lib.utils.base_utils import dotdict
+    out = dotdict()
+    for k, v in b.items():
+        out[k] = to_ref_batch(v) if isinstance(v, dict) else v
+    return out
+
+
+def npz(path, **kw):
+    arrs = {}
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        arrs[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, path), **arrs)
+    print('wrote', path, {k: a.shape for k, a in arrs.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel'])
+    args = ap.parse_args()
+    mode = args.mode
+    from relightableavatar_amd import synthetic
+    from relightableavatar_amd.config import make_cfg
+    cfg = install_reference()
+    set_cfg(cfg, mode)
+    torch.manual_seed(0)
+    torch.set_grad_enabled(True)
+    my_cfg = make_cfg({'ops': 'relight', 'anisdf': 'anisdf', 'sphere': 'sphere_tracing', 'relight': 'relight', 'novel': 'novel_light'}[mode])
+    relight = mode in ('ops', 'relight', 'novel')
+    sd = synthetic.make_state_dict(0, relight=relight, cfg=my_cfg)
+    if relight:
+        from lib.networks.relight.relight_network import Network
+    else:
+        from lib.networks.deform.base_network import Network
+    net = Network()
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not [m for m in missing if 'embedder' not in m], missing
+    net.eval()
+
+    if mode == 'ops':
+        gen_ops(net, cfg, synthetic)
+        return
+    from lib.networks.renderer import base_renderer, sphere_tracing_renderer
+    if mode == 'anisdf':
+        H, crop = 128, 24
+        batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop))
+        with torch.no_grad():
+            out = base_renderer.Renderer(net).render(batch)
+        npz('frame_anisdf.npz', H=H, crop=crop, n_samples=cfg.n_samples,
+            **{k: out[k] for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'cpts_map', 'bpts_map', 'resd_map')})
+    elif mode == 'sphere':
+        H, crop = 128, 32
+        batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop))
+        with torch.no_grad():
+            out = sphere_tracing_renderer.Renderer(net).render(batch)
+        npz('frame_sphere.npz', H=H, crop=crop,
+            **{k: out[k] for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'cpts_map', 'bpts_map', 'resd_map')})
+    elif mode == 'relight':
+        H, crop = 128, 16
+        batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop))
+        cfg.vis_specular_map = True
+        with torch.no_grad():
+            out = sphere_tracing_renderer.Renderer(net).render(batch)
+        npz('frame_relight.npz', H=H, crop=crop, wbounds_after=batch.wbounds,
+            **{k: out[k] for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'albedo_map', 'roughness_map',
+                                   'shade_map', 'spec_map', 'cpts_map', 'bpts_map', 'resd_map')})
+    elif mode == 'novel':
+        from lib.networks.renderer import novel_light_sphere_tracing
+        H, crop = 128, 12
+        batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop, n_novel_lights=3))
+        with torch.no_grad():
+            out = novel_light_sphere_tracing.Renderer(net).render(batch)
+        kw = dict(H=H, crop=crop)
+        for name in out:
+            if name == 'diff':
+                continue
+            for k in ('rgb_map', 'shade_map', 'spec_map', 'acc_map', 'lvis_map', 'ldot_map', 'albedo_map', 'norm_map'):
+                if k in out[name]:
+                    kw[f'{name}.{k}'] = out[name][k]
+        npz('frame_novel.npz', **kw)
+
+
+def gen_ops(net, cfg, synthetic):
+    """Stage-level goldens (relight network = superset of AniSDF stages)."""
+    from lib.utils.base_utils import dotdict
+    from lib.utils import relight_utils, net_utils, sample_utils
+    from lib.networks import embedder
+    from lib.networks.renderer import sphere_tracing_renderer as st
+    g = torch.Generator().manual_seed(123)
+    batch = to_ref_batch(synthetic.make_body(0, posed=True))
+    # --- A: positional encoding
+    x = (torch.rand(64, 3, generator=g) - 0.5) * 2.0
+    kw = dict(pe_x=x)
+    for L in (10, 8, 4):
+        kw[f'pe{L}'] = embedder.PositionalEncoding(L)(x[None])[0]
+    # --- B,C: MLPs on big-pose points
+    bpts = (torch.rand(256, 3, generator=g) - 0.5) * 1.0
+    cond = batch.poses.view(1, -1)
+    with torch.no_grad():
+        resd = net.residual_deformation_network(bpts[None], cond)[0]
+        sdf, feat = net.signed_distance_network.sdf_feat((bpts + resd)[None])
+        occ = net_utils.sdf_to_occ(sdf, net.signed_distance_network.beta)
+        albedo = net.albedo_network(feat)
+        rough = net.roughness_network(feat)
+        view = torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1)
+        nrm = torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1)
+        cfix = batch.train_motion.poses[:, 0].view(1, 1, -1).expand(1, 256, -1)
+        rgb = net.render_network(view[None], nrm[None], feat, cfix)
+    kw.update(mlp_bpts=bpts, mlp_resd=resd, mlp_sdf=sdf[0], mlp_feat=feat[0], mlp_occ=occ[0], mlp_albedo=albedo[0],
+              mlp_rough=rough[0], col_view=view, col_norm=nrm, col_rgb=rgb[0])
+    # --- D,E,F: knn / warp / HDQ on world points around the body
+    wb = batch.wbounds[0]
+    xw = wb[0] + (wb[1] - wb[0]) * torch.rand(4096, 3, generator=g)
+    xw = torch.cat([xw, batch.pverts[0, ::40] @ batch.R[0].T + batch.Th[0] + 0.01 * torch.randn(173, 3, generator=g)])
+    ppts = (xw - batch.Th[0]) @ batch.R[0]
+    with torch.no_grad():
+        sdf_batch, nn_batch, inds, S, d2, nn, _ = sample_utils.geodesic_knn(ppts[None], batch.pverts, batch.pnorm, batch.tverts, batch.tnorm, 3, 0.125)
+        ret = net.world_to_bigpose(xw[None], torch.ones_like(xw)[None] * torch.tensor([0.0, 0.6, 0.8]), batch, dist_th=0.125)
+        hdq = net.inference_world_distance_field(xw[None], batch, smooth_transition=True, dist_th=0.125)
+        hdq_nosmooth = net.inference_world_distance_field(xw[None], batch, smooth_transition=False, dist_th=0.125)
+    fine = torch.zeros(xw.shape[0], dtype=torch.bool)
+    fine[inds[0]] = True
+
+    def scat(v):  # scatter compacted rows back to the full set so the fixture is order-free
+        o = torch.zeros(xw.shape[0], *v.shape[2:], dtype=v.dtype)
+        o[ret.inds[0]] = v[0]
+        return o
+    kw.update(hdq_x=xw, knn_sdf_batch=sdf_batch[0], knn_nn_batch=nn_batch[0], knn_fine=fine,
+              warp_bpts=scat(ret.bpts), warp_tpts=scat(ret.tpts), warp_A_bw=scat(ret.A_bw), warp_big_A_bw=scat(ret.big_A_bw),
+              warp_bvds=scat(ret.bvds), warp_d2=scat(ret.d2), warp_nn=scat(ret.nn), hdq_sdf=hdq[0], hdq_sdf_nosmooth=hdq_nosmooth[0])
+    # --- K: full forward (normals, raw 17)
+    xs = xw[fine][:300]
+    out = net(xs[None], None, 0.005, batch)
+    _, geo = net.forward_geometry(xs[None], None, 0.005, batch)
+    kw.update(fwd_x=xs, fwd_raw=out.raw[0].detach(), fwd_inds=geo.inds[0], fwd_norm_c=geo.norm[0].detach(), fwd_sdf_c=geo.sdf[0].detach())
+    # --- L: light geometry, envmap sampling, microfacet, srgb
+    xyz, area = relight_utils.gen_light_xyz(16, 32, 10, device='cpu')
+    dirs = torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=-1)
+    probe = net.global_env_map.detach()
+    kw.update(light_xyz=xyz, light_area=area, light_sharp=net.light_sharp, env_probe=probe, env_dirs=dirs,
+              env_sample=relight_utils.sample_envmap_image(probe[None], dirs[None])[0])
+    N, L = 40, 512
+    p2l = torch.randn(L, N, 3, generator=g)   # (L,P,3) like surf2light
+    p2c = torch.randn(N, 3, generator=g)
+    nn_ = torch.randn(N, 3, generator=g)
+    alb = torch.rand(N, 3, generator=g)
+    rgh = torch.rand(N, 1, generator=g) * 0.9 + 0.09
+    rgh[:4] = 0.09
+    brdf = net.microfacet(p2l.clone().view(1, 16, 32, N, 3), p2c.clone()[None], nn_.clone()[None], alb.clone()[None], rgh.clone()[None]).view(L, N, 3)
+    lin = torch.cat([torch.linspace(-0.1, 1.2, 200), torch.tensor([0.0, 0.0031308, 0.0031309, 1.0])])
+    kw.update(mf_p2l=p2l, mf_p2c=p2c, mf_n=nn_, mf_albedo=alb, mf_rough=rgh, mf_brdf=brdf, srgb_in=lin, srgb_out=relight_utils.linear2srgb(lin))
+    # --- volume rendering + aabb
+    raw = torch.rand(50, 5, 7, generator=g)
+    al = torch.rand(50, 5, generator=g)
+    al[:5] = 0
+    w_, m_, a_ = net_utils.volume_rendering(raw[None], al[None])
+    ro = (torch.rand(300, 3, generator=g) - 0.5)
+    rd = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1)
+    rd[:3, 0] = 0.0
+    rd[3:6, 1] = 1e-9
+    rd[6:9, 2] = -1e-17
+    bb = torch.tensor([[[-0.6, -0.5, -0.7], [0.6, 0.5, 0.7]]])
+    nr, fr_ = net_utils.get_near_far_aabb(bb, ro[None], rd[None].clone(), return_raw=True)
+    kw.update(vr_raw=raw, vr_alpha=al, vr_weights=w_[0], vr_map=m_[0], vr_acc=a_[0], aabb_o=ro, aabb_d=rd, aabb_bounds=bb[0], aabb_near=nr[0], aabb_far=fr_[0])
+    # --- G: sphere tracing (surface + shadow) through the real HDQ
+    b2 = synthetic.make_batch(128, 128, seed=0, posed=True, crop=20)
+    ray_o, ray_d, near, far = b2.ray_o, b2.ray_d, b2.near, b2.far
+    dec = lambda x, **k: net.inference_world_distance_field(x, batch, smooth_transition=True, **k)
+    with torch.no_grad():
+        surf, edge, occ_, st_, ot_ = st.sphere_tracing(ray_o, ray_d, near, far, dec, None, None)
+        # shadow-style trace with per-ray tan_i
+        tan_i = (9.0 + 20 * torch.rand(1, ray_o.shape[1], 1, generator=g))
+        o2 = surf + 0.0
+        d2_ = torch.nn.functional.normalize(torch.randn(1, ray_o.shape[1], 3, generator=g), dim=-1)
+        surf2, edge2, occ2, st2, ot2 = st.sphere_tracing(o2, d2_, torch.full_like(near, 0.02), torch.full_like(near, 0.8), dec, None, None,
+                                                         iter=4, offset=0.01, relax=0.0, tan_i=tan_i, soft_shadow=True, dist_th=0.125)
+    kw.update(st_o=ray_o[0], st_d=ray_d[0], st_near=near[0], st_far=far[0], st_surf=surf[0], st_occ=occ_[0], st_st=st_[0], st_ot=ot_[0],
+              sh_o=o2[0], sh_d=d2_[0], sh_tan_i=tan_i[0], sh_occ=occ2[0], sh_ot=ot2[0])
+    # --- J: light visibility on a handful of surface points
+    hit = (1 - occ_[0, :, 0]) > 0
+    sp = surf[0][hit][:24]
+    with torch.no_grad():
+        fw = net(sp[None], None, 0.005, batch).raw[0]
+    nrm_s = fw[:, 13:16]
+    nrm_s = torch.where(nrm_s.sum(-1, keepdim=True) == 0, torch.ones_like(nrm_s), nrm_s)
+    nrm_s = net_utils.normalize(nrm_s)
+    acc_s = (1 - occ_[0, :, 0])[hit][:24]
+    bbox = batch.wbounds.clone()
+    bbox[:, 0] -= 0.25
+    bbox[:, 1] += 0.25
+    shadow_dec = lambda o, d, n, f, *a, **k: st.sphere_tracing(o, d, n, f, dec, None, None, *a, **k)
+    with torch.no_grad():
+        lvis, ldot = st.light_visibility(sp[None], nrm_s[None], acc_s[None], net.light_xyz, net.light_sharp, shadow_dec, bbox, **cfg.obj_lvis)
+    kw.update(lv_surf=sp, lv_norm=nrm_s, lv_acc=acc_s, lv_bbox=bbox[0], lv_lvis=lvis[0].reshape(512, -1), lv_ldot=ldot[0].reshape(512, -1))
+    npz('ops.npz', **kw)
+
+
+if __name__ == '__main__':
+    main()
