@@ -1,0 +1,201 @@
+/*
+ * relightableavatar.h — C ABI of the MI355X-native render hot path (librelightableavatar_hip.so).
+ *
+ * The reference (zju3dv/RelightableAvatar) is pure Python and has no FFI of its own; the drop-in
+ * boundary is its plugin API: make_network / make_renderer / Renderer.render(batch)
+ * (lib/networks/make_network.py:4-7, lib/networks/renderer/make_renderer.py:5-8).  The Python
+ * classes in relightableavatar_amd/{networks,renderer} keep that API and bind these entry points
+ * with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; every float* is fp32; "dev" = device (HBM) pointer,
+ *    "host" = host pointer.  stream is a hipStream_t passed as void* (torch's current stream);
+ *    every launch goes on it, no hidden synchronisation except where stated.
+ *  - every function returns 0 on success, non-zero on error; ra_last_error() gives the message
+ *    (thread-local).  The library never calls abort().
+ *  - all mutable state lives in the opaque ra_ctx (packed weights, frame state, scratch arenas,
+ *    work counters).  One ctx per device; a ctx is not thread-safe, distinct ctxs are independent.
+ *  - batch size B is 1 (base.yaml:74 test.batch_size 1); arrays are passed without the batch dim.
+ */
+#ifndef RELIGHTABLEAVATAR_H
+#define RELIGHTABLEAVATAR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RA_ABI_VERSION 1
+#define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
+
+typedef struct ra_ctx ra_ctx;
+
+const char* ra_last_error(void);
+int ra_abi_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int ra_ctx_create(ra_ctx** out, int device);
+int ra_ctx_destroy(ra_ctx* ctx);
+
+/* ---- constants the reference reads from its global cfg (lib/config/config.py) ------------ */
+typedef struct ra_config {
+    int   xyz_res, sdf_res, view_res;         /* 10, 8, 4   (configs/base.yaml:47-49)            */
+    int   n_bones;                            /* 52  -> cond_dim = 3 * n_bones                    */
+    int   relight;                            /* 1: RelightableAvatar heads, 0: AniSDF colour net */
+    float resd_limit;                         /* 0.05 (config.py:224)                             */
+    float blend_radius;                       /* 0.075 (config.py:191)                            */
+    float albedo_slope, albedo_bias;          /* 1.0, 0.0  (config.py:407-408)                    */
+    float roughness_slope, roughness_bias;    /* 0.9, 0.09 (config.py:409-410)                    */
+    float fresnel_f0;                         /* 0.02 (config.py:89)                              */
+    float shading_albedo;                     /* 0.8  (config.py:394)                             */
+    float albedo_multiplier;                  /* 1.0                                              */
+    int   lambert_only, glossy_only;          /* ablation switches (config.py:48-49)              */
+    int   tonemapping;                        /* cfg.tonemapping_rendering                        */
+    float bg_brightness;                      /* 0.0                                              */
+} ra_config;
+int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
+
+/* ---- weights: one call per state_dict entry (SURVEY.md section 8b "weights on disk") ------
+ * name is the reference's state_dict key, data a HOST fp32 array of `numel` elements in
+ * torch's row-major layout.  ra_finalize_weights folds weight_norm (W = g*v/|v|, net_utils.py:
+ * 1326-1327), folds 1/sqrt(2) of the SDF skip (net_utils.py:1345-1346), pads to MFMA tiles,
+ * converts to bf16 fragment order and uploads.  Replaces load_network()+nn.Module parameters
+ * (lib/utils/net_utils.py:1514-1584). */
+int ra_set_weight(ra_ctx* ctx, const char* name, const float* host_data, size_t numel);
+int ra_finalize_weights(ra_ctx* ctx, void* stream);
+
+/* ---- per-frame SMPL state: the batch keys world_to_bigpose consumes
+ * (lib/networks/deform/base_network.py:238-336; schema lib/datasets/base_dataset.py:337-397).
+ * All dev pointers, copied into the ctx (async on stream).  cond_fix = train_motion.poses[:,
+ * fix_material] (base_network.py:501-503), may be NULL for the relight network. */
+typedef struct ra_frame {
+    const float* R;        /* 3x3   */
+    const float* Th;       /* 3     */
+    const float* poses;    /* n_bones*3 (cond)            */
+    const float* cond_fix; /* n_bones*3 or NULL            */
+    const float* A;        /* n_bones x 4 x 4             */
+    const float* big_A;    /* n_bones x 4 x 4             */
+    const float* pverts;   /* n_verts x 3                 */
+    const float* pnorm;    /* n_verts x 3                 */
+    const float* tverts;   /* n_verts x 3                 */
+    const float* weights;  /* n_verts x n_bones           */
+    int n_verts;
+} ra_frame;
+int ra_set_frame(ra_ctx* ctx, const ra_frame* frame, void* stream);
+
+/* ---- operators -------------------------------------------------------------------------- */
+/* Network.inference_world_distance_field (base_network.py:365-387): hierarchical distance
+ * query. x: n x 3 world points -> sdf: n. */
+int ra_hdq_sdf(ra_ctx* ctx, const float* x_dev, int n, float dist_th, int smooth_transition,
+               float* sdf_dev, void* stream);
+
+/* Network.forward in eval mode (relight_network.py:91-104 / base_network.py:496-515).
+ * x, v: n x 3 (v may be NULL for the relight network); raw: n x ra_raw_channels(), zeros for
+ * points farther than dist_th from the body.  Channels: relight [cpts3,bpts3,resd3,albedo3,
+ * roughness1,norm3,occ1] = 17; AniSDF [cpts3,bpts3,resd3,norm3,rgb3,occ1] = 16. */
+int ra_raw_channels(const ra_ctx* ctx);
+int ra_forward(ra_ctx* ctx, const float* x_dev, const float* v_dev, int n, float dist_th,
+               float* raw_dev, void* stream);
+
+/* sphere_tracing (sphere_tracing_renderer.py:20-216, mode 'hdq') over n rays.
+ * tan_i_dev: per-ray sharpness (soft shadow) or NULL -> scalar tan_i.  Outputs may be NULL. */
+typedef struct ra_trace_params {
+    int   iters;            /* 16 surface / 4 shadow                                   */
+    float tan_i;            /* cfg.sphere_tracing.tan_i = 1000 (hard)                  */
+    float tan_i_multiplier; /* 1                                                       */
+    float relax, offset, eps;
+    int   shadow_skip_iter; /* 1                                                       */
+    int   clay_book;        /* !cfg.no_claybook                                        */
+    int   soft_shadow;
+    float dist_th;          /* HDQ threshold forwarded to the distance query           */
+} ra_trace_params;
+int ra_sphere_trace(ra_ctx* ctx, const float* ray_o, const float* ray_d, const float* near_,
+                    const float* far_, const float* tan_i_dev, int n, const ra_trace_params* p,
+                    float* surf, float* occ, float* st, float* ot, void* stream);
+
+/* ---- renderers: one chunk of rays (chunkify, net_utils.py:291-359) ------------------------ */
+typedef struct ra_render_out { /* all dev, all optional (NULL = not wanted); P rays        */
+    float* rgb;        /* P x 3                                                         */
+    float* acc;        /* P                                                             */
+    float* depth;      /* P                                                             */
+    float* surf;       /* P x 3                                                         */
+    float* norm;       /* P x 3                                                         */
+    float* albedo;     /* P x 3   (relight)                                             */
+    float* roughness;  /* P       (relight)                                             */
+    float* shade;      /* P x 3   (relight)                                             */
+    float* spec;       /* P x 3   (relight, cfg.vis_specular_map)                        */
+    float* cpts;       /* P x 3                                                         */
+    float* bpts;       /* P x 3                                                         */
+    float* resd;       /* P x 3                                                         */
+    float* ray_o;      /* P x 3   origins of hit rays, zeros elsewhere                  */
+    float* lvis;       /* P x 512 (cfg.vis_novel_light)                                 */
+    float* ldot;       /* P x 512 (cfg.vis_novel_light)                                 */
+} ra_render_out;
+
+typedef struct ra_sphere_params {
+    ra_trace_params surface;   /* cfg.sphere_tracing                                     */
+    ra_trace_params shadow;    /* cfg.obj_lvis (iter 4, offset .01, dist_th .125)         */
+    float shadow_near_offset;  /* cfg.obj_lvis.near_offset = 0.02                        */
+    float dist_th;             /* cfg.dist_th for the material query                     */
+    float surf_sample_range;   /* 0.005                                                  */
+    int   n_samples;           /* 3                                                      */
+    int   relighting;          /* cfg.relighting                                         */
+    int   no_visibility, local_visibility;
+    int   premultiply;         /* alpha_output_ (sphere_tracing_renderer.py:454-460,1113) */
+} ra_sphere_params;
+
+/* sphere_tracing_renderer.Renderer.get_pixel_value -> render_human (:551-784, :981-1039) for one
+ * chunk.  bbox: 6 floats (min xyz, max xyz) = batch.wbounds AFTER the caller applied the
+ * per-chunk margin growth (quirk: :1020-1022).  probe: env_h2 x env_w2 x 3 linear radiance
+ * (the learned 32x64 map or a novel 16x32 probe); light_xyz/area/sharp: 512 lights. */
+int ra_render_sphere_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, const float* near_,
+                           const float* far_, int P, const float* bbox_host6,
+                           const float* probe_dev, int probe_h, int probe_w,
+                           const ra_sphere_params* p, const ra_render_out* out, void* stream);
+
+/* base_renderer.Renderer.get_pixel_value (base_renderer.py:53-113): uniform samples,
+ * Network.forward per sample, alpha compositing. near/far already clipped by the caller. */
+int ra_render_volume_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, const float* near_,
+                           const float* far_, int P, int n_samples, float dist_th,
+                           const ra_render_out* out, void* stream);
+
+/* novel_light_sphere_tracing.render_human (:21-66): re-shade cached maps under n_probes probes
+ * in one pass.  probes: n_probes x h x w x 3. Outputs n_probes x P x 3 each (may be NULL). */
+int ra_reshade(ra_ctx* ctx, const float* ray_o, const float* surf, const float* norm,
+               const float* albedo, const float* roughness, const float* lvis, const float* ldot,
+               int P, const float* probes_dev, int n_probes, int probe_h, int probe_w,
+               float* rgb, float* shade, float* spec, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+typedef struct ra_counters {       /* cumulative since ra_reset_counters; read with a sync  */
+    uint64_t n_coarse;             /* 3-NN queries (K1)                                       */
+    uint64_t n_fine_sdf;           /* resd+SDF forward, sdf only  (F_sdf  = 1 901 568 FLOP)   */
+    uint64_t n_fine_full;          /* resd+SDF forward+tangents+heads (geometry points)       */
+    uint64_t n_shadow_rays;
+    uint64_t n_hit_pixels;
+    uint64_t n_shaded;             /* pixel x probe shading evaluations                       */
+} ra_counters;
+int ra_get_counters(ra_ctx* ctx, ra_counters* out, void* stream); /* synchronises stream */
+int ra_reset_counters(ra_ctx* ctx, void* stream);
+
+/* time (ms) spent in the fused MLP kernel launches since the last reset, measured with HIP
+ * events on `stream`; n_launches receives the launch count.  Synchronises. */
+int ra_get_mlp_time(ra_ctx* ctx, float* ms, int* n_launches, void* stream);
+int ra_enable_timing(ra_ctx* ctx, int on);
+
+/* ---- test hooks: stage outputs for the parity tests (tests/test_gpu_*.py); not used by renderers ---- */
+/* resd + sdf MLPs on given big-pose points: resd n x 3, sdf n, feat n x 256 (any may be NULL) */
+int ra_debug_mlp(ra_ctx* ctx, const float* bpts_dev, int n, float* resd, float* sdf, float* feat, void* stream);
+/* full kernel with identity warp: d sdf/d bpts n x 3, sdf n, feat n x 256, raw n x C */
+int ra_debug_full(ra_ctx* ctx, const float* bpts_dev, int n, float* grad, float* sdf, float* feat, float* raw, void* stream);
+/* coarse level: per-point coarse sdf n, sdf_batch n x 3, nn_batch n x 3 (int32), filtered d2 n x 3, and for fine points
+ * bpts/tpts n x 3, blended (A|big_A) rows n x 24 (zeros elsewhere); fine_count_host receives the count (synchronises) */
+int ra_debug_hdq(ra_ctx* ctx, const float* x_dev, int n, float dist_th, float* sdf_coarse, float* sdf_batch, int* nn_batch,
+                 float* d2, float* bpts, float* tpts, float* mats, int* fine_count_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELIGHTABLEAVATAR_H */

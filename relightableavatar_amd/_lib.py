@@ -1,0 +1,116 @@
+"""ctypes binding of the C ABI (include/relightableavatar.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no HIP device is
+visible when a context is created, this raises — it never routes through the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librelightableavatar_hip.so')
+_lib = None
+
+
+class RaError(RuntimeError):
+    pass
+
+
+class ra_config(C.Structure):
+    _fields_ = [('xyz_res', C.c_int), ('sdf_res', C.c_int), ('view_res', C.c_int), ('n_bones', C.c_int), ('relight', C.c_int),
+                ('resd_limit', C.c_float), ('blend_radius', C.c_float), ('albedo_slope', C.c_float), ('albedo_bias', C.c_float),
+                ('roughness_slope', C.c_float), ('roughness_bias', C.c_float), ('fresnel_f0', C.c_float),
+                ('shading_albedo', C.c_float), ('albedo_multiplier', C.c_float), ('lambert_only', C.c_int),
+                ('glossy_only', C.c_int), ('tonemapping', C.c_int), ('bg_brightness', C.c_float)]
+
+
+class ra_frame(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('R', 'Th', 'poses', 'cond_fix', 'A', 'big_A', 'pverts', 'pnorm', 'tverts', 'weights')] + \
+               [('n_verts', C.c_int)]
+
+
+class ra_trace_params(C.Structure):
+    _fields_ = [('iters', C.c_int), ('tan_i', C.c_float), ('tan_i_multiplier', C.c_float), ('relax', C.c_float),
+                ('offset', C.c_float), ('eps', C.c_float), ('shadow_skip_iter', C.c_int), ('clay_book', C.c_int),
+                ('soft_shadow', C.c_int), ('dist_th', C.c_float)]
+
+
+RENDER_OUT_KEYS = ('rgb', 'acc', 'depth', 'surf', 'norm', 'albedo', 'roughness', 'shade', 'spec', 'cpts', 'bpts', 'resd',
+                   'ray_o', 'lvis', 'ldot')
+
+
+class ra_render_out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in RENDER_OUT_KEYS]
+
+
+class ra_sphere_params(C.Structure):
+    _fields_ = [('surface', ra_trace_params), ('shadow', ra_trace_params), ('shadow_near_offset', C.c_float),
+                ('dist_th', C.c_float), ('surf_sample_range', C.c_float), ('n_samples', C.c_int), ('relighting', C.c_int),
+                ('no_visibility', C.c_int), ('local_visibility', C.c_int), ('premultiply', C.c_int)]
+
+
+class ra_counters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ('n_coarse', 'n_fine_sdf', 'n_fine_full', 'n_shadow_rays', 'n_hit_pixels', 'n_shaded')]
+
+
+# every symbol include/relightableavatar.h declares
+SYMBOLS = {
+    'ra_last_error': (C.c_char_p, []),
+    'ra_abi_version': (C.c_int, []),
+    'ra_ctx_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    'ra_ctx_destroy': (C.c_int, [C.c_void_p]),
+    'ra_set_config': (C.c_int, [C.c_void_p, C.POINTER(ra_config)]),
+    'ra_set_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    'ra_finalize_weights': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'ra_set_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_frame), C.c_void_p]),
+    'ra_hdq_sdf': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    'ra_raw_channels': (C.c_int, [C.c_void_p]),
+    'ra_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    'ra_sphere_trace': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(ra_trace_params)] + [C.c_void_p] * 5),
+    'ra_render_sphere_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(ra_sphere_params), C.POINTER(ra_render_out), C.c_void_p]),
+    'ra_render_volume_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.POINTER(ra_render_out), C.c_void_p]),
+    'ra_reshade': (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    'ra_get_counters': (C.c_int, [C.c_void_p, C.POINTER(ra_counters), C.c_void_p]),
+    'ra_reset_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'ra_get_mlp_time': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
+    'ra_enable_timing': (C.c_int, [C.c_void_p, C.c_int]),
+    'ra_debug_mlp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ra_debug_full': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ra_debug_hdq': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 7 + [C.POINTER(C.c_int), C.c_void_p]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j8']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RaError('building the HIP extension failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RaError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                      f'(make -C relightableavatar_amd/csrc). There is no CPU fallback for the render path.')
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)      # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if L.ra_abi_version() != 1:
+        raise RaError('ABI version mismatch')
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib().ra_last_error()
+        raise RaError(f'{what}: {msg.decode() if msg else "unknown error"}')

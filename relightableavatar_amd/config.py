@@ -8,6 +8,21 @@ reproduces the mode merges for the BASELINE experiments.
 """
 from .base_utils import dotdict
 
+_ACTIVE = None
+
+
+def set_active_cfg(cfg):
+    """the reference has one global cfg; plugin classes take no arguments and read the active one."""
+    global _ACTIVE
+    _ACTIVE = cfg
+
+
+def active_cfg():
+    global _ACTIVE
+    if _ACTIVE is None:
+        _ACTIVE = default_cfg()
+    return _ACTIVE
+
 
 def default_cfg() -> dotdict:
     c = dotdict()

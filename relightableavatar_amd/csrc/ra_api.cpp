@@ -1,0 +1,613 @@
+// C ABI + orchestration of the render hot path (include/relightableavatar.h).
+// Every entry point only enqueues work on the caller's stream; counts that steer later passes
+// (fine points, hit pixels, shadow rays) stay on the device and kernels size themselves from them.
+#include "ra_ctx.hpp"
+
+#include <cstring>
+
+static thread_local std::string g_err;
+void ra_set_error(const std::string& msg) { g_err = msg; }
+
+#define RA_CHECK(cond, msg)          \
+    do {                             \
+        if (!(cond)) {               \
+            ra_set_error(msg);       \
+            return 1;                \
+        }                            \
+    } while (0)
+
+int DevBuf::ensure(size_t need) {
+    if (need <= bytes && p) return 0;
+    if (need == 0) need = 16;
+    if (p) { hipDeviceSynchronize(); hipFree(p); p = nullptr; bytes = 0; }
+    size_t want = need + need / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { ra_set_error(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); p = nullptr; return 1; }
+    bytes = want;
+    return 0;
+}
+void DevBuf::release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+
+void launch_gather_rows(const int* hit_idx, const int* hit_count, int P, const float* src, int C, float* dst, hipStream_t s);
+
+extern "C" {
+
+const char* ra_last_error(void) { return g_err.c_str(); }
+int ra_abi_version(void) { return RA_ABI_VERSION; }
+
+int ra_ctx_create(ra_ctx** out, int device) {
+    RA_CHECK(out, "ra_ctx_create: null out");
+    int n = 0;
+    RA_HIP(hipGetDeviceCount(&n));
+    RA_CHECK(n > 0, "ra_ctx_create: no HIP device visible (the render path has no CPU fallback)");
+    RA_CHECK(device >= 0 && device < n, "ra_ctx_create: bad device index");
+    RA_HIP(hipSetDevice(device));
+    ra_ctx* c = new ra_ctx();
+    c->device = device;
+    if (c->dcounters.ensure(256)) { delete c; return 1; }
+    RA_HIP(hipMemset(c->dcounters.p, 0, 256));
+    *out = c;
+    return 0;
+}
+
+int ra_ctx_destroy(ra_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    DevBuf* bufs[] = {&c->warena, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
+                      &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
+                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& kv : c->scratch) kv.second.release();
+    for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+    return 0;
+}
+
+int ra_set_config(ra_ctx* c, const ra_config* cfg) {
+    RA_CHECK(c && cfg, "ra_set_config: null argument");
+    RA_CHECK(cfg->n_bones > 0 && cfg->n_bones <= 256, "ra_set_config: bad n_bones");
+    c->cfg = *cfg;
+    c->have_cfg = true;
+    return 0;
+}
+
+int ra_set_weight(ra_ctx* c, const char* name, const float* data, size_t numel) {
+    RA_CHECK(c && name && (data || numel == 0), "ra_set_weight: null argument");
+    c->state_dict[name] = std::vector<float>(data, data + numel);
+    c->have_weights = false;
+    return 0;
+}
+
+static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
+    if (b.ensure(bytes)) return 1;
+    if (bytes) RA_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+int ra_finalize_weights(ra_ctx* c, void* stream) {
+    RA_CHECK(c && c->have_cfg, "ra_finalize_weights: call ra_set_config first");
+    hipStream_t s = (hipStream_t)stream;
+    RA_HIP(hipSetDevice(c->device));
+    std::string err;
+    if (ra_pack_weights(c, err)) { ra_set_error("ra_finalize_weights: " + err); return 1; }
+    HostNets& H = c->host;
+    if (upload(c->warena, H.warena.data(), H.warena.size() * 2, s)) return 1;
+    if (upload(c->barena, H.barena.data(), H.barena.size() * 4, s)) return 1;
+    if (upload(c->cond_r0, H.cond_r0.data(), H.cond_r0.size() * 4, s)) return 1;
+    if (upload(c->cond_r4, H.cond_r4.data(), H.cond_r4.size() * 4, s)) return 1;
+    if (upload(c->b_r0, H.b_r0.data(), H.b_r0.size() * 4, s)) return 1;
+    if (upload(c->b_r4, H.b_r4.data(), H.b_r4.size() * 4, s)) return 1;
+    if (H.has_color) {
+        if (upload(c->cond_c3, H.cond_c3.data(), H.cond_c3.size() * 4, s)) return 1;
+        if (upload(c->b_c3, H.b_c3.data(), H.b_c3.size() * 4, s)) return 1;
+    }
+    if (c->cfg.relight) {
+        c->n_lights = (int)H.light_area.size();
+        if (upload(c->light_xyz, H.light_xyz.data(), H.light_xyz.size() * 4, s)) return 1;
+        if (upload(c->light_area, H.light_area.data(), H.light_area.size() * 4, s)) return 1;
+        if (upload(c->light_sharp, H.light_sharp.data(), H.light_sharp.size() * 4, s)) return 1;
+        if (c->light_dir.ensure(H.light_xyz.size() * 4)) return 1;
+        launch_light_dirs(c->light_xyz.as<float>(), c->n_lights, c->light_dir.as<float>(), s);
+    }
+    RA_HIP(hipStreamSynchronize(s));     // host staging vectors may be reused
+    c->have_weights = true;
+    return 0;
+}
+
+int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
+    RA_CHECK(c && f, "ra_set_frame: null argument");
+    RA_CHECK(c->have_weights, "ra_set_frame: weights not finalized");
+    RA_CHECK(f->R && f->Th && f->poses && f->A && f->big_A && f->pverts && f->pnorm && f->tverts && f->weights, "ra_set_frame: null frame array");
+    RA_CHECK(f->n_verts >= 3, "ra_set_frame: need at least 3 vertices (K=3 neighbours)");
+    hipStream_t s = (hipStream_t)stream;
+    RA_HIP(hipSetDevice(c->device));
+    const int nv = f->n_verts, nb = c->cfg.n_bones, cond = nb * 3;
+    if (c->fR.ensure(9 * 4) || c->fTh.ensure(3 * 4) || c->fvertA.ensure((size_t)nv * 24 * 4) || c->fpverts4.ensure((size_t)nv * 16) ||
+        c->fpnorm.ensure((size_t)nv * 12) || c->ftverts.ensure((size_t)nv * 12) || c->fbias_r0.ensure(1024) || c->fbias_r4.ensure(1024) ||
+        c->fbias_c3.ensure(1024) || c->fcond.ensure((size_t)cond * 4))
+        return 1;
+    RA_HIP(hipMemcpyAsync(c->fR.p, f->R, 36, hipMemcpyDeviceToDevice, s));
+    RA_HIP(hipMemcpyAsync(c->fTh.p, f->Th, 12, hipMemcpyDeviceToDevice, s));
+    RA_HIP(hipMemcpyAsync(c->fpnorm.p, f->pnorm, (size_t)nv * 12, hipMemcpyDeviceToDevice, s));
+    RA_HIP(hipMemcpyAsync(c->ftverts.p, f->tverts, (size_t)nv * 12, hipMemcpyDeviceToDevice, s));
+    launch_pack_verts(f->pverts, nv, c->fpverts4.as<float4>(), s);
+    launch_vert_blend(f->weights, f->A, f->big_A, nv, nb, c->fvertA.as<float>(), s);
+    launch_fold_bias(c->cond_r0.as<float>(), cond, 0, cond, f->poses, c->b_r0.as<float>(), c->fbias_r0.as<float>(), s);
+    launch_fold_bias(c->cond_r4.as<float>(), cond, 0, cond, f->poses, c->b_r4.as<float>(), c->fbias_r4.as<float>(), s);
+    if (c->host.has_color && f->cond_fix)
+        launch_fold_bias(c->cond_c3.as<float>(), cond, 0, cond, f->cond_fix, c->b_c3.as<float>(), c->fbias_c3.as<float>(), s);
+    FrameState& fr = c->fr;
+    fr.R = c->fR.as<float>(); fr.Th = c->fTh.as<float>(); fr.vertA = c->fvertA.as<float>(); fr.pverts4 = c->fpverts4.as<float4>();
+    fr.pnorm = c->fpnorm.as<float>(); fr.tverts = c->ftverts.as<float>(); fr.bias_r0 = c->fbias_r0.as<float>();
+    fr.bias_r4 = c->fbias_r4.as<float>(); fr.bias_c3 = c->fbias_c3.as<float>(); fr.n_verts = nv;
+    c->have_frame = true;
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Timer {
+    ra_ctx* c; hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr;
+    Timer(ra_ctx* c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_) {
+        if (!c->timing) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t x, y;
+            hipEventCreate(&x); hipEventCreate(&y);
+            c->ev_pool.push_back({x, y});
+            c->ev_kind.push_back(0);
+        }
+        c->ev_kind[c->ev_used] = kind;
+        a = c->ev_pool[c->ev_used].first; b = c->ev_pool[c->ev_used].second;
+        c->ev_used++;
+        hipEventRecord(a, s);
+    }
+    ~Timer() { if (a) hipEventRecord(b, s); }
+};
+
+DevCounters* dcnt(ra_ctx* c) { return c->dcounters.as<DevCounters>(); }
+int* icnt(ra_ctx* c, int k) { return reinterpret_cast<int*>(c->dcounters.as<char>() + 128) + k; }   // small int counters
+enum { CNT_FINE = 0, CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3 };
+
+// one hierarchical distance query over the points of rs; writes sdf[n]
+int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s) {
+    if (n <= 0) return 0;
+    int err = 0;
+    int* fine_idx = c->buf<int>("fine_idx", n, &err);
+    float* bpts = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
+    if (err) return 1;
+    HdqOut out{};
+    out.sdf = sdf; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = bpts;
+    out.counters = dcnt(c);
+    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
+    MlpIO io{};
+    io.bpts = bpts; io.idx = fine_idx; io.count = icnt(c, CNT_FINE); io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
+    io.counters = dcnt(c);
+    {
+        Timer t(c, s, 0);
+        launch_mlp_sdf(c->host.geo, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+    }
+    return 0;
+}
+
+// Network.forward (eval) on n (or *n_dev) points: raw[n][C], zero for non-fine points
+int forward_pass(ra_ctx* c, const float* x, const float* v, int n, const int* n_dev, float th, float* raw, hipStream_t s) {
+    if (n <= 0) return 0;
+    int err = 0;
+    const int C = c->cfg.relight ? 17 : 16;
+    int* fine_idx = c->buf<int>("fine_idx", n, &err);
+    float* bpts = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
+    float* mats = c->buf<float>("fine_mats", (size_t)n * 24, &err);
+    float* sdf = c->buf<float>("fwd_sdf", n, &err);
+    if (err) return 1;
+    hipMemsetAsync(raw, 0, (size_t)n * C * sizeof(float), s);
+    RaySet rs{};
+    rs.mode = 0; rs.x = x; rs.n_dev = n_dev;
+    HdqOut out{};
+    out.sdf = sdf; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = bpts; out.mats = mats;
+    out.counters = dcnt(c);
+    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
+    FullIO io{};
+    io.bpts = bpts; io.mats = mats; io.view = v; io.idx = fine_idx; io.count = icnt(c, CNT_FINE); io.raw = raw; io.C = C;
+    io.beta = c->host.beta; io.resd_limit = c->cfg.resd_limit;
+    io.albedo_slope = c->cfg.albedo_slope; io.albedo_bias = c->cfg.albedo_bias;
+    io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
+    io.relight = c->cfg.relight;
+    io.counters = dcnt(c);
+    {
+        Timer t(c, s, 1);
+        launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+    }
+    return 0;
+}
+
+int check_ready(ra_ctx* c, const char* who) {
+    if (!c) { ra_set_error(std::string(who) + ": null ctx"); return 1; }
+    if (!c->have_weights) { ra_set_error(std::string(who) + ": weights not finalized"); return 1; }
+    if (!c->have_frame) { ra_set_error(std::string(who) + ": no frame set (ra_set_frame)"); return 1; }
+    if (hipSetDevice(c->device) != hipSuccess) { ra_set_error(std::string(who) + ": hipSetDevice failed"); return 1; }
+    return 0;
+}
+
+TraceState alloc_trace(ra_ctx* c, const char* pfx, int n, bool soft, int* err) {
+    TraceState ts{};
+    std::string p(pfx);
+    ts.t = c->buf<float>(p + "t", n, err);
+    ts.d0 = c->buf<float>(p + "d0", n, err);
+    ts.occ = c->buf<float>(p + "occ", n, err);
+    ts.ot = c->buf<float>(p + "ot", n, err);
+    if (!soft) {
+        ts.dt = c->buf<float>(p + "dt", n, err);
+        ts.st = c->buf<float>(p + "st", n, err);
+        ts.cd = c->buf<float>(p + "cd", n, err);
+        ts.off = c->buf<float>(p + "off", n, err);
+        ts.rlx = c->buf<float>(p + "rlx", n, err);
+    }
+    return ts;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ra_raw_channels(const ra_ctx* c) { return c && c->cfg.relight ? 17 : 16; }
+
+int ra_hdq_sdf(ra_ctx* c, const float* x, int n, float dist_th, int smooth, float* sdf, void* stream) {
+    if (check_ready(c, "ra_hdq_sdf")) return 1;
+    RA_CHECK(n >= 0 && (n == 0 || (x && sdf)), "ra_hdq_sdf: bad arguments");
+    RaySet rs{};
+    rs.mode = 0; rs.x = x;
+    if (hdq_pass(c, rs, n, dist_th, smooth, sdf, (hipStream_t)stream)) return 1;
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_forward(ra_ctx* c, const float* x, const float* v, int n, float dist_th, float* raw, void* stream) {
+    if (check_ready(c, "ra_forward")) return 1;
+    RA_CHECK(n >= 0 && (n == 0 || (x && raw)), "ra_forward: bad arguments");
+    RA_CHECK(c->cfg.relight || v || n == 0, "ra_forward: the AniSDF colour net needs view directions");
+    if (forward_pass(c, x, v, n, nullptr, dist_th, raw, (hipStream_t)stream)) return 1;
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const float* near_, const float* far_, const float* tan_i,
+                    int n, const ra_trace_params* p, float* surf, float* occ, float* st, float* ot, void* stream) {
+    if (check_ready(c, "ra_sphere_trace")) return 1;
+    RA_CHECK(p && n >= 0 && (n == 0 || (ray_o && ray_d && near_ && far_)), "ra_sphere_trace: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    TraceState ts = alloc_trace(c, "tr_", n, false, &err);   // full state for either mode
+    float* sdf = c->buf<float>("tr_sdf", n, &err);
+    if (err) return 1;
+    ts.near_ = near_; ts.far_ = far_; ts.tan_i = tan_i; ts.light = nullptr;
+    launch_trace_init(ts, n, nullptr, *p, s);
+    RaySet rs{};
+    rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t;
+    for (int it = 0; it < p->iters; ++it) {
+        if (hdq_pass(c, rs, n, p->dist_th, 1, sdf, s)) return 1;
+        launch_trace_update(ts, sdf, n, nullptr, it, *p, s);
+    }
+    if (occ) RA_HIP(hipMemcpyAsync(occ, ts.occ, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    if (st) RA_HIP(hipMemcpyAsync(st, ts.st, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    if (ot) RA_HIP(hipMemcpyAsync(ot, ts.ot, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    if (surf) {
+        float* depth = c->buf<float>("tr_depth", n, &err);
+        float* acc = c->buf<float>("tr_acc", n, &err);
+        int* hidx = c->buf<int>("tr_hidx", n, &err);
+        if (err) return 1;
+        launch_surface_finish(ray_o, ray_d, ts.st, ts.occ, n, surf, depth, acc, hidx, icnt(c, CNT_HIT), s);
+    }
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P,
+                           const float* bbox, const float* probe, int ph, int pw, const ra_sphere_params* p,
+                           const ra_render_out* out, void* stream) {
+    if (check_ready(c, "ra_render_sphere_chunk")) return 1;
+    RA_CHECK(p && out && P >= 0, "ra_render_sphere_chunk: bad arguments");
+    if (P == 0) return 0;
+    RA_CHECK(ray_o && ray_d && near_ && far_, "ra_render_sphere_chunk: null ray arrays");
+    const bool relit = p->relighting != 0;
+    RA_CHECK(!relit || (c->cfg.relight && probe && bbox && c->n_lights > 0), "ra_render_sphere_chunk: relighting needs the relight network, a probe and a bbox");
+    RA_CHECK(p->n_samples >= 1 && p->n_samples <= 16, "ra_render_sphere_chunk: n_samples out of range");
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    const int S = p->n_samples, C = c->cfg.relight ? 17 : 16, L = c->n_lights;
+    // ---- surface trace (HOT LOOP A)
+    TraceState ts = alloc_trace(c, "sf_", P, false, &err);
+    float* sdf = c->buf<float>("sf_sdf", P, &err);
+    float* surf = c->buf<float>("sf_surf", (size_t)P * 3, &err);
+    float* depth = c->buf<float>("sf_depth", P, &err);
+    float* acc = c->buf<float>("sf_acc", P, &err);
+    int* hit_idx = c->buf<int>("sf_hit", P, &err);
+    if (err) return 1;
+    ts.near_ = near_; ts.far_ = far_;
+    launch_trace_init(ts, P, nullptr, p->surface, s);
+    RaySet rs{};
+    rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t;
+    for (int it = 0; it < p->surface.iters; ++it) {
+        if (hdq_pass(c, rs, P, p->surface.dist_th, 1, sdf, s)) return 1;
+        launch_trace_update(ts, sdf, P, nullptr, it, p->surface, s);
+    }
+    int* hit_count = icnt(c, CNT_HIT);
+    launch_surface_finish(ray_o, ray_d, ts.st, ts.occ, P, surf, depth, acc, hit_idx, hit_count, s);
+    launch_accumulate(hit_count, &dcnt(c)->n_hit_pixels, s);
+    // ---- material query on S samples around each hit (render_human :602-620)
+    float* xs = c->buf<float>("mt_x", (size_t)P * S * 3, &err);
+    float* vs = c->buf<float>("mt_v", (size_t)P * S * 3, &err);
+    float* raw = c->buf<float>("mt_raw", (size_t)P * S * C, &err);
+    SurfaceMaps m{};
+    m.cpts = c->buf<float>("mp_cpts", (size_t)P * 3, &err);
+    m.bpts = c->buf<float>("mp_bpts", (size_t)P * 3, &err);
+    m.resd = c->buf<float>("mp_resd", (size_t)P * 3, &err);
+    m.norm = c->buf<float>("mp_norm", (size_t)P * 3, &err);
+    m.albedo = c->buf<float>("mp_albedo", (size_t)P * 3, &err);
+    m.rough = c->buf<float>("mp_rough", P, &err);
+    m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
+    if (err) return 1;
+    launch_surface_samples(surf, ray_d, hit_idx, hit_count, P, S, p->surf_sample_range, xs, vs, icnt(c, CNT_SAMP), s);
+    if (forward_pass(c, xs, vs, P * S, icnt(c, CNT_SAMP), p->dist_th, raw, s)) return 1;
+    launch_surface_composite(raw, C, S, hit_count, P, c->cfg.relight, c->cfg, m, s);
+    // ---- light visibility + shading (HOT LOOP B)
+    float *lvis = nullptr, *ldot = nullptr, *shade = nullptr, *spec = nullptr;
+    if (relit) {
+        const size_t NR = (size_t)P * L;
+        lvis = c->buf<float>("lv_lvis", NR, &err);
+        ldot = c->buf<float>("lv_ldot", NR, &err);
+        ShadowGen g{};
+        g.surf = surf; g.norm = m.norm; g.acc = acc; g.hit_idx = hit_idx; g.hit_count = hit_count; g.ldir = c->light_dir.as<float>();
+        for (int k = 0; k < 6; ++k) g.bbox[k] = bbox[k];
+        g.near_offset = p->shadow_near_offset; g.L = L; g.no_visibility = p->no_visibility; g.local_visibility = p->local_visibility;
+        g.lvis = lvis; g.ldot = ldot;
+        const bool traced = !(p->no_visibility || p->local_visibility);
+        if (traced) {
+            g.ray_pix = c->buf<int>("lv_pix", NR, &err);
+            g.ray_light = c->buf<int>("lv_light", NR, &err);
+            g.ray_slot = c->buf<int>("lv_slot", NR, &err);
+            g.near_ = c->buf<float>("lv_near", NR, &err);
+            g.far_ = c->buf<float>("lv_far", NR, &err);
+        }
+        g.ray_count = icnt(c, CNT_RAYS);
+        TraceState sh{};
+        float* ssdf = nullptr;
+        if (traced) {
+            sh = alloc_trace(c, "sh_", (int)NR, true, &err);
+            ssdf = c->buf<float>("sh_sdf", NR, &err);
+        }
+        if (err) return 1;
+        launch_shadow_gen(g, P, s);
+        if (traced) {
+            sh.near_ = g.near_; sh.far_ = g.far_; sh.tan_i = c->light_sharp.as<float>(); sh.light = g.ray_light;
+            launch_trace_init(sh, (int)NR, g.ray_count, p->shadow, s);
+            RaySet r2{};
+            r2.mode = 2; r2.o = surf; r2.t = sh.t; r2.pix = g.ray_pix; r2.light = g.ray_light; r2.ldir = c->light_dir.as<float>();
+            r2.n_dev = g.ray_count;
+            for (int it = 0; it < p->shadow.iters; ++it) {
+                if (hdq_pass(c, r2, (int)NR, p->shadow.dist_th, 1, ssdf, s)) return 1;
+                launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, p->shadow, s);
+            }
+            launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
+            launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);
+        }
+        m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
+        shade = c->buf<float>("mp_shade", (size_t)P * 3, &err);
+        spec = c->buf<float>("mp_spec", (size_t)P * 3, &err);
+        if (err) return 1;
+        ShadeIn in{};
+        in.ray_o = ray_o; in.surf = surf; in.idx = hit_idx; in.count = hit_count; in.n = P;
+        in.norm = m.norm; in.albedo = m.albedo; in.rough = m.rough; in.lvis = lvis; in.ldot = ldot;
+        in.light_xyz = c->light_xyz.as<float>(); in.light_area = c->light_area.as<float>(); in.L = L;
+        in.probes = probe; in.n_probes = 1; in.ph = ph; in.pw = pw; in.want_spec = out->spec != nullptr;
+        in.rgb = m.rgb; in.shade = shade; in.spec = spec;
+        launch_shade(in, c->cfg, s);
+        c->n_shaded += 0;   // counted on device via hit pixels
+    }
+    // ---- scatter to the full ray set (zeros elsewhere), premultiplied by acc (alpha_output_)
+    const int pm = p->premultiply;
+    auto scat = [&](float* dst, const float* src, int Cc, bool premul, bool src_full) {
+        if (!dst) return;
+        hipMemsetAsync(dst, 0, (size_t)P * Cc * sizeof(float), s);
+        launch_scatter_maps(hit_idx, hit_count, P, premul ? 1 : 0, acc, src, Cc, dst, src_full ? 1 : 0, s);
+    };
+    scat(out->acc, acc, 1, false, true);
+    scat(out->depth, depth, 1, pm, true);
+    scat(out->surf, surf, 3, pm, true);
+    scat(out->ray_o, ray_o, 3, false, true);
+    scat(out->norm, m.norm, 3, pm, false);
+    scat(out->cpts, m.cpts, 3, pm, false);
+    scat(out->bpts, m.bpts, 3, pm, false);
+    scat(out->resd, m.resd, 3, false, false);
+    scat(out->rgb, m.rgb, 3, pm, false);
+    if (c->cfg.relight) {
+        scat(out->albedo, m.albedo, 3, pm, false);
+        scat(out->roughness, m.rough, 1, pm, false);
+    }
+    if (relit) {
+        scat(out->shade, shade, 3, pm, false);
+        scat(out->spec, spec, 3, pm, false);
+        scat(out->lvis, lvis, L, pm, false);
+        scat(out->ldot, ldot, L, pm, false);
+    }
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_render_volume_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P,
+                           int n_samples, float dist_th, const ra_render_out* out, void* stream) {
+    if (check_ready(c, "ra_render_volume_chunk")) return 1;
+    RA_CHECK(out && P >= 0 && n_samples >= 1, "ra_render_volume_chunk: bad arguments");
+    if (P == 0) return 0;
+    RA_CHECK(ray_o && ray_d && near_ && far_, "ra_render_volume_chunk: null ray arrays");
+    RA_CHECK(!c->cfg.relight, "ra_render_volume_chunk: volume rendering is wired for the AniSDF network (base_renderer)");
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    const int S = n_samples, C = 16;
+    const size_t N = (size_t)P * S;
+    RA_CHECK(N < (1u << 30), "ra_render_volume_chunk: chunk too large");
+    float* xs = c->buf<float>("vl_x", N * 3, &err);
+    float* vs = c->buf<float>("vl_v", N * 3, &err);
+    float* raw = c->buf<float>("vl_raw", N * C, &err);
+    if (err) return 1;
+    launch_volume_samples(ray_o, ray_d, near_, far_, P, S, xs, vs, s);
+    if (forward_pass(c, xs, vs, (int)N, nullptr, dist_th, raw, s)) return 1;
+    launch_volume_composite(raw, C, near_, far_, P, S, c->cfg.bg_brightness, *out, s);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_reshade(ra_ctx* c, const float* ray_o, const float* surf, const float* norm, const float* albedo, const float* roughness,
+               const float* lvis, const float* ldot, int P, const float* probes, int n_probes, int ph, int pw, float* rgb,
+               float* shade, float* spec, void* stream) {
+    RA_CHECK(c && c->have_weights && c->cfg.relight, "ra_reshade: needs a relight ctx with weights");
+    RA_CHECK(P >= 0 && n_probes >= 0, "ra_reshade: bad sizes");
+    if (P == 0 || n_probes == 0) return 0;
+    RA_CHECK(ray_o && surf && norm && albedo && roughness && lvis && ldot && probes, "ra_reshade: null input");
+    RA_HIP(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    for (int q0 = 0; q0 < n_probes; q0 += 8) {
+        const int nq = n_probes - q0 < 8 ? n_probes - q0 : 8;
+        ShadeIn in{};
+        in.ray_o = ray_o; in.surf = surf; in.idx = nullptr; in.count = nullptr; in.n = P;
+        in.norm = norm; in.albedo = albedo; in.rough = roughness; in.lvis = lvis; in.ldot = ldot;
+        in.light_xyz = c->light_xyz.as<float>(); in.light_area = c->light_area.as<float>(); in.L = c->n_lights;
+        in.probes = probes + (size_t)q0 * ph * pw * 3; in.n_probes = nq; in.ph = ph; in.pw = pw; in.want_spec = spec != nullptr;
+        in.rgb = rgb ? rgb + (size_t)q0 * P * 3 : nullptr;
+        in.shade = shade ? shade + (size_t)q0 * P * 3 : nullptr;
+        in.spec = spec ? spec + (size_t)q0 * P * 3 : nullptr;
+        ra_config cfg = c->cfg;
+        cfg.tonemapping = 1;      // novel_light_sphere_tracing.py:47 applies linear2srgb unconditionally
+        launch_shade(in, cfg, s);
+    }
+    c->n_shaded += (uint64_t)P * n_probes;
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_get_counters(ra_ctx* c, ra_counters* out, void* stream) {
+    RA_CHECK(c && out, "ra_get_counters: null argument");
+    RA_HIP(hipSetDevice(c->device));
+    RA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long h[8];
+    RA_HIP(hipMemcpy(h, c->dcounters.p, sizeof(h), hipMemcpyDeviceToHost));
+    out->n_coarse = h[0];
+    out->n_fine_sdf = h[1];
+    out->n_fine_full = h[2];
+    out->n_shadow_rays = h[3];
+    out->n_hit_pixels = h[4];
+    out->n_shaded = c->n_shaded + h[4];
+    return 0;
+}
+
+int ra_reset_counters(ra_ctx* c, void* stream) {
+    RA_CHECK(c, "ra_reset_counters: null ctx");
+    RA_HIP(hipSetDevice(c->device));
+    RA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    RA_HIP(hipMemset(c->dcounters.p, 0, 64));
+    c->n_coarse = 0;
+    c->n_shaded = 0;
+    c->ev_used = 0;
+    return 0;
+}
+
+int ra_enable_timing(ra_ctx* c, int on) {
+    RA_CHECK(c, "ra_enable_timing: null ctx");
+    c->timing = on != 0;
+    return 0;
+}
+
+int ra_get_mlp_time(ra_ctx* c, float* ms, int* n_launches, void* stream) {
+    RA_CHECK(c && ms && n_launches, "ra_get_mlp_time: null argument");
+    RA_HIP(hipSetDevice(c->device));
+    RA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    float tot = 0.f;
+    int n = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        if (c->ev_kind[i] != 0) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { tot += t; ++n; }
+    }
+    *ms = tot;
+    *n_launches = n;
+    return 0;
+}
+
+// ---- test hooks: stage outputs for parity tests (not used by the renderers) -------------------
+int ra_debug_mlp(ra_ctx* c, const float* bpts, int n, float* resd, float* sdf, float* feat, void* stream) {
+    if (check_ready(c, "ra_debug_mlp")) return 1;
+    if (n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    int* cnt = icnt(c, CNT_FINE);
+    int* idx = c->buf<int>("fine_idx", n, &err);
+    if (err) return 1;
+    RA_HIP(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    RA_HIP(hipStreamSynchronize(s));
+    MlpIO io{};
+    io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = nullptr; io.dist_th = 1.f; io.smooth = 0;
+    io.dbg_resd = resd; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
+    launch_mlp_sdf(c->host.geo, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_debug_full(ra_ctx* c, const float* bpts, int n, float* grad, float* sdf, float* feat, float* raw, void* stream) {
+    if (check_ready(c, "ra_debug_full")) return 1;
+    if (n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    const int C = c->cfg.relight ? 17 : 16;
+    int* cnt = icnt(c, CNT_FINE);
+    int* idx = c->buf<int>("fine_idx", n, &err);
+    float* view = c->buf<float>("dbg_view", (size_t)n * 3, &err);
+    if (err) return 1;
+    std::vector<int> h(n);
+    for (int i = 0; i < n; ++i) h[i] = i;
+    RA_HIP(hipMemcpyAsync(idx, h.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    RA_HIP(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    RA_HIP(hipMemsetAsync(view, 0, (size_t)n * 12, s));
+    RA_HIP(hipStreamSynchronize(s));
+    FullIO io{};
+    io.bpts = bpts; io.mats = nullptr; io.view = view; io.idx = idx; io.count = cnt; io.raw = raw; io.C = C;
+    io.beta = c->host.beta; io.resd_limit = c->cfg.resd_limit;
+    io.albedo_slope = c->cfg.albedo_slope; io.albedo_bias = c->cfg.albedo_bias;
+    io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
+    io.relight = c->cfg.relight;
+    io.dbg_grad = grad; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
+    launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_debug_hdq(ra_ctx* c, const float* x, int n, float th, float* sdf_coarse, float* sdf_batch, int* nn_batch, float* d2,
+                 float* bpts, float* tpts, float* mats, int* fine_count_host, void* stream) {
+    if (check_ready(c, "ra_debug_hdq")) return 1;
+    if (n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    int* fine_idx = c->buf<int>("fine_idx", n, &err);
+    float* fb = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
+    if (err) return 1;
+    RaySet rs{};
+    rs.mode = 0; rs.x = x;
+    HdqOut out{};
+    out.sdf = sdf_coarse; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = fb;
+    out.dbg_sdf_batch = sdf_batch; out.dbg_nn_batch = nn_batch; out.dbg_d2 = d2; out.dbg_bpts = bpts; out.dbg_tpts = tpts; out.dbg_mats = mats;
+    out.counters = nullptr;
+    RA_HIP(hipMemsetAsync(bpts, 0, (size_t)n * 12, s));
+    RA_HIP(hipMemsetAsync(tpts, 0, (size_t)n * 12, s));
+    RA_HIP(hipMemsetAsync(mats, 0, (size_t)n * 96, s));
+    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
+    RA_HIP(hipStreamSynchronize(s));
+    RA_HIP(hipMemcpy(fine_count_host, icnt(c, CNT_FINE), sizeof(int), hipMemcpyDeviceToHost));
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

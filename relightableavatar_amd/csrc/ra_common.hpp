@@ -1,0 +1,123 @@
+// Shared declarations of the gfx950 render hot path (see include/relightableavatar.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/relightableavatar.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------
+// Packed network (bf16, MFMA fragment order) — built by ra_pack.cpp, consumed by ra_mlp.hip.
+// A "wide" layer has 256 output rows; its weights are stored as
+//   [nb = 8 row blocks of 32][ks = K/16][lane = 64][8 bf16]
+// so that one wave-wide 16-byte load per lane yields the A fragment of
+// v_mfma_f32_32x32x16_bf16 (lane l: row 32*nb + (l&31), k = 16*ks + 8*(l>>5) + 0..7).
+// A "head" layer has <= 32 output rows and the same layout with nb = 1.
+// Offsets are in units of bf16x8 (16 bytes) into the weight arena, biases in floats.
+// ---------------------------------------------------------------------------------------------
+struct WideLayer { uint32_t w; uint32_t ks; uint32_t bias; };
+
+struct GeoNet {             // residual deformation + signed distance networks
+    // residual net (base_network.py:14-42): L0 K=64 (PE10 padded), L1-3, L4 = L4a (K=256) + L4b (K=64, PE skip), L5-7, head 3
+    WideLayer r[8];         // r[0]..r[7] (r[4] = the 256-wide part of the skip layer)
+    WideLayer r4b;          // PE part of the skip layer (bias unused)
+    WideLayer rhead;        // 256 -> 3 (rows padded to 32)
+    // sdf net (net_utils.py:1276-1352): l0 K=64 (PE8 padded), l1,l2, l3 (205 rows + 51 zero rows), l4..l7 (1/sqrt2 folded into l4), l8
+    WideLayer s[8];
+    WideLayer shead;        // row 0 = sdf
+    WideLayer sfeat;        // rows = feat 0..255 (lin8 rows 1..256)
+    // per-frame folded biases for r[0] and r[4] live in frame state (cond folded in)
+};
+
+struct MatNet {             // albedo + roughness heads fused block-diagonally (relight_network.py:45-47)
+    WideLayer m0;           // 256 -> [128 albedo | 128 roughness]
+    WideLayer m1;           // block diagonal 256 -> 256
+    WideLayer mhead;        // rows 0..2 albedo (cols 0..127), row 3 roughness (cols 128..255)
+};
+
+struct ColNet {             // RenderNetwork (base_network.py:132-171)
+    WideLayer c0a;          // feat part of l0 (K=256)
+    WideLayer c0b;          // [PE4(view) 27, norm 3, pad 2] part of l0 (K=32)
+    WideLayer c1, c2, c3;   // c3's cond slice folded into a per-frame bias
+    WideLayer chead;        // 256 -> 3
+};
+
+// tile geometry of the fused MLP kernels
+constexpr int TM = 128;     // columns (points, or point x {primal,tx,ty,tz}) per workgroup tile
+constexpr int XS = 264;     // LDS row stride in bf16 (528 B = 16 * 33: conflict-free ds_read_b128)
+constexpr int MLP_THREADS = 256;
+
+struct FrameState {         // device pointers owned by the ctx
+    float* R;        // 9
+    float* Th;       // 3
+    float* vertA;    // n_verts x 24: per-vertex blended (A | big_A) rows 0..2 (3x4 each)
+    float4* pverts4; // n_verts (x,y,z,0)
+    float* pnorm;    // n_verts x 3
+    float* tverts;   // n_verts x 3
+    float* bias_r0;  // 256: b_r0 + W_r0[:, 63:219] cond
+    float* bias_r4;  // 256
+    float* bias_c3;  // 256 (colour net, cond_fix)
+    int n_verts;
+};
+
+struct DevCounters {       // device-side work counters (ra_get_counters)
+    unsigned long long n_coarse, n_fine_sdf, n_fine_full, n_shadow_rays, n_hit_pixels;
+};
+
+struct MlpIO {
+    const float* bpts;      // n_slots x 3 big-pose points (compacted)
+    const int* idx;         // n_slots: point index of each slot
+    const int* count;       // device: number of valid slots
+    float* sdf;             // per point: in = coarse smpl sdf, out = blended HDQ sdf
+    float dist_th;
+    int smooth;
+    // debug / stage outputs (nullable)
+    float* dbg_resd;        // n_slots x 3
+    float* dbg_sdf;         // n_slots (raw network sdf)
+    float* dbg_feat;        // n_slots x 256
+    DevCounters* counters;  // nullable
+};
+
+struct FullIO {             // geometry + material / colour forward with tangents
+    const float* bpts;      // n_slots x 3
+    const float* mats;      // n_slots x 24 (A_bw rows | big_A_bw rows), nullable -> identity
+    const float* view;      // n_points x 3 world view dirs (AniSDF), nullable
+    const int* idx;
+    const int* count;
+    float* raw;             // n_points x C, scattered by idx
+    int C;
+    float beta;             // clamp(_beta, 1e-9, 1e6)
+    float resd_limit;
+    float albedo_slope, albedo_bias, rough_slope, rough_bias;
+    int relight;
+    // debug (nullable)
+    float* dbg_grad;        // n_slots x 3  d sdf / d bpts
+    float* dbg_feat;        // n_slots x 256
+    float* dbg_sdf;         // n_slots
+    DevCounters* counters;  // nullable
+};
+
+void launch_mlp_sdf(const GeoNet& net, const bf16x8* warena, const float* barena, const FrameState& fr,
+                    const MlpIO& io, int max_slots, hipStream_t stream);
+void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const bf16x8* warena,
+                     const float* barena, const FrameState& fr, const FullIO& io, int max_slots, hipStream_t stream);
+
+// --- error plumbing ---------------------------------------------------------------------------
+void ra_set_error(const std::string& msg);
+#define RA_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ra_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)

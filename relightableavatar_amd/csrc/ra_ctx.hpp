@@ -1,0 +1,55 @@
+// The opaque context behind the C ABI: packed weights, frame state, scratch arenas, counters.
+#pragma once
+#include "ra_kernels.hpp"
+
+struct HostNets {
+    GeoNet geo{};
+    MatNet mat{};
+    ColNet col{};
+    bool has_color = false;
+    float beta = 0.1f;
+    std::vector<uint16_t> warena;
+    std::vector<float> barena;
+    std::vector<float> cond_r0, b_r0, cond_r4, b_r4, cond_c3, b_c3;   // fp32 cond slices [256][cond]
+    std::vector<float> light_xyz, light_area, light_sharp;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);   // grow-only; returns non-zero on failure
+    void release();
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ra_ctx {
+    int device = 0;
+    ra_config cfg{};
+    bool have_cfg = false, have_weights = false, have_frame = false;
+    std::map<std::string, std::vector<float>> state_dict;
+    HostNets host;
+    // device copies
+    DevBuf warena, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
+    int n_lights = 0;
+    // frame
+    FrameState fr{};
+    DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond;
+    // scratch (grow-only)
+    std::map<std::string, DevBuf> scratch;
+    DevBuf dcounters;       // DevCounters + small int counters
+    // host-side counters
+    uint64_t n_coarse = 0, n_shaded = 0;
+    // timing of the fused MLP launches
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_kind;      // 0: mlp_sdf launch, 1: mlp_full launch
+    size_t ev_used = 0;
+
+    template <typename T> T* buf(const std::string& name, size_t count, int* err) {
+        DevBuf& b = scratch[name];
+        if (b.ensure(count * sizeof(T))) { *err = 1; return nullptr; }
+        return b.as<T>();
+    }
+};
+
+int ra_pack_weights(ra_ctx* ctx, std::string& err);

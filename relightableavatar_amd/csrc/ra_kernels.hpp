@@ -1,0 +1,118 @@
+// Launchers of the non-MLP kernels (ra_hdq.hip, ra_trace.hip).
+#pragma once
+#include "ra_common.hpp"
+
+// where the query points of a pass come from
+struct RaySet {
+    int mode;             // 0: x[i];  1: o[i] + t[i] d[i];  2: o[pix[i]] + t[i] ldir[light[i]]
+    const float* x;       // mode 0: n x 3
+    const float* o;       // mode 1: n x 3; mode 2: n_pix x 3
+    const float* d;       // mode 1: n x 3
+    const float* t;       // modes 1,2: n
+    const int* pix;       // mode 2
+    const int* light;     // mode 2
+    const float* ldir;    // mode 2: n_lights x 3 (unit)
+    const int* n_dev;     // optional device-side count (<= n launched); nullptr -> n
+};
+
+struct HdqOut {
+    float* sdf;           // n: coarse signed distance (smpl_sdf after the abs rule)
+    int* fine_count;      // device counter, zeroed by the launcher
+    int* fine_idx;        // slot -> point
+    float* bpts;          // slot x 3
+    float* mats;          // slot x 24 or nullptr
+    // debug (nullable): per point
+    float* dbg_sdf_batch; // n x 3
+    int* dbg_nn_batch;    // n x 3
+    float* dbg_d2;        // n x 3 (filtered)
+    float* dbg_tpts;      // slot-ordered? no: per point n x 3 (only fine points written)
+    float* dbg_bpts;      // n x 3
+    float* dbg_mats;      // n x 24
+    DevCounters* counters; // nullable
+};
+
+void launch_vert_blend(const float* weights, const float* A, const float* big_A, int n_verts, int n_bones, float* vertA,
+                       hipStream_t s);
+void launch_pack_verts(const float* pverts, int n_verts, float4* out, hipStream_t s);
+void launch_fold_bias(const float* W, int ld, int col0, int ncond, const float* cond, const float* bias, float* out,
+                      hipStream_t s);   // out[r] = bias[r] + sum_c W[r*ld + col0 + c] * cond[c], r < 256
+void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
+                       hipStream_t s);
+
+struct TraceState {       // SoA per ray
+    float *t, *d0, *dt, *st, *ot, *cd, *occ, *off, *rlx;
+    const float *near_, *far_;
+    const float* tan_i;   // per ray (mode 1) or per light (mode 2) or nullptr -> scalar
+    const int* light;     // mode 2
+};
+void launch_trace_init(const TraceState& ts, int n, const int* n_dev, const ra_trace_params& p, hipStream_t s);
+void launch_trace_update(const TraceState& ts, const float* sdf, int n, const int* n_dev, int iter,
+                         const ra_trace_params& p, hipStream_t s);
+
+// surface pass epilogue: surf/depth/acc, hit compaction
+void launch_surface_finish(const float* ray_o, const float* ray_d, const float* st, const float* occ, int P, float* surf,
+                           float* depth, float* acc, int* hit_idx, int* hit_count, hipStream_t s);
+// 3 (S) samples per hit pixel: x = surf + z * view
+void launch_surface_samples(const float* surf, const float* ray_d, const int* hit_idx, const int* hit_count, int P, int S,
+                            float range, float* x, float* v, int* n_out, hipStream_t s);
+// per hit pixel: composite S samples of raw (C channels, last = occ), normalise, split
+struct SurfaceMaps {      // per hit slot
+    float *cpts, *bpts, *resd, *norm, *albedo, *rough, *rgb;
+};
+void launch_surface_composite(const float* raw, int C, int S, const int* hit_count, int P, int relight, const ra_config& cfg,
+                              const SurfaceMaps& m, hipStream_t s);
+
+// shadow rays
+struct ShadowGen {
+    const float* surf;    // P x 3 (full ray indexing)
+    const float* norm;    // hit-slot x 3
+    const float* acc;     // P
+    const int* hit_idx;   // slot -> ray
+    const int* hit_count;
+    const float* ldir;    // L x 3 unit light directions
+    float bbox[6];
+    float near_offset;
+    int L;
+    int no_visibility, local_visibility;
+    // out
+    float* lvis;          // slot x L
+    float* ldot;          // slot x L
+    int* ray_pix;         // ray -> full ray index (origin = surf[pix])
+    int* ray_light;
+    int* ray_slot;        // ray -> slot*L + light (where occ lands)
+    float *near_, *far_;
+    int* ray_count;
+};
+void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s);
+void launch_shadow_scatter(const float* occ, const int* ray_slot, const int* ray_count, int max_rays, float* lvis, hipStream_t s);
+
+struct ShadeIn {
+    const float* ray_o;   // indexed by ray (idx != null) or by slot
+    const float* surf;    // same indexing
+    const int* idx;       // slot -> ray or nullptr (identity)
+    const int* count;     // device count or nullptr -> n
+    int n;
+    const float *norm, *albedo, *rough;   // per slot
+    const float *lvis, *ldot;             // slot x L
+    const float *light_xyz, *light_area;  // L x 3, L
+    int L;
+    const float* probes;  // n_probes x h x w x 3
+    int n_probes, ph, pw;
+    int want_spec;
+    float *rgb, *shade, *spec;            // n_probes x n x 3 (slot indexed)
+};
+void launch_shade(const ShadeIn& in, const ra_config& cfg, hipStream_t s);
+
+// scatter hit-slot maps into full-ray outputs (zeros elsewhere), optional premultiplication by acc
+// src_full: src is indexed by ray (like dst) instead of by hit slot
+void launch_scatter_maps(const int* hit_idx, const int* hit_count, int P, int premultiply, const float* acc_full,
+                         const float* src, int C, float* dst, int src_full, hipStream_t s);
+void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s);
+
+// volume path
+void launch_volume_samples(const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P, int S,
+                           float* x, float* v, hipStream_t s);
+void launch_volume_composite(const float* raw, int C, const float* near_, const float* far_, int P, int S, float bg,
+                             const ra_render_out& out, hipStream_t s);
+void launch_fill(float* p, size_t n, float v, hipStream_t s);
+void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s);

@@ -1,0 +1,604 @@
+// Fused MLP kernels for gfx950 (MI355X): residual-deformation + signed-distance networks evaluated
+// back to back on a tile of 128 columns without ever writing activations to HBM.
+//
+//   reference: ResidualDeformation.forward  lib/networks/deform/base_network.py:34-42
+//              MLP.forward                  lib/utils/net_utils.py:1263-1273
+//              SignedDistanceNetwork        lib/networks/deform/base_network.py:78-97
+//              SphereSignedDistanceField    lib/utils/net_utils.py:1337-1352
+//              HDQ blend                    lib/networks/deform/base_network.py:374-382
+//              forward_geometry (normals)   lib/networks/deform/base_network.py:456-494
+//              material heads               lib/networks/relight/relight_network.py:45-47,97-104
+//              RenderNetwork                lib/networks/deform/base_network.py:152-171
+//
+// Design (DESIGN.md "K3/K4"):
+//  * one workgroup = 4 waves = one tile of TM=128 columns; activations live in LDS as bf16
+//    [128][264] (row stride 528 B = 16*33 -> conflict-free ds_read_b128 B fragments);
+//    73.7 KB LDS per workgroup -> two workgroups per CU, so one workgroup's VALU epilogue
+//    (bias, activation, bf16 pack) overlaps the other's MFMA stream on the same SIMDs.
+//  * D = W . X^T with v_mfma_f32_32x32x16_bf16: A = weights (rows n), B = activations (cols m).
+//    Wave w owns output rows [64w, 64w+64) for all 128 columns: 2x4 accumulator tiles = 128 VGPRs.
+//    Weight A-fragments are pre-packed in fragment order (ra_pack.cpp) and come straight from
+//    L2 with one coalesced 1 KiB load per fragment; they never touch LDS.
+//  * the D layout gives every lane 4 consecutive output rows of one column -> the epilogue
+//    packs 4 bf16 and writes them with one ds_write_b64 as the next layer's B operand.
+//  * skip connections re-compute the positional encoding into the tile instead of keeping it
+//    (keeps LDS at 2 workgroups/CU); cond (156 constants per frame) is folded into biases.
+//  * the "full" kernel carries 3 forward-mode tangent columns next to each primal column
+//    (tile = 32 points x {value, d/dbx, d/dby, d/dbz}) to produce d sdf / d bpts exactly as
+//    autograd does, then runs the material heads / colour net on the same tile.
+#include "ra_common.hpp"
+
+namespace {
+
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2;
+constexpr float INV_2PI = 0.15915494309189535f;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// y = act(z), dy = act'(z)
+template <int ACT>
+__device__ __forceinline__ float act_fn(float z, float& dy) {
+    if (ACT == ACT_RELU) {
+        dy = z > 0.f ? 1.f : 0.f;
+        return fmaxf(z, 0.f);
+    } else if (ACT == ACT_SOFTPLUS) {       // nn.Softplus(beta=100, threshold=20)
+        const float u = 100.f * z;
+        if (u > 20.f) { dy = 1.f; return z; }
+        const float e = __expf(u);
+        dy = e / (1.f + e);
+        return 0.01f * __logf(1.f + e);
+    } else {
+        dy = 1.f;
+        return z;
+    }
+}
+
+// acc[nt][mt] += W[64*wave + 32*nt .. +32, kcols] . X[32*mt .. +32, kcol0 .. kcol0 + 16*KS]^T
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[2][MT], const bf16x8* __restrict__ wl, const bf16* xs,
+                                          int kcol0, int wave, int lane) {
+    const bf16x8* a0p = wl + (size_t)((2 * wave + 0) * KS) * 64 + lane;
+    const bf16x8* a1p = wl + (size_t)((2 * wave + 1) * KS) * 64 + lane;
+    const bf16* bp = xs + (lane & 31) * XS + kcol0 + (lane >> 5) * 8;
+#pragma unroll 2
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a0 = a0p[ks * 64];
+        const bf16x8 a1 = a1p[ks * 64];
+        bf16x8 b[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const bf16x8*>(bp + mt * 32 * XS + ks * 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[0][mt] = mfma32(a0, b[mt], acc[0][mt]);
+            acc[1][mt] = mfma32(a1, b[mt], acc[1][mt]);
+        }
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][MT]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+}
+
+__device__ __forceinline__ void store4(bf16* dst, float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
+    *reinterpret_cast<bf16x4*>(dst) = v;
+}
+
+// write act(acc + bias) as bf16 into xs[:, 0..255]; GRAD: column group 0 is the primal,
+// groups 1..3 hold tangents and get act'(z_primal) * t (no bias).
+template <int ACT, bool GRAD, int MT>
+__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], const float* __restrict__ bias, bf16* xs,
+                                              int wave, int lane) {
+    const int mrow = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n0 = 64 * wave + 32 * nt + 8 * q + 4 * (lane >> 5);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
+            float y[4], dy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = act_fn<ACT>(acc[nt][0][4 * q + j] + bv[j], dy[j]);
+            store4(xs + mrow * XS + n0, y[0], y[1], y[2], y[3]);
+#pragma unroll
+            for (int mt = 1; mt < MT; ++mt) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (GRAD) {
+                        o[j] = acc[nt][mt][4 * q + j] * dy[j];
+                    } else {
+                        float d_;
+                        o[j] = act_fn<ACT>(acc[nt][mt][4 * q + j] + bv[j], d_);
+                    }
+                }
+                store4(xs + (mt * 32 + mrow) * XS + n0, o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// <=32 output rows; wave w handles columns [32w, 32w+32). Lanes 0..31 end up with rows 0..3 of
+// column 32w+lane in acc[0..3].
+template <int KS>
+__device__ __forceinline__ f32x16 gemm_head(const bf16x8* __restrict__ wl, const bf16* xs, int kcol0, int colgrp, int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bf16x8* ap = wl + lane;
+    const bf16* bp = xs + (colgrp * 32 + (lane & 31)) * XS + kcol0 + (lane >> 5) * 8;
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = ap[ks * 64];
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
+        acc = mfma32(a, b, acc);
+    }
+    return acc;
+}
+
+// positional encoding of one column into row[0 .. 3+6L) (embedder.py:26-37 channel order:
+// x, then per frequency the 3 sines then the 3 cosines), optional zero padding up to npad.
+// half h of the frequencies is written by this thread. jrow == nullptr: primal values;
+// otherwise the tangent: d channel / d b_j = channel'(x_c) * J[c][j] with jcol = J[:, j].
+template <int L>
+__device__ __forceinline__ void pe_write_col(bf16* row, const float x[3], const float* jcol, int h, int npad) {
+    float rev[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rev[c] = x[c] * INV_2PI;
+    if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[c] = (bf16)(jcol ? jcol[c] : x[c]);
+    }
+    const int f0 = h * (L / 2), f1 = f0 + (L / 2);
+#pragma unroll
+    for (int f = f0; f < f1; ++f) {
+        const float sc = (float)(1 << f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = rev[c] * sc;                  // revolutions; exact power-of-two scaling
+            const float s = __builtin_amdgcn_sinf(a);
+            const float co = __builtin_amdgcn_cosf(a);
+            if (jcol) {
+                row[3 + 6 * f + c] = (bf16)(sc * co * jcol[c]);
+                row[3 + 6 * f + 3 + c] = (bf16)(-sc * s * jcol[c]);
+            } else {
+                row[3 + 6 * f + c] = (bf16)s;
+                row[3 + 6 * f + 3 + c] = (bf16)co;
+            }
+        }
+    }
+    if (h == 1)
+        for (int c = 3 + 6 * L; c < npad; ++c) row[c] = (bf16)0.f;
+}
+
+struct Smem {
+    bf16 xs[TM * XS];       // activation tile
+    float pts[TM * 4];      // big-pose point of each column (xyz, pad)
+    float cpts[TM * 4];     // canonical point (bpts + resd)
+    float misc[TM * 4];     // head outputs
+    float jac[32 * 12];     // full kernel: d cpts / d bpts per point (row-major 3x3 + pad)
+    int count;
+};
+
+// =============================================================================================
+//  K3: HDQ fine query — resd + sdf (sdf only) on 128 points per tile, blend epilogue
+// =============================================================================================
+template <bool DEBUG>
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, const bf16x8* __restrict__ wa,
+                                                                const float* __restrict__ ba, FrameState fr, MlpIO io) {
+    __shared__ __attribute__((aligned(16))) Smem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sm.count = *io.count;
+    __syncthreads();
+    const int count = sm.count;
+    if (blockIdx.x == 0 && tid == 0 && io.counters) atomicAdd(&io.counters->n_fine_sdf, (unsigned long long)count);
+    f32x16 acc[2][4];
+
+    for (int tile = blockIdx.x; tile * TM < count; tile += gridDim.x) {
+        const int slot0 = tile * TM;
+        // ---- load points
+        if (tid < TM) {
+            const int s = slot0 + tid;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (s < count) { x = io.bpts[3 * s]; y = io.bpts[3 * s + 1]; z = io.bpts[3 * s + 2]; }
+            sm.pts[4 * tid] = x; sm.pts[4 * tid + 1] = y; sm.pts[4 * tid + 2] = z; sm.pts[4 * tid + 3] = 0.f;
+        }
+        __syncthreads();
+        const int pm = tid >> 1, ph = tid & 1;
+        // ---- residual deformation net
+        { const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
+          pe_write_col<10>(sm.xs + pm * XS, x, nullptr, ph, 64); }
+        __syncthreads();
+        zero_acc<4>(acc);
+        gemm_wide<4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
+        __syncthreads();
+        epilogue_wide<ACT_RELU, false, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < 8; ++l) {
+            zero_acc<4>(acc);
+            gemm_wide<16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            if (l == 4) {   // skip: cat([x, input]) — re-encode the input into cols 0..63 and accumulate
+                const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
+                pe_write_col<10>(sm.xs + pm * XS, x, nullptr, ph, 64);
+                __syncthreads();
+                gemm_wide<4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
+                __syncthreads();
+            }
+            epilogue_wide<ACT_RELU, false, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
+            __syncthreads();
+        }
+        {   // head: resd = tanh(z) * resd_limit (0.05); cpts = bpts + resd
+            const f32x16 h = gemm_head<16>(wa + net.rhead.w, sm.xs, 0, wave, lane);
+            if (lane < 32) {
+                const int m = wave * 32 + lane;
+                const float* b = ba + net.rhead.bias;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float resd = tanhf(h[c] + b[c]) * 0.05f;
+                    sm.cpts[4 * m + c] = sm.pts[4 * m + c] + resd;
+                    if (DEBUG && io.dbg_resd && slot0 + m < count) io.dbg_resd[3 * (slot0 + m) + c] = resd;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- signed distance net
+        { const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
+          pe_write_col<8>(sm.xs + pm * XS, x, nullptr, ph, 64); }
+        __syncthreads();
+        zero_acc<4>(acc);
+        gemm_wide<4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
+        __syncthreads();
+        epilogue_wide<ACT_SOFTPLUS, false, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < 8; ++l) {
+            zero_acc<4>(acc);
+            gemm_wide<16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            epilogue_wide<ACT_SOFTPLUS, false, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
+            __syncthreads();
+            if (l == 3) {   // skip: cat([x(205), input(51)]) / sqrt(2): input goes to cols 205..255
+                const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
+                pe_write_col<8>(sm.xs + pm * XS + 205, x, nullptr, ph, 51);
+                __syncthreads();
+            }
+        }
+        if (DEBUG && io.dbg_feat) {     // feature rows of lin8 (test hook; the product path uses the full kernel)
+            zero_acc<4>(acc);
+            gemm_wide<16, 4>(acc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
+            const float* b = ba + net.sfeat.bias;
+            for (int nt = 0; nt < 2; ++nt)
+                for (int mt = 0; mt < 4; ++mt)
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = 64 * wave + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int s = slot0 + mt * 32 + (lane & 31);
+                        if (s < count) io.dbg_feat[(size_t)s * 256 + n] = acc[nt][mt][r] + b[n];
+                    }
+        }
+        {   // head: sdf, then the HDQ blend (base_network.py:374-382)
+            const f32x16 h = gemm_head<16>(wa + net.shead.w, sm.xs, 0, wave, lane);
+            if (lane < 32) {
+                const int s = slot0 + wave * 32 + lane;
+                if (s < count) {
+                    float d = h[0] + ba[net.shead.bias];
+                    if (DEBUG && io.dbg_sdf) io.dbg_sdf[s] = d;
+                    if (io.sdf) {
+                        const int p = io.idx[s];
+                        if (io.smooth) {
+                            const float smpl = io.sdf[p];
+                            const float r = fminf(fmaxf(fabsf(d) / io.dist_th, 0.f), 1.f);
+                            d = smpl * r + d * (1.f - r);
+                        }
+                        io.sdf[p] = d;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+//  K4: full geometry forward with forward-mode tangents + material heads / colour net
+//      tile = 32 points x {value, d/dbx, d/dby, d/dbz}
+// =============================================================================================
+__device__ __forceinline__ void inv3(const float R[9], float M[9]) {   // blend_utils.py:125-165
+    M[0] = R[4] * R[8] - R[7] * R[5];
+    M[3] = -R[3] * R[8] + R[6] * R[5];
+    M[6] = R[3] * R[7] - R[6] * R[4];
+    M[1] = -R[1] * R[8] + R[7] * R[2];
+    M[4] = R[0] * R[8] - R[6] * R[2];
+    M[7] = -R[0] * R[7] + R[6] * R[1];
+    M[2] = R[1] * R[5] - R[4] * R[2];
+    M[5] = -R[0] * R[5] + R[3] * R[2];
+    M[8] = R[0] * R[4] - R[3] * R[1];
+    const float D = R[0] * M[0] + R[1] * M[3] + R[2] * M[6];
+    const float inv = 1.f / (D + 1e-8f);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] *= inv;
+}
+
+__device__ __forceinline__ void normalize3(float v[3]) {   // net_utils.py:1626-1628
+    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-8f;
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+
+__device__ __forceinline__ float sdf_to_occ_dev(float sdf, float beta) {   // net_utils.py:852-893
+    const float x = -sdf;
+    float sigma;
+    if (x <= 0.f) sigma = 1.f / beta * (0.5f * expf(x / beta));
+    else sigma = 1.f / beta * (1.f - 0.5f * expf(-x / beta));
+    return 1.f - expf(-fmaxf(sigma, 0.f) * 0.005f);
+}
+
+__global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, MatNet mat, ColNet col,
+                                                                 const bf16x8* __restrict__ wa, const float* __restrict__ ba,
+                                                                 FrameState fr, FullIO io) {
+    __shared__ __attribute__((aligned(16))) Smem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sm.count = *io.count;
+    __syncthreads();
+    const int count = sm.count;
+    if (blockIdx.x == 0 && tid == 0 && io.counters) atomicAdd(&io.counters->n_fine_full, (unsigned long long)count);
+    f32x16 acc[2][4];
+    // PE mapping: point pm, column group pg (0 primal, 1..3 tangents), frequency half ph
+    const int pm = tid & 31, pg = (tid >> 5) & 3, ph = tid >> 7;
+
+    for (int tile = blockIdx.x; tile * 32 < count; tile += gridDim.x) {
+        const int slot0 = tile * 32;
+        if (tid < 32) {
+            const int s = slot0 + tid;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (s < count) { x = io.bpts[3 * s]; y = io.bpts[3 * s + 1]; z = io.bpts[3 * s + 2]; }
+            sm.pts[4 * tid] = x; sm.pts[4 * tid + 1] = y; sm.pts[4 * tid + 2] = z;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sm.jac[12 * tid + i] = (i % 4 == 0) ? 1.f : 0.f;   // identity for the resd PE
+        }
+        __syncthreads();
+        auto write_pe10 = [&]() {
+            const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
+            if (pg == 0) pe_write_col<10>(sm.xs + pm * XS, x, nullptr, ph, 64);
+            else { const float jc[3] = {pg == 1 ? 1.f : 0.f, pg == 2 ? 1.f : 0.f, pg == 3 ? 1.f : 0.f};
+                   pe_write_col<10>(sm.xs + (pg * 32 + pm) * XS, x, jc, ph, 64); }
+        };
+        auto write_pe8 = [&](int col0, int npad) {
+            const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
+            if (pg == 0) pe_write_col<8>(sm.xs + pm * XS + col0, x, nullptr, ph, npad);
+            else { const float* J = sm.jac + 12 * pm; const int j = pg - 1;
+                   const float jc[3] = {J[0 + j], J[3 + j], J[6 + j]};
+                   pe_write_col<8>(sm.xs + (pg * 32 + pm) * XS + col0, x, jc, ph, npad); }
+        };
+        // ---- residual deformation net with tangents
+        write_pe10();
+        __syncthreads();
+        zero_acc<4>(acc);
+        gemm_wide<4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
+        __syncthreads();
+        epilogue_wide<ACT_RELU, true, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < 8; ++l) {
+            zero_acc<4>(acc);
+            gemm_wide<16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            if (l == 4) {
+                write_pe10();
+                __syncthreads();
+                gemm_wide<4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
+                __syncthreads();
+            }
+            epilogue_wide<ACT_RELU, true, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
+            __syncthreads();
+        }
+        {   // head: wave g holds z (g = 0) or dz/db_{g-1}
+            const f32x16 h = gemm_head<16>(wa + net.rhead.w, sm.xs, 0, wave, lane);
+            if (lane < 32) { sm.misc[4 * (wave * 32 + lane) + 0] = h[0]; sm.misc[4 * (wave * 32 + lane) + 1] = h[1];
+                             sm.misc[4 * (wave * 32 + lane) + 2] = h[2]; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float* b = ba + net.rhead.bias;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float th = tanhf(sm.misc[4 * tid + c] + b[c]);
+                const float resd = th * io.resd_limit;
+                sm.cpts[4 * tid + c] = sm.pts[4 * tid + c] + resd;
+                sm.pts[4 * tid + 3] = 0.f;
+                const float dth = (1.f - th * th) * io.resd_limit;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    sm.jac[12 * tid + 3 * c + j] = (c == j ? 1.f : 0.f) + dth * sm.misc[4 * ((j + 1) * 32 + tid) + c];
+            }
+        }
+        __syncthreads();
+        // ---- signed distance net with tangents
+        write_pe8(0, 64);
+        __syncthreads();
+        zero_acc<4>(acc);
+        gemm_wide<4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
+        __syncthreads();
+        epilogue_wide<ACT_SOFTPLUS, true, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < 8; ++l) {
+            zero_acc<4>(acc);
+            gemm_wide<16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            epilogue_wide<ACT_SOFTPLUS, true, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
+            __syncthreads();
+            if (l == 3) { write_pe8(205, 51); __syncthreads(); }
+        }
+        {   // sdf head on all four column groups: value and the three partials
+            const f32x16 h = gemm_head<16>(wa + net.shead.w, sm.xs, 0, wave, lane);
+            if (lane < 32) sm.misc[4 * (wave * 32 + lane) + 3] = h[0];
+        }
+        // features (primal columns only) -> xs rows 0..31 as the next net's input
+        f32x16 facc[2][1];
+        zero_acc<1>(facc);
+        gemm_wide<16, 1>(facc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
+        __syncthreads();
+        epilogue_wide<ACT_NONE, false, 1>(facc, ba + net.sfeat.bias, sm.xs, wave, lane);
+        if (io.dbg_feat) {
+            const float* b = ba + net.sfeat.bias;
+            for (int nt = 0; nt < 2; ++nt)
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 64 * wave + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int s = slot0 + (lane & 31);
+                    if (s < count) io.dbg_feat[(size_t)s * 256 + n] = facc[nt][0][r] + b[n];
+                }
+        }
+        __syncthreads();
+        // ---- per-point geometry outputs (threads 0..31)
+        float nrm[3] = {0.f, 0.f, 0.f}, bv[3] = {0.f, 0.f, 0.f};
+        float sdfv = 0.f, occ = 0.f;
+        if (tid < 32) {
+            sdfv = sm.misc[4 * tid + 3] + ba[net.shead.bias];
+            float g[3] = {sm.misc[4 * (32 + tid) + 3], sm.misc[4 * (64 + tid) + 3], sm.misc[4 * (96 + tid) + 3]};
+            const int s = slot0 + tid;
+            if (io.dbg_grad && s < count) { io.dbg_grad[3 * s] = g[0]; io.dbg_grad[3 * s + 1] = g[1]; io.dbg_grad[3 * s + 2] = g[2]; }
+            if (io.dbg_sdf && s < count) io.dbg_sdf[s] = sdfv;
+            occ = sdf_to_occ_dev(sdfv, io.beta);
+            normalize3(g);
+            float A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, B[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (io.mats && s < count) {
+                const float* M = io.mats + (size_t)s * 24;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { A[3 * i + j] = M[4 * i + j]; B[3 * i + j] = M[12 + 4 * i + j]; }
+            }
+            float Ai[9], Bi[9];
+            inv3(A, Ai);
+            inv3(B, Bi);
+            // normal: big-pose -> T (big_R^T), T -> pose (R_inv^T), pose -> world (R), base_network.py:471-475
+            float nt_[3], np_[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) nt_[i] = B[0 + i] * g[0] + B[3 + i] * g[1] + B[6 + i] * g[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) np_[i] = Ai[0 + i] * nt_[0] + Ai[3 + i] * nt_[1] + Ai[6 + i] * nt_[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) nrm[i] = np_[0] * fr.R[3 * i] + np_[1] * fr.R[3 * i + 1] + np_[2] * fr.R[3 * i + 2];
+            normalize3(nrm);
+            if (!io.relight && io.view && s < count) {   // view dirs to big-pose space, base_network.py:324-334 (not re-normalised)
+                const int p = io.idx[s];
+                const float v[3] = {io.view[3 * p], io.view[3 * p + 1], io.view[3 * p + 2]};
+                float pv[3], tv[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pv[i] = v[0] * fr.R[i] + v[1] * fr.R[3 + i] + v[2] * fr.R[6 + i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) tv[i] = A[0 + i] * pv[0] + A[3 + i] * pv[1] + A[6 + i] * pv[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bv[i] = Bi[0 + i] * tv[0] + Bi[3 + i] * tv[1] + Bi[6 + i] * tv[2];
+            }
+        }
+        // ---- heads on the 32 primal columns
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (io.relight) {
+            zero_acc<1>(facc);
+            gemm_wide<16, 1>(facc, wa + mat.m0.w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            epilogue_wide<ACT_SOFTPLUS, false, 1>(facc, ba + mat.m0.bias, sm.xs, wave, lane);
+            __syncthreads();
+            zero_acc<1>(facc);
+            gemm_wide<16, 1>(facc, wa + mat.m1.w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            epilogue_wide<ACT_SOFTPLUS, false, 1>(facc, ba + mat.m1.bias, sm.xs, wave, lane);
+            __syncthreads();
+            if (wave == 0) {
+                const f32x16 h = gemm_head<16>(wa + mat.mhead.w, sm.xs, 0, 0, lane);
+                if (lane < 32) {
+                    const float* b = ba + mat.mhead.bias;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o4[c] = io.albedo_slope / (1.f + expf(-(h[c] + b[c]))) + io.albedo_bias;
+                    o4[3] = io.rough_slope / (1.f + expf(-(h[3] + b[3]))) + io.rough_bias;
+                }
+            }
+        } else {
+            zero_acc<1>(facc);
+            gemm_wide<16, 1>(facc, wa + col.c0a.w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            if (tid < 32) {     // [PE4(bvds) 27 | world normal 3 | pad 2] -> cols 0..31
+                bf16* row = sm.xs + tid * XS;
+                pe_write_col<4>(row, bv, nullptr, 0, 27);
+                pe_write_col<4>(row, bv, nullptr, 1, 27);
+                row[27] = (bf16)nrm[0]; row[28] = (bf16)nrm[1]; row[29] = (bf16)nrm[2];
+                row[30] = (bf16)0.f; row[31] = (bf16)0.f;
+            }
+            __syncthreads();
+            gemm_wide<2, 1>(facc, wa + col.c0b.w, sm.xs, 0, wave, lane);
+            __syncthreads();
+            epilogue_wide<ACT_RELU, false, 1>(facc, ba + col.c0a.bias, sm.xs, wave, lane);
+            __syncthreads();
+            const WideLayer cl[3] = {col.c1, col.c2, col.c3};
+#pragma unroll 1
+            for (int l = 0; l < 3; ++l) {
+                zero_acc<1>(facc);
+                gemm_wide<16, 1>(facc, wa + cl[l].w, sm.xs, 0, wave, lane);
+                __syncthreads();
+                epilogue_wide<ACT_RELU, false, 1>(facc, l == 2 ? fr.bias_c3 : ba + cl[l].bias, sm.xs, wave, lane);
+                __syncthreads();
+            }
+            if (wave == 0) {
+                const f32x16 h = gemm_head<16>(wa + col.chead.w, sm.xs, 0, 0, lane);
+                if (lane < 32) {
+                    const float* b = ba + col.chead.bias;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o4[c] = 1.f / (1.f + expf(-(h[c] + b[c])));
+                }
+            }
+        }
+        // ---- scatter raw (threads 0..31 = wave 0 lanes 0..31 hold everything)
+        if (tid < 32) {
+            const int s = slot0 + tid;
+            if (s < count) {
+                float* o = io.raw + (size_t)io.idx[s] * io.C;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    o[c] = sm.cpts[4 * tid + c];
+                    o[3 + c] = sm.pts[4 * tid + c];
+                    o[6 + c] = sm.cpts[4 * tid + c] - sm.pts[4 * tid + c];
+                }
+                if (io.relight) {
+                    o[9] = o4[0]; o[10] = o4[1]; o[11] = o4[2]; o[12] = o4[3];
+                    o[13] = nrm[0]; o[14] = nrm[1]; o[15] = nrm[2]; o[16] = occ;
+                } else {
+                    o[9] = nrm[0]; o[10] = nrm[1]; o[11] = nrm[2];
+                    o[12] = o4[0]; o[13] = o4[1]; o[14] = o4[2]; o[15] = occ;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+void launch_mlp_sdf(const GeoNet& net, const bf16x8* warena, const float* barena, const FrameState& fr, const MlpIO& io,
+                    int max_slots, hipStream_t stream) {
+    if (max_slots <= 0) return;
+    const int tiles = (max_slots + TM - 1) / TM;
+    const int grid = tiles < 512 ? tiles : 512;     // 2 workgroups per CU x 256 CUs, persistent over tiles
+    if (io.dbg_resd || io.dbg_sdf || io.dbg_feat)
+        hipLaunchKernelGGL(mlp_sdf_kernel<true>, dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+    else
+        hipLaunchKernelGGL(mlp_sdf_kernel<false>, dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+}
+
+void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const bf16x8* warena, const float* barena,
+                     const FrameState& fr, const FullIO& io, int max_slots, hipStream_t stream) {
+    if (max_slots <= 0) return;
+    const int tiles = (max_slots + 31) / 32;
+    const int grid = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL(mlp_full_kernel, dim3(grid), dim3(MLP_THREADS), 0, stream, net, mat, col, warena, barena, fr, io);
+}

@@ -1,0 +1,213 @@
+// Host-side weight packer: reference state_dict (fp32) -> bf16 MFMA fragment order.
+//   weight_norm fold  W = g * v / |v|_row          lib/utils/net_utils.py:1326-1327, base_network.py:145-149
+//   SDF skip          cat([x, inputs]) / sqrt(2)   lib/utils/net_utils.py:1345-1346 (folded into lin4)
+//   resd skip         cat([x, input])              lib/utils/net_utils.py:1266-1267 (x first)
+//   cond slices are kept in fp32 for the per-frame bias fold (ra_set_frame)
+#include "ra_ctx.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+uint16_t f2bf(float f) {   // round to nearest even
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    const uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    return (uint16_t)(u >> 16);
+}
+
+struct Mat {
+    int rows = 0, cols = 0;
+    std::vector<float> v;
+    Mat() {}
+    Mat(int r, int c) : rows(r), cols(c), v((size_t)r * c, 0.f) {}
+    float& at(int r, int c) { return v[(size_t)r * cols + c]; }
+    float at(int r, int c) const { return v[(size_t)r * cols + c]; }
+};
+
+struct Packer {
+    std::vector<uint16_t> w;    // bf16 arena (multiple of 8 elements)
+    std::vector<float> b;       // bias arena
+
+    // M: [rows<=256 or <=32][K], K multiple of 16 after padding
+    WideLayer add(const Mat& M, const std::vector<float>& bias, int n_rows_pad) {
+        const int K = (M.cols + 15) / 16 * 16;
+        const int KS = K / 16, NB = n_rows_pad / 32;
+        WideLayer L;
+        L.w = (uint32_t)(w.size() / 8);
+        L.ks = (uint32_t)KS;
+        L.bias = (uint32_t)b.size();
+        w.resize(w.size() + (size_t)NB * KS * 64 * 8, 0);
+        uint16_t* o = w.data() + (size_t)L.w * 8;
+        for (int nb = 0; nb < NB; ++nb)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = nb * 32 + (lane & 31), col = ks * 16 + (lane >> 5) * 8 + e;
+                        float val = 0.f;
+                        if (row < M.rows && col < M.cols) val = M.at(row, col);
+                        o[(((size_t)nb * KS + ks) * 64 + lane) * 8 + e] = f2bf(val);
+                    }
+        for (int r = 0; r < n_rows_pad; ++r) b.push_back(r < (int)bias.size() ? bias[r] : 0.f);
+        while (b.size() % 4) b.push_back(0.f);
+        return L;
+    }
+};
+
+Mat slice_cols(const Mat& M, int c0, int c1) {
+    Mat o(M.rows, c1 - c0);
+    for (int r = 0; r < M.rows; ++r)
+        for (int c = c0; c < c1; ++c) o.at(r, c - c0) = M.at(r, c);
+    return o;
+}
+
+Mat slice_rows(const Mat& M, int r0, int r1) {
+    Mat o(r1 - r0, M.cols);
+    for (int r = r0; r < r1; ++r)
+        for (int c = 0; c < M.cols; ++c) o.at(r - r0, c) = M.at(r, c);
+    return o;
+}
+
+}  // namespace
+
+static bool get(const std::map<std::string, std::vector<float>>& sd, const std::string& k, std::vector<float>& out) {
+    auto it = sd.find(k);
+    if (it == sd.end()) return false;
+    out = it->second;
+    return true;
+}
+
+static bool get_mat(const std::map<std::string, std::vector<float>>& sd, const std::string& k, int rows, int cols, Mat& M, std::string& err) {
+    std::vector<float> v;
+    if (!get(sd, k, v)) { err = "missing weight " + k; return false; }
+    if ((int)v.size() != rows * cols) { err = "bad shape for " + k + ": numel " + std::to_string(v.size()) + " expected " + std::to_string(rows) + "x" + std::to_string(cols); return false; }
+    M = Mat(rows, cols);
+    M.v = v;
+    return true;
+}
+
+static bool get_wn(const std::map<std::string, std::vector<float>>& sd, const std::string& p, int rows, int cols, Mat& M, std::vector<float>& bias, std::string& err) {
+    Mat v;
+    std::vector<float> g;
+    if (!get_mat(sd, p + ".weight_v", rows, cols, v, err)) return false;
+    if (!get(sd, p + ".weight_g", g) || (int)g.size() != rows) { err = "missing/bad " + p + ".weight_g"; return false; }
+    if (!get(sd, p + ".bias", bias) || (int)bias.size() != rows) { err = "missing/bad " + p + ".bias"; return false; }
+    M = Mat(rows, cols);
+    for (int r = 0; r < rows; ++r) {
+        double n2 = 0;
+        for (int c = 0; c < cols; ++c) n2 += (double)v.at(r, c) * v.at(r, c);
+        const float s = g[r] / (float)std::sqrt(n2);
+        for (int c = 0; c < cols; ++c) M.at(r, c) = v.at(r, c) * s;
+    }
+    return true;
+}
+
+int ra_pack_weights(ra_ctx* ctx, std::string& err) {
+    const auto& sd = ctx->state_dict;
+    const ra_config& c = ctx->cfg;
+    const int cond = c.n_bones * 3;
+    const int xyz_dim = 3 + 6 * c.xyz_res, sdf_dim = 3 + 6 * c.sdf_res, view_dim = 3 + 6 * c.view_res;
+    if (c.xyz_res != 10 || c.sdf_res != 8 || c.view_res != 4) { err = "kernels are specialised for xyz_res=10, sdf_res=8, view_res=4 (configs/base.yaml:47-49)"; return 1; }
+    Packer P;
+    HostNets& H = ctx->host;
+    // ---- residual deformation
+    const std::string rp = "residual_deformation_network.mlp.linears.";
+    const int in_ch = xyz_dim + cond;
+    for (int i = 0; i < 9; ++i) {
+        const int I = i == 0 ? in_ch : (i == 4 ? 256 + in_ch : 256);
+        const int O = i == 8 ? 3 : 256;
+        Mat W;
+        std::vector<float> b;
+        if (!get_mat(sd, rp + std::to_string(i) + ".weight", O, I, W, err)) return 1;
+        if (!get(sd, rp + std::to_string(i) + ".bias", b) || (int)b.size() != O) { err = "missing/bad " + rp + std::to_string(i) + ".bias"; return 1; }
+        if (i == 0) {
+            H.geo.r[0] = P.add(slice_cols(W, 0, xyz_dim), b, 256);
+            H.cond_r0 = slice_cols(W, xyz_dim, in_ch).v;
+            H.b_r0 = b;
+        } else if (i == 4) {
+            H.geo.r[4] = P.add(slice_cols(W, 0, 256), b, 256);
+            H.geo.r4b = P.add(slice_cols(W, 256, 256 + xyz_dim), std::vector<float>(), 256);
+            H.cond_r4 = slice_cols(W, 256 + xyz_dim, 256 + in_ch).v;
+            H.b_r4 = b;
+        } else if (i == 8) {
+            H.geo.rhead = P.add(W, b, 32);
+        } else {
+            H.geo.r[i] = P.add(W, b, 256);
+        }
+    }
+    // ---- signed distance
+    const std::string sp = "signed_distance_network.mlp.lin";
+    for (int l = 0; l < 9; ++l) {
+        const int I = l == 0 ? sdf_dim : 256;
+        const int O = l == 3 ? 256 - sdf_dim : (l == 8 ? 257 : 256);
+        Mat W;
+        std::vector<float> b;
+        if (!get_wn(sd, sp + std::to_string(l), O, I, W, b, err)) return 1;
+        if (l == 4) for (auto& x : W.v) x *= (float)(1.0 / std::sqrt(2.0));
+        if (l == 8) {
+            H.geo.shead = P.add(slice_rows(W, 0, 1), std::vector<float>(b.begin(), b.begin() + 1), 32);
+            H.geo.sfeat = P.add(slice_rows(W, 1, 257), std::vector<float>(b.begin() + 1, b.end()), 256);
+        } else {
+            H.geo.s[l] = P.add(W, b, 256);
+        }
+    }
+    {
+        std::vector<float> beta;
+        if (!get(sd, "signed_distance_network._beta", beta) || beta.size() != 1) { err = "missing signed_distance_network._beta"; return 1; }
+        H.beta = std::fmin(std::fmax(beta[0], 1e-9f), 1e6f);     // base_network.py:74-76
+    }
+    // ---- colour net (always present in both checkpoints; frozen for relight)
+    H.has_color = sd.count("render_network.l0.weight_v") > 0;
+    if (H.has_color) {
+        const int in0 = view_dim + 3 + 256;
+        Mat W;
+        std::vector<float> b;
+        if (!get_wn(sd, "render_network.l0", 256, in0, W, b, err)) return 1;
+        H.col.c0a = P.add(slice_cols(W, view_dim + 3, in0), b, 256);
+        H.col.c0b = P.add(slice_cols(W, 0, view_dim + 3), std::vector<float>(), 256);
+        if (!get_wn(sd, "render_network.l1", 256, 256, W, b, err)) return 1;
+        H.col.c1 = P.add(W, b, 256);
+        if (!get_wn(sd, "render_network.l2", 256, 256, W, b, err)) return 1;
+        H.col.c2 = P.add(W, b, 256);
+        if (!get_wn(sd, "render_network.l3", 256, 256 + cond, W, b, err)) return 1;
+        H.col.c3 = P.add(slice_cols(W, 0, 256), b, 256);
+        H.cond_c3 = slice_cols(W, 256, 256 + cond).v;
+        H.b_c3 = b;
+        if (!get_wn(sd, "render_network.l4", 3, 256, W, b, err)) return 1;
+        H.col.chead = P.add(W, b, 32);
+    }
+    // ---- material heads (relight)
+    if (c.relight) {
+        Mat a0, a1, a2, r0, r1, r2;
+        std::vector<float> ba0, ba1, ba2, br0, br1, br2;
+        const std::string an = "albedo_network.linears.", rn = "roughness_network.linears.";
+        if (!get_mat(sd, an + "0.weight", 128, 256, a0, err) || !get_mat(sd, an + "1.weight", 128, 128, a1, err) || !get_mat(sd, an + "2.weight", 3, 128, a2, err)) return 1;
+        if (!get_mat(sd, rn + "0.weight", 128, 256, r0, err) || !get_mat(sd, rn + "1.weight", 128, 128, r1, err) || !get_mat(sd, rn + "2.weight", 1, 128, r2, err)) return 1;
+        if (!get(sd, an + "0.bias", ba0) || !get(sd, an + "1.bias", ba1) || !get(sd, an + "2.bias", ba2) || !get(sd, rn + "0.bias", br0) || !get(sd, rn + "1.bias", br1) || !get(sd, rn + "2.bias", br2)) { err = "missing material bias"; return 1; }
+        Mat m0(256, 256), m1(256, 256), mh(4, 256);
+        std::vector<float> b0(256), b1(256), bh(4);
+        for (int r = 0; r < 128; ++r) {
+            for (int k = 0; k < 256; ++k) { m0.at(r, k) = a0.at(r, k); m0.at(128 + r, k) = r0.at(r, k); }
+            for (int k = 0; k < 128; ++k) { m1.at(r, k) = a1.at(r, k); m1.at(128 + r, 128 + k) = r1.at(r, k); }
+            b0[r] = ba0[r]; b0[128 + r] = br0[r];
+            b1[r] = ba1[r]; b1[128 + r] = br1[r];
+        }
+        for (int k = 0; k < 128; ++k) {
+            for (int r = 0; r < 3; ++r) mh.at(r, k) = a2.at(r, k);
+            mh.at(3, 128 + k) = r2.at(0, k);
+        }
+        for (int r = 0; r < 3; ++r) bh[r] = ba2[r];
+        bh[3] = br2[0];
+        H.mat.m0 = P.add(m0, b0, 256);
+        H.mat.m1 = P.add(m1, b1, 256);
+        H.mat.mhead = P.add(mh, bh, 32);
+        if (!get(sd, "light_xyz_", H.light_xyz) || !get(sd, "light_area", H.light_area) || !get(sd, "light_sharp", H.light_sharp)) { err = "missing light_xyz_/light_area/light_sharp"; return 1; }
+        if (H.light_xyz.size() != H.light_area.size() * 3 || H.light_area.size() != H.light_sharp.size() || H.light_area.size() > RA_N_LIGHTS_MAX) { err = "bad light buffer shapes"; return 1; }
+    }
+    H.warena = P.w;
+    H.barena = P.b;
+    return 0;
+}

@@ -1,0 +1,596 @@
+// K5-K8: ray-state kernels around the distance query (gfx950) — all HBM-streaming, SoA, one
+// thread per ray / pixel-light pair / pixel; compaction by wave ballot + one atomic per wave.
+//
+//   reference: sphere_tracing        lib/networks/renderer/sphere_tracing_renderer.py:103-216
+//              light_visibility      :265-344     get_near_far_aabb  lib/utils/net_utils.py:1683-1712
+//              render_human          :551-784     evaluate_shade     :369-376
+//              Microfacet / safe_divide / sample_envmap_image / linear2srgb
+//                                    lib/utils/relight_utils.py:484-633,106-127,179-192
+//              volume_rendering      lib/utils/net_utils.py:970-999
+//              base_renderer         lib/networks/renderer/base_renderer.py:15-113
+#include "ra_kernels.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr float PI_F = 3.14159265358979323846f;
+
+__device__ __forceinline__ int live_count(const int* n_dev, int n) { return n_dev ? min(*n_dev, n) : n; }
+
+// torch.linspace(0, 1, S)[s]: step = 1/(S-1); first half start + s*step, second half end - (S-1-s)*step
+__device__ __forceinline__ float linspace01(int s, int S) {
+    if (S == 1) return 0.f;
+    const float step = 1.f / (float)(S - 1);
+    return (s < S / 2) ? (float)s * step : 1.f - (float)(S - 1 - s) * step;
+}
+
+// ------------------------------------------------------------------------------------------ trace
+__global__ void trace_init_kernel(TraceState ts, int n_launch, const int* n_dev, float offset, float relax) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= live_count(n_dev, n_launch)) return;
+    const float nr = ts.near_[i], fr = ts.far_[i];
+    ts.t[i] = nr;
+    ts.d0[i] = 1e9f;
+    ts.occ[i] = 1.f;
+    if (ts.dt) ts.dt[i] = 1e9f;
+    if (ts.st) ts.st[i] = fr;
+    if (ts.ot) ts.ot[i] = fr;
+    if (ts.cd) ts.cd[i] = 1e9f;
+    if (ts.off) ts.off[i] = offset;
+    if (ts.rlx) ts.rlx[i] = relax;
+}
+
+template <bool SOFT>
+__global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf, int n_launch, const int* n_dev, int iter,
+                                    ra_trace_params p) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= live_count(n_dev, n_launch)) return;
+    const float d1 = sdf[i];
+    const float d0 = ts.d0[i];
+    float t = ts.t[i];
+    float occ = ts.occ[i];
+    const float nr = ts.near_[i], fr = ts.far_[i];
+    float tan_i = p.tan_i;                                   // hard shadow (sphere_tracing_renderer.py:107-110)
+    if (SOFT) {
+        const float ti = ts.tan_i ? (ts.light ? ts.tan_i[ts.light[i]] : ts.tan_i[i]) : p.tan_i;
+        tan_i = p.tan_i_multiplier * ti;
+    }
+    const float tan2 = (1.f / tan_i) * 2.f;
+    float off = ts.off ? ts.off[i] : p.offset;
+    float rlx = ts.rlx ? ts.rlx[i] : p.relax;
+    float ot = ts.ot ? ts.ot[i] : 0.f;
+    if (SOFT && p.clay_book && iter >= p.shadow_skip_iter) {    // :157-172
+        const float dx0 = d0 + rlx * d0 + off;
+        const float dx1 = d1 + rlx * d1 + off;
+        const float dy = (dx1 * dx1) / (2.f * dx0);
+        const float dx = (sqrtf(dx1 * dx1 - dy * dy) - off) / (1.f + rlx);
+        const float den = fmaxf(fmaxf(t - dy, nr), p.eps);
+        const float cls = fmaxf(dx, 0.f) / den / tan2;
+        const bool msk = (cls < occ) && (dy < t) && (dx1 > 0.f) && (dx0 > 0.f) && (dx > 0.f) && (dy > 0.f) && (dy < dx0);
+        if (msk) { ot = t - dy; occ = cls; }
+    }
+    if (iter >= p.shadow_skip_iter) {                           // :175-179
+        const float cls = fmaxf(d1, 0.f) / fmaxf(fmaxf(t, nr), p.eps) / tan2;
+        if (cls < occ) { ot = t; occ = cls; }
+    }
+    if (!SOFT) {                                                // :182-197
+        const float d1u = fabsf(d1), d0u = fabsf(d0);
+        float st = ts.st[i], cd = ts.cd[i];
+        const float dt = ts.dt[i];
+        const float s0 = (d0 > 0.f) ? 1.f : ((d0 < 0.f) ? -1.f : 0.f);
+        const float s1 = (d1 > 0.f) ? 1.f : ((d1 < 0.f) ? -1.f : 0.f);
+        if (s0 != s1) {
+            st = t - dt * fminf(fmaxf(d1u / (d0u + d1u + p.eps), 0.f), 1.f);
+            off = 0.f;
+            rlx = 0.f;
+        }
+        if (d1u < cd) { cd = d1u; st = t; }
+        ts.st[i] = st;
+        ts.cd[i] = cd;
+        ts.off[i] = off;
+        ts.rlx[i] = rlx;
+    }
+    const float dtn = d1 + rlx * d1 + off;                      // :200-205
+    t = t + dtn;
+    t = fminf(t, fr);
+    t = fmaxf(t, nr);
+    if (ts.dt) ts.dt[i] = dtn;
+    ts.t[i] = t;
+    ts.d0[i] = d1;
+    ts.occ[i] = occ;
+    if (ts.ot) ts.ot[i] = ot;
+}
+
+// ------------------------------------------------------------------------------------------ surface
+__global__ void surface_finish_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ st,
+                                      const float* __restrict__ occ, int P, float* __restrict__ surf, float* __restrict__ depth,
+                                      float* __restrict__ acc, int* __restrict__ hit_idx, int* __restrict__ hit_count) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    bool hit = false;
+    if (i < P) {
+        const float s = st[i];
+        const float sx = ro[3 * i] + s * rd[3 * i], sy = ro[3 * i + 1] + s * rd[3 * i + 1], sz = ro[3 * i + 2] + s * rd[3 * i + 2];
+        surf[3 * i] = sx; surf[3 * i + 1] = sy; surf[3 * i + 2] = sz;
+        depth[i] = (sx - ro[3 * i]) / rd[3 * i];                // :574 (x component only)
+        const float a = 1.f - occ[i];                           // :575
+        acc[i] = a;
+        hit = a > 0.f;                                          // :590
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(hit_count, __popcll(m));
+    base = __shfl(base, 0);
+    if (hit) hit_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+__global__ void surface_samples_kernel(const float* __restrict__ surf, const float* __restrict__ rd, const int* __restrict__ hit_idx,
+                                       const int* __restrict__ hit_count, int S, float range, float* __restrict__ x,
+                                       float* __restrict__ v, int* __restrict__ n_out) {
+    const int nh = *hit_count;
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k == 0) *n_out = nh * S;
+    if (k >= nh * S) return;
+    const int h = k / S, s = k - h * S;
+    const int r = hit_idx[h];
+    const float zv = (S == 1) ? 0.5f : linspace01(s, S);            // :607-611
+    const float z = zv * (2.f * range) - range;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float d = rd[3 * r + c];
+        x[3 * k + c] = surf[3 * r + c] + z * d;
+        v[3 * k + c] = d;
+    }
+}
+
+// volume-render the S surface samples of one hit pixel, renormalise by acc (:616-620), split and
+// clip (:629-655)
+__global__ void surface_composite_kernel(const float* __restrict__ raw, int C, int S, const int* __restrict__ hit_count, int relight,
+                                         ra_config cfg, SurfaceMaps m) {
+    const int h = blockIdx.x * TPB + threadIdx.x;
+    if (h >= *hit_count) return;
+    float out[16];
+    const int CC = C - 1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) out[c] = 0.f;
+    float T = 1.f, accw = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* r = raw + ((size_t)h * S + s) * C;
+        const float a = r[CC];
+        const float w = a * T;                                  // alpha * cumprod(1 - alpha + 1e-8) (net_utils.py:987-990)
+        T *= (1.f - a + 1e-8f);
+        accw += w;
+        for (int c = 0; c < CC; ++c) out[c] += w * r[c];
+    }
+    // (+ (1 - acc) * bg_brightness, then / (occ + 1e-8))
+    const float inv = 1.f / (accw + 1e-8f);
+    for (int c = 0; c < CC; ++c) out[c] = (out[c] + (1.f - accw) * cfg.bg_brightness) * inv;
+    float* nrm = relight ? out + 13 : out + 9;
+    if (nrm[0] + nrm[1] + nrm[2] == 0.f) { nrm[0] = nrm[1] = nrm[2] = 1.f; }     // :642
+    const float nn = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]) + 1e-8f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        m.cpts[3 * h + c] = out[c];
+        m.bpts[3 * h + c] = out[3 + c];
+        m.resd[3 * h + c] = out[6 + c];
+        m.norm[3 * h + c] = nrm[c] / nn;
+    }
+    if (relight) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = fminf(fmaxf(out[9 + c], cfg.albedo_bias), cfg.albedo_bias + cfg.albedo_slope);
+            if (cfg.albedo_multiplier > 0.f) a *= cfg.albedo_multiplier;
+            m.albedo[3 * h + c] = a;
+        }
+        m.rough[h] = fminf(fmaxf(out[12], cfg.roughness_bias), cfg.roughness_bias + cfg.roughness_slope);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m.rgb[3 * h + c] = out[12 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shadow rays
+__global__ void light_dirs_kernel(const float* __restrict__ xyz, int L, float* __restrict__ ldir) {
+    const int l = blockIdx.x * TPB + threadIdx.x;
+    if (l >= L) return;
+    const float x = xyz[3 * l], y = xyz[3 * l + 1], z = xyz[3 * l + 2];
+    const float n = sqrtf(x * x + y * y + z * z) + 1e-8f;       // normalize(), net_utils.py:1626
+    ldir[3 * l] = x / n; ldir[3 * l + 1] = y / n; ldir[3 * l + 2] = z / n;
+}
+
+__global__ void shadow_gen_kernel(ShadowGen g) {
+    const int nh = *g.hit_count;
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    bool trace = false;
+    int h = 0, l = 0, r = 0;
+    float nr = 0.f, fr = 0.f;
+    if (k < (long long)nh * g.L) {
+        h = (int)(k / g.L);
+        l = (int)(k - (long long)h * g.L);
+        r = g.hit_idx[h];
+        const float dx = g.ldir[3 * l], dy = g.ldir[3 * l + 1], dz = g.ldir[3 * l + 2];
+        const float ldot = dx * g.norm[3 * h] + dy * g.norm[3 * h + 1] + dz * g.norm[3 * h + 2];     // :292
+        g.ldot[k] = ldot;
+        float lv;
+        if (g.no_visibility) lv = 1.f;
+        else if (g.local_visibility) lv = ldot > 0.f ? 1.f : 0.f;
+        else {
+            const bool front = (ldot > 0.f) && (g.acc[r] > 0.f);                                        // :303
+            lv = 0.f;
+            if (front) {
+                // get_near_far_aabb (net_utils.py:1683-1712), tiny components -> +1e-8
+                float d[3] = {dx, dy, dz};
+                const float o[3] = {g.surf[3 * r], g.surf[3 * r + 1], g.surf[3 * r + 2]};
+                nr = -3.0e38f; fr = 3.0e38f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (d[c] < 1e-8f && d[c] > -1e-16f) d[c] = 1e-8f;
+                    const float t0 = (g.bbox[c] - o[c]) / d[c], t1 = (g.bbox[3 + c] - o[c]) / d[c];
+                    nr = fmaxf(nr, fminf(t0, t1));
+                    fr = fminf(fr, fmaxf(t0, t1));
+                }
+                nr = fmaxf(nr, g.near_offset);                                                          // :311
+                fr = fmaxf(fr, g.near_offset);
+                trace = nr < fr;
+                lv = 1.f;           // outside the box: visible (:341); traced rays are overwritten later
+            }
+        }
+        g.lvis[k] = lv;
+    }
+    const unsigned long long m = __ballot(trace);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(g.ray_count, __popcll(m));
+    base = __shfl(base, 0);
+    if (trace) {
+        const int s = base + __popcll(m & ((1ull << lane) - 1ull));
+        g.ray_pix[s] = r;
+        g.ray_light[s] = l;
+        g.ray_slot[s] = (int)k;
+        g.near_[s] = nr;
+        g.far_[s] = fr;
+    }
+}
+
+__global__ void shadow_scatter_kernel(const float* __restrict__ occ, const int* __restrict__ ray_slot, const int* __restrict__ ray_count,
+                                      int max_rays, float* __restrict__ lvis) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= min(*ray_count, max_rays)) return;
+    lvis[ray_slot[i]] = occ[i];
+}
+
+// ------------------------------------------------------------------------------------------ shading
+// safe_divide with its in-place clamps (relight_utils.py:618-633). a and b are clamped by reference
+// because the reference aliases them with tensors it keeps using.
+__device__ __forceinline__ float safe_div(float& a, float& b) {
+    const float eps = 1e-8f;
+    if (a < eps && a >= 0.f) a = eps;
+    if (a > -eps && a <= 0.f) a = -eps;
+    if (b < eps && b >= 0.f) b = eps;
+    if (b > -eps && b <= 0.f) b = -eps;
+    float d = a / b;
+    if (d != d) d = 0.f;
+    if (isinf(d)) d = 0.f;
+    return fminf(fmaxf(d, -1e10f), 1e10f);
+}
+
+__device__ __forceinline__ void fnormalize(float v[3]) {       // F.normalize(eps=1e-7)
+    const float n = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-7f);
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+
+// equirect bilinear lookup, align_corners=False, border padding (relight_utils.py:106-127)
+__device__ __forceinline__ void sample_probe(const float* __restrict__ img, int H, int W, const float d[3], float out[3]) {
+    const float theta = acosf(d[2]) - 1e-6f;
+    const float phi = atan2f(d[1], d[0]);
+    const float qy = (theta / PI_F) * 2.f - 1.f;
+    const float qx = -phi / PI_F;
+    float ix = ((qx + 1.f) * W - 1.f) * 0.5f;
+    float iy = ((qy + 1.f) * H - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    out[0] = out[1] = out[2] = 0.f;
+    auto add = [&](int xx, int yy, float w) {
+        if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+            const float* p = img + ((size_t)yy * W + xx) * 3;
+            out[0] += w * p[0]; out[1] += w * p[1]; out[2] += w * p[2];
+        }
+    };
+    add(x0, y0, wx0 * wy0);
+    add(x1, y0, wx1 * wy0);
+    add(x0, y1, wx0 * wy1);
+    add(x1, y1, wx1 * wy1);
+}
+
+__device__ __forceinline__ float srgb(float x) {                // relight_utils.py:179-192
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    return (x <= 0.0031308f) ? x * 12.92f : 1.055f * powf(x + 1e-7f, 1.f / 2.4f) - (1.055f - 1.f);
+}
+
+// one wave per (pixel slot); lanes stride over the L lights; probes looped inside so the BRDF,
+// visibility and area weights are computed once per light for all probes.
+constexpr int MAXP = 8;
+__global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
+    const int n = in.count ? min(*in.count, in.n) : in.n;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const int h = wave;
+    const int r = in.idx ? in.idx[h] : h;
+    const float sp[3] = {in.surf[3 * r], in.surf[3 * r + 1], in.surf[3 * r + 2]};
+    float v[3] = {in.ray_o[3 * r] - sp[0], in.ray_o[3 * r + 1] - sp[1], in.ray_o[3 * r + 2] - sp[2]};
+    {   // surf2cam = normalize(ray_o - surf)  (:716), then F.normalize inside Microfacet
+        const float nn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-8f;
+        v[0] /= nn; v[1] /= nn; v[2] /= nn;
+        fnormalize(v);
+    }
+    float nrm[3] = {in.norm[3 * h], in.norm[3 * h + 1], in.norm[3 * h + 2]};
+    fnormalize(nrm);
+    const float alb[3] = {in.albedo[3 * h], in.albedo[3 * h + 1], in.albedo[3 * h + 2]};
+    const float rough = in.rough[h];
+    const float alpha = rough * rough;
+    const float a2 = alpha * alpha;
+    const float v_dot_n = fminf(fmaxf(v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2], 1e-4f), 1.f);
+    // view-only part of G (_get_g :580-595); cos_theta_v is clamped in place by the first safe_divide
+    float cos_v = nrm[0] * v[0] + nrm[1] * v[1] + nrm[2] * v[2];
+    {
+        const float eps = 1e-8f;
+        if (cos_v < eps && cos_v >= 0.f) cos_v = eps;
+        if (cos_v > -eps && cos_v <= 0.f) cos_v = -eps;
+    }
+    float cvs = fminf(fmaxf(cos_v * cos_v, 0.f), 1.f);
+    float one_m = 1.f - cvs;
+    float tan_v_sq = safe_div(one_m, cvs);
+    tan_v_sq = fminf(fmaxf(tan_v_sq, 0.f), 1e10f);
+    const float g_den0 = 1.f + sqrtf(1.f + a2 * tan_v_sq);
+
+    float rgb[MAXP][3], shd[MAXP][3], spc[MAXP][3];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[q][c] = shd[q][c] = spc[q][c] = 0.f;
+
+    for (int l = lane; l < in.L; l += 64) {
+        float s2l[3] = {in.light_xyz[3 * l] - sp[0], in.light_xyz[3 * l + 1] - sp[1], in.light_xyz[3 * l + 2] - sp[2]};
+        {
+            const float nn = sqrtf(s2l[0] * s2l[0] + s2l[1] * s2l[1] + s2l[2] * s2l[2]) + 1e-8f;      // :715
+            s2l[0] /= nn; s2l[1] /= nn; s2l[2] /= nn;
+        }
+        float pl[3] = {s2l[0], s2l[1], s2l[2]};
+        fnormalize(pl);
+        const float l_dot_n = fminf(fmaxf(pl[0] * nrm[0] + pl[1] * nrm[1] + pl[2] * nrm[2], 1e-4f), 1.f);
+        float hv[3] = {pl[0] + v[0], pl[1] + v[1], pl[2] + v[2]};
+        fnormalize(hv);
+        const float omc5 = 1.f - (pl[0] * hv[0] + pl[1] * hv[1] + pl[2] * hv[2]);
+        const float f = cfg.fresnel_f0 + (1.f - cfg.fresnel_f0) * (omc5 * omc5 * omc5 * omc5 * omc5);
+        // D (_get_d :598-608)
+        const float cos_m = hv[0] * nrm[0] + hv[1] * nrm[1] + hv[2] * nrm[2];
+        const float chi_d = cos_m > 0.f ? 1.f : 0.f;
+        float cms = cos_m * cos_m;
+        float omc = 1.f - cms;
+        const float tan_m_sq = safe_div(omc, cms);          // clamps cms in place
+        float dden = PI_F * (cms * cms) * ((a2 + tan_m_sq) * (a2 + tan_m_sq));
+        float dnum = a2 * chi_d;
+        const float dd = safe_div(dnum, dden);
+        // G
+        float cos_t = hv[0] * v[0] + hv[1] * v[1] + hv[2] * v[2];
+        float cvc = cos_v;
+        const float dv = safe_div(cos_t, cvc);
+        float gnum = (dv > 0.f ? 1.f : 0.f) * 2.f;
+        float gden = g_den0;
+        const float gg = safe_div(gnum, gden);
+        float mnum = f * gg * dd;
+        float mden = 4.f * 1.f * fabsf(v_dot_n);
+        const float glossy = safe_div(mnum, mden);
+        const float area = in.light_area[l];
+        const float lv = in.lvis[(size_t)h * in.L + l];
+        const float ld = in.ldot[(size_t)h * in.L + l];
+        float brdf[3], sbrdf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float lam = alb[c] / PI_F * l_dot_n;
+            brdf[c] = cfg.lambert_only ? lam : (cfg.glossy_only ? glossy : glossy + lam);
+        }
+        sbrdf = cfg.lambert_only ? 0.f : glossy;             // albedo = 0 variant (:740)
+        const float spec_ld = 1.f / (fabsf(1.f) + 1e-8f);    // :743
+        for (int q = 0; q < in.n_probes; ++q) {
+            float Lr[3];
+            sample_probe(in.probes + (size_t)q * in.ph * in.pw * 3, in.ph, in.pw, s2l, Lr);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float sh = lv * 1.f * area * Lr[c];     // cancel_cosine: ldot -> 1 (:724-727)
+                rgb[q][c] += brdf[c] * sh;
+                shd[q][c] += lv * ld * area * Lr[c];
+                spc[q][c] += sbrdf * (1.f * spec_ld * area * Lr[c]);
+            }
+        }
+    }
+    for (int q = 0; q < in.n_probes; ++q) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = rgb[q][c], b = shd[q][c], d = spc[q][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); d += __shfl_xor(d, o); }
+            if (lane == 0) {
+                const size_t k = ((size_t)q * in.n + h) * 3 + c;
+                if (in.rgb) in.rgb[k] = cfg.tonemapping ? srgb(a) : a;
+                if (in.shade) in.shade[k] = b * cfg.shading_albedo / PI_F;
+                if (in.spec && in.want_spec) in.spec[k] = d;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ scatter
+__global__ void scatter_maps_kernel(const int* __restrict__ hit_idx, const int* __restrict__ hit_count, int premultiply,
+                                    const float* __restrict__ acc_full, const float* __restrict__ src, int C, float* __restrict__ dst,
+                                    int src_full) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int nh = *hit_count;
+    if (k >= (long long)nh * C) return;
+    const int h = (int)(k / C), c = (int)(k - (long long)h * C);
+    const int r = hit_idx[h];
+    float v = src_full ? src[(size_t)r * C + c] : src[k];
+    if (premultiply) v *= acc_full[r];
+    dst[(size_t)r * C + c] = v;
+}
+
+__global__ void gather_rows_kernel(const int* __restrict__ hit_idx, const int* __restrict__ hit_count, const float* __restrict__ src,
+                                   int C, float* __restrict__ dst) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int nh = *hit_count;
+    if (k >= (long long)nh * C) return;
+    const int h = (int)(k / C), c = (int)(k - (long long)h * C);
+    dst[k] = src[(size_t)hit_idx[h] * C + c];
+}
+
+__global__ void accumulate_kernel(const int* __restrict__ count, unsigned long long* __restrict__ dst) {
+    atomicAdd(dst, (unsigned long long)*count);
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------ volume path
+__global__ void volume_samples_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr,
+                                      const float* __restrict__ fr, int P, int S, float* __restrict__ x, float* __restrict__ v) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (k >= (long long)P * S) return;
+    const int r = (int)(k / S), s = (int)(k - (long long)r * S);
+    const float tv = linspace01(s, S);
+    const float z = nr[r] * (1.f - tv) + fr[r] * tv;            // base_renderer.py:17-18
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        x[3 * k + c] = ro[3 * r + c] + rd[3 * r + c] * z;
+        v[3 * k + c] = rd[3 * r + c];
+    }
+}
+
+__global__ void volume_composite_kernel(const float* __restrict__ raw, int C, const float* __restrict__ nr, const float* __restrict__ fr,
+                                        int P, int S, float bg, ra_render_out out) {
+    const int r = blockIdx.x * TPB + threadIdx.x;
+    if (r >= P) return;
+    float o[16];
+    const int CC = C - 1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = 0.f;
+    float T = 1.f, acc = 0.f, depth = 0.f;
+    const float n_ = nr[r], f_ = fr[r];
+    for (int s = 0; s < S; ++s) {
+        const float* p = raw + ((size_t)r * S + s) * C;
+        const float a = p[CC];
+        const float w = a * T;
+        T *= (1.f - a + 1e-8f);
+        acc += w;
+        const float tv = linspace01(s, S);
+        depth += w * (n_ * (1.f - tv) + f_ * tv);
+        if (a != 0.f)
+            for (int c = 0; c < CC; ++c) o[c] += w * p[c];
+    }
+    for (int c = 0; c < CC; ++c) o[c] += (1.f - acc) * bg;
+    if (out.acc) out.acc[r] = acc;
+    if (out.depth) out.depth[r] = depth;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (out.cpts) out.cpts[3 * r + c] = o[c];
+        if (out.bpts) out.bpts[3 * r + c] = o[3 + c];
+        if (out.resd) out.resd[3 * r + c] = o[6 + c];
+        if (out.norm) out.norm[3 * r + c] = o[9 + c];
+        if (out.rgb) out.rgb[3 * r + c] = o[12 + c];
+    }
+}
+
+inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TPB - 1) / TPB)); }
+
+}  // namespace
+
+void launch_trace_init(const TraceState& ts, int n, const int* n_dev, const ra_trace_params& p, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(trace_init_kernel, grid_for(n), dim3(TPB), 0, s, ts, n, n_dev, p.offset, p.relax);
+}
+
+void launch_trace_update(const TraceState& ts, const float* sdf, int n, const int* n_dev, int iter, const ra_trace_params& p,
+                         hipStream_t s) {
+    if (n <= 0) return;
+    if (p.soft_shadow) hipLaunchKernelGGL(trace_update_kernel<true>, grid_for(n), dim3(TPB), 0, s, ts, sdf, n, n_dev, iter, p);
+    else hipLaunchKernelGGL(trace_update_kernel<false>, grid_for(n), dim3(TPB), 0, s, ts, sdf, n, n_dev, iter, p);
+}
+
+void launch_surface_finish(const float* ray_o, const float* ray_d, const float* st, const float* occ, int P, float* surf,
+                           float* depth, float* acc, int* hit_idx, int* hit_count, hipStream_t s) {
+    hipMemsetAsync(hit_count, 0, sizeof(int), s);
+    if (P <= 0) return;
+    hipLaunchKernelGGL(surface_finish_kernel, grid_for(P), dim3(TPB), 0, s, ray_o, ray_d, st, occ, P, surf, depth, acc, hit_idx, hit_count);
+}
+
+void launch_surface_samples(const float* surf, const float* ray_d, const int* hit_idx, const int* hit_count, int P, int S,
+                            float range, float* x, float* v, int* n_out, hipStream_t s) {
+    if (P <= 0) { hipMemsetAsync(n_out, 0, sizeof(int), s); return; }
+    hipLaunchKernelGGL(surface_samples_kernel, grid_for((long long)P * S), dim3(TPB), 0, s, surf, ray_d, hit_idx, hit_count, S, range, x, v, n_out);
+}
+
+void launch_surface_composite(const float* raw, int C, int S, const int* hit_count, int P, int relight, const ra_config& cfg,
+                              const SurfaceMaps& m, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(surface_composite_kernel, grid_for(P), dim3(TPB), 0, s, raw, C, S, hit_count, relight, cfg, m);
+}
+
+void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s) {
+    hipLaunchKernelGGL(light_dirs_kernel, grid_for(L), dim3(TPB), 0, s, xyz, L, ldir);
+}
+
+void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s) {
+    hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
+    if (P <= 0) return;
+    hipLaunchKernelGGL(shadow_gen_kernel, grid_for((long long)P * g.L), dim3(TPB), 0, s, g);
+}
+
+void launch_shadow_scatter(const float* occ, const int* ray_slot, const int* ray_count, int max_rays, float* lvis, hipStream_t s) {
+    if (max_rays <= 0) return;
+    hipLaunchKernelGGL(shadow_scatter_kernel, grid_for(max_rays), dim3(TPB), 0, s, occ, ray_slot, ray_count, max_rays, lvis);
+}
+
+void launch_shade(const ShadeIn& in, const ra_config& cfg, hipStream_t s) {
+    if (in.n <= 0) return;
+    hipLaunchKernelGGL(shade_kernel, grid_for((long long)in.n * 64), dim3(TPB), 0, s, in, cfg);
+}
+
+void launch_scatter_maps(const int* hit_idx, const int* hit_count, int P, int premultiply, const float* acc_full, const float* src,
+                         int C, float* dst, int src_full, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(scatter_maps_kernel, grid_for((long long)P * C), dim3(TPB), 0, s, hit_idx, hit_count, premultiply, acc_full, src, C, dst, src_full);
+}
+
+void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(1), 0, s, count, dst);
+}
+
+void launch_gather_rows(const int* hit_idx, const int* hit_count, int P, const float* src, int C, float* dst, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, grid_for((long long)P * C), dim3(TPB), 0, s, hit_idx, hit_count, src, C, dst);
+}
+
+void launch_fill(float* p, size_t n, float v, hipStream_t s) {
+    if (n == 0) return;
+    if (v == 0.f) { hipMemsetAsync(p, 0, n * sizeof(float), s); return; }
+    hipLaunchKernelGGL(fill_kernel, grid_for((long long)n), dim3(TPB), 0, s, p, n, v);
+}
+
+void launch_volume_samples(const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P, int S, float* x,
+                           float* v, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(volume_samples_kernel, grid_for((long long)P * S), dim3(TPB), 0, s, ray_o, ray_d, near_, far_, P, S, x, v);
+}
+
+void launch_volume_composite(const float* raw, int C, const float* near_, const float* far_, int P, int S, float bg,
+                             const ra_render_out& out, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(volume_composite_kernel, grid_for(P), dim3(TPB), 0, s, raw, C, near_, far_, P, S, bg, out);
+}

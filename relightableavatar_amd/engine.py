@@ -1,0 +1,203 @@
+"""Engine: thin Python owner of one ra_ctx (the C ABI context).
+
+PyTorch is plumbing here: it owns device memory (torch tensors whose data_ptr() is handed to the
+library) and the stream.  All arithmetic of the render path happens in the HIP library.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ra_config, ra_counters, ra_frame, ra_render_out, ra_sphere_params, ra_trace_params
+from .base_utils import dotdict
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    def __init__(self, cfg, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.RaError('relightableavatar_amd needs a HIP device (MI355X); there is no CPU fallback for the render path')
+        self.lib = _lib.lib()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.cfg = cfg
+        self.ctx = C.c_void_p()
+        check(self.lib.ra_ctx_create(C.byref(self.ctx), self.device.index or 0), 'ra_ctx_create')
+        self.relight = bool(cfg.relighting) or 'relight' in cfg.network_module
+        c = ra_config(xyz_res=cfg.xyz_res, sdf_res=cfg.sdf_res, view_res=cfg.view_res, n_bones=cfg.n_bones, relight=int(self.relight),
+                      resd_limit=cfg.resd_limit, blend_radius=cfg.blend_radius, albedo_slope=cfg.albedo_slope,
+                      albedo_bias=cfg.albedo_bias, roughness_slope=cfg.roughness_slope, roughness_bias=cfg.roughness_bias,
+                      fresnel_f0=cfg.fresnel_f0, shading_albedo=cfg.shading_albedo, albedo_multiplier=cfg.albedo_multiplier,
+                      lambert_only=int(cfg.lambert_only), glossy_only=int(cfg.glossy_only),
+                      tonemapping=int(cfg.tonemapping_rendering), bg_brightness=cfg.bg_brightness)
+        check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
+        self._frame_key = None
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, 'ctx', None) and self.ctx.value:
+                self.lib.ra_ctx_destroy(self.ctx)
+                self.ctx = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_state_dict(self, sd: dict):
+        """hand every tensor of the reference state_dict to the packer (host fp32)."""
+        for k, v in sd.items():
+            if not isinstance(v, torch.Tensor) or not v.dtype.is_floating_point:
+                continue
+            h = v.detach().to('cpu', torch.float32).contiguous()
+            check(self.lib.ra_set_weight(self.ctx, k.encode(), C.c_void_p(h.data_ptr()), h.numel()), f'ra_set_weight({k})')
+        check(self.lib.ra_finalize_weights(self.ctx, self.stream), 'ra_finalize_weights')
+        self._frame_key = None
+
+    def set_frame(self, batch, force=False):
+        """upload the SMPL frame state (batch keys of SURVEY.md section 8b)."""
+        key = tuple((batch[k].data_ptr(), batch[k]._version) for k in ('poses', 'pverts', 'A', 'R', 'Th'))
+        if key == self._frame_key and not force:
+            return
+        d = self.device
+        t = {k: _f32(batch[k][0], d) for k in ('R', 'Th', 'poses', 'A', 'big_A', 'pverts', 'pnorm', 'tverts', 'weights')}
+        cond_fix = None
+        if 'train_motion' in batch and self.cfg.fix_material >= 0:
+            cond_fix = _f32(batch['train_motion']['poses'][0, self.cfg.fix_material], d)
+        elif not self.relight:
+            cond_fix = t['poses']
+        fr = ra_frame(R=_ptr(t['R']), Th=_ptr(t['Th']), poses=_ptr(t['poses']), cond_fix=_ptr(cond_fix), A=_ptr(t['A']),
+                      big_A=_ptr(t['big_A']), pverts=_ptr(t['pverts']), pnorm=_ptr(t['pnorm']), tverts=_ptr(t['tverts']),
+                      weights=_ptr(t['weights']), n_verts=int(t['pverts'].shape[0]))
+        assert t['weights'].shape[-1] == self.cfg.n_bones, 'batch.weights does not match cfg.n_bones'
+        check(self.lib.ra_set_frame(self.ctx, C.byref(fr), self.stream), 'ra_set_frame')
+        self._keep = [t, cond_fix]   # the library copies asynchronously on the stream
+        self._frame_key = key
+
+    # ------------------------------------------------------------------ operators
+    def hdq_sdf(self, x: torch.Tensor, dist_th: float, smooth: bool) -> torch.Tensor:
+        x = _f32(x.reshape(-1, 3), self.device)
+        out = torch.empty(x.shape[0], device=self.device, dtype=torch.float32)
+        check(self.lib.ra_hdq_sdf(self.ctx, _ptr(x), x.shape[0], dist_th, int(smooth), _ptr(out), self.stream), 'ra_hdq_sdf')
+        return out
+
+    def forward(self, x: torch.Tensor, v, dist_th: float) -> torch.Tensor:
+        x = _f32(x.reshape(-1, 3), self.device)
+        v = None if v is None else _f32(v.reshape(-1, 3), self.device)
+        C_ = self.lib.ra_raw_channels(self.ctx)
+        raw = torch.empty(x.shape[0], C_, device=self.device, dtype=torch.float32)
+        check(self.lib.ra_forward(self.ctx, _ptr(x), _ptr(v), x.shape[0], dist_th, _ptr(raw), self.stream), 'ra_forward')
+        return raw
+
+    def trace_params(self, tc, dist_th, soft, iters=None) -> ra_trace_params:
+        st = self.cfg.sphere_tracing
+        return ra_trace_params(iters=int(tc.iter if iters is None else iters), tan_i=st.tan_i, tan_i_multiplier=st.tan_i_multiplier,
+                               relax=tc.relax, offset=tc.offset, eps=st.eps, shadow_skip_iter=st.shadow_skip_iter,
+                               clay_book=int(not self.cfg.no_claybook), soft_shadow=int(soft), dist_th=dist_th)
+
+    def sphere_trace(self, ray_o, ray_d, near, far, params: ra_trace_params, tan_i=None):
+        d = self.device
+        ray_o, ray_d = _f32(ray_o.reshape(-1, 3), d), _f32(ray_d.reshape(-1, 3), d)
+        near, far = _f32(near.reshape(-1), d), _f32(far.reshape(-1), d)
+        tan_i = None if tan_i is None else _f32(tan_i.reshape(-1), d)
+        n = ray_o.shape[0]
+        surf = torch.empty(n, 3, device=d)
+        occ, st, ot = (torch.empty(n, device=d) for _ in range(3))
+        check(self.lib.ra_sphere_trace(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(near), _ptr(far), _ptr(tan_i), n, C.byref(params),
+                                       _ptr(surf), _ptr(occ), _ptr(st), _ptr(ot), self.stream), 'ra_sphere_trace')
+        return surf, occ, st, ot
+
+    def sphere_params(self) -> ra_sphere_params:
+        c = self.cfg
+        return ra_sphere_params(surface=self.trace_params(c.sphere_tracing, c.dist_th, False),
+                                shadow=self.trace_params(c.obj_lvis, c.obj_lvis.dist_th, not c.no_dfss),
+                                shadow_near_offset=c.obj_lvis.near_offset, dist_th=c.dist_th,
+                                surf_sample_range=c.surf_sample_range, n_samples=c.n_samples, relighting=int(c.relighting),
+                                no_visibility=int(c.no_visibility), local_visibility=int(c.local_visibility), premultiply=1)
+
+    def render_sphere_chunk(self, ray_o, ray_d, near, far, bbox6, probe, params, outs: dict):
+        """ray tensors: contiguous fp32 device views (P,3)/(P,); outs: name -> tensor view or missing."""
+        P = ray_o.shape[0]
+        ro = ra_render_out(**{k: _ptr(outs.get(k)) for k in _lib.RENDER_OUT_KEYS})
+        bb = (C.c_float * 6)(*[float(v) for v in bbox6]) if bbox6 is not None else None
+        ph, pw = (probe.shape[0], probe.shape[1]) if probe is not None else (0, 0)
+        check(self.lib.ra_render_sphere_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(near), _ptr(far), P, bb, _ptr(probe), ph, pw,
+                                              C.byref(params), C.byref(ro), self.stream), 'ra_render_sphere_chunk')
+
+    def render_volume_chunk(self, ray_o, ray_d, near, far, n_samples, dist_th, outs: dict):
+        P = ray_o.shape[0]
+        ro = ra_render_out(**{k: _ptr(outs.get(k)) for k in _lib.RENDER_OUT_KEYS})
+        check(self.lib.ra_render_volume_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(near), _ptr(far), P, n_samples, dist_th,
+                                              C.byref(ro), self.stream), 'ra_render_volume_chunk')
+
+    def reshade(self, ray_o, surf, norm, albedo, rough, lvis, ldot, probes, want_spec=True):
+        """probes (n,h,w,3) -> rgb, shade, spec each (n,P,3)."""
+        d = self.device
+        a = [_f32(t, d) for t in (ray_o.reshape(-1, 3), surf.reshape(-1, 3), norm.reshape(-1, 3), albedo.reshape(-1, 3), rough.reshape(-1))]
+        P = a[0].shape[0]
+        lvis, ldot = _f32(lvis.reshape(P, -1), d), _f32(ldot.reshape(P, -1), d)
+        probes = _f32(probes, d)
+        n, ph, pw = probes.shape[0], probes.shape[1], probes.shape[2]
+        rgb, shade = torch.empty(n, P, 3, device=d), torch.empty(n, P, 3, device=d)
+        spec = torch.empty(n, P, 3, device=d) if want_spec else None
+        check(self.lib.ra_reshade(self.ctx, *[_ptr(t) for t in a], _ptr(lvis), _ptr(ldot), P, _ptr(probes), n, ph, pw,
+                                  _ptr(rgb), _ptr(shade), _ptr(spec), self.stream), 'ra_reshade')
+        return rgb, shade, spec
+
+    # ------------------------------------------------------------------ measurement
+    def counters(self) -> dotdict:
+        c = ra_counters()
+        check(self.lib.ra_get_counters(self.ctx, C.byref(c), self.stream), 'ra_get_counters')
+        return dotdict({k: int(getattr(c, k)) for k, _ in ra_counters._fields_})
+
+    def reset_counters(self):
+        check(self.lib.ra_reset_counters(self.ctx, self.stream), 'ra_reset_counters')
+
+    def enable_timing(self, on=True):
+        check(self.lib.ra_enable_timing(self.ctx, int(on)), 'ra_enable_timing')
+
+    def mlp_time(self):
+        ms, n = C.c_float(), C.c_int()
+        check(self.lib.ra_get_mlp_time(self.ctx, C.byref(ms), C.byref(n), self.stream), 'ra_get_mlp_time')
+        return float(ms.value), int(n.value)
+
+    # ------------------------------------------------------------------ test hooks
+    def debug_mlp(self, bpts, want_feat=True):
+        d = self.device
+        bpts = _f32(bpts.reshape(-1, 3), d)
+        n = bpts.shape[0]
+        resd, sdf = torch.empty(n, 3, device=d), torch.empty(n, device=d)
+        feat = torch.empty(n, 256, device=d) if want_feat else None
+        check(self.lib.ra_debug_mlp(self.ctx, _ptr(bpts), n, _ptr(resd), _ptr(sdf), _ptr(feat), self.stream), 'ra_debug_mlp')
+        return resd, sdf, feat
+
+    def debug_full(self, bpts):
+        d = self.device
+        bpts = _f32(bpts.reshape(-1, 3), d)
+        n = bpts.shape[0]
+        grad, sdf, feat = torch.empty(n, 3, device=d), torch.empty(n, device=d), torch.empty(n, 256, device=d)
+        raw = torch.zeros(n, self.lib.ra_raw_channels(self.ctx), device=d)
+        check(self.lib.ra_debug_full(self.ctx, _ptr(bpts), n, _ptr(grad), _ptr(sdf), _ptr(feat), _ptr(raw), self.stream), 'ra_debug_full')
+        return grad, sdf, feat, raw
+
+    def debug_hdq(self, x, dist_th):
+        d = self.device
+        x = _f32(x.reshape(-1, 3), d)
+        n = x.shape[0]
+        o = dotdict(sdf_coarse=torch.empty(n, device=d), sdf_batch=torch.empty(n, 3, device=d),
+                    nn_batch=torch.empty(n, 3, device=d, dtype=torch.int32), d2=torch.empty(n, 3, device=d),
+                    bpts=torch.empty(n, 3, device=d), tpts=torch.empty(n, 3, device=d), mats=torch.empty(n, 24, device=d))
+        cnt = C.c_int()
+        check(self.lib.ra_debug_hdq(self.ctx, _ptr(x), n, dist_th, _ptr(o.sdf_coarse), _ptr(o.sdf_batch), _ptr(o.nn_batch), _ptr(o.d2),
+                                    _ptr(o.bpts), _ptr(o.tpts), _ptr(o.mats), C.byref(cnt), self.stream), 'ra_debug_hdq')
+        o.fine_count = int(cnt.value)
+        return o

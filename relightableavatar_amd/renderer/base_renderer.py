@@ -1,0 +1,40 @@
+"""Volume renderer, host-side mirror of lib/networks/renderer/base_renderer.py (eval path):
+uniform samples between near/far, Network.forward per sample, alpha compositing — one
+ra_render_volume_chunk call per chunk of cfg.render_chunk_size rays."""
+import torch
+from torch import nn
+
+from .. import config
+from ..base_utils import dotdict
+from .chunking import chunks
+
+
+class Renderer(nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.cfg = config.active_cfg()
+
+    @torch.no_grad()
+    def render(self, batch):
+        cfg = self.cfg
+        eng = self.net.set_frame(batch)
+        dev = eng.device
+        f = lambda t: t[0].to(dev, torch.float32).contiguous()
+        ray_o, ray_d = f(batch.ray_o), f(batch.ray_d)
+        near = f(batch.near).clip(min=cfg.clip_near)      # base_renderer.py:120-121
+        far = f(batch.far).clip(max=cfg.clip_far)
+        P = ray_o.shape[0]
+        full = dotdict(rgb=torch.zeros(P, 3, device=dev), acc=torch.zeros(P, device=dev), depth=torch.zeros(P, device=dev),
+                       norm=torch.zeros(P, 3, device=dev), cpts=torch.zeros(P, 3, device=dev), bpts=torch.zeros(P, 3, device=dev),
+                       resd=torch.zeros(P, 3, device=dev))
+        for a, b in chunks(P, cfg.render_chunk_size):
+            eng.render_volume_chunk(ray_o[a:b], ray_d[a:b], near[a:b], far[a:b], cfg.n_samples, cfg.dist_th,
+                                    {k: v[a:b] for k, v in full.items()})
+        ret = dotdict()
+        ret.depth_map = full.depth[None]
+        ret.cpts_map, ret.bpts_map, ret.resd_map = full.cpts[None], full.bpts[None], full.resd[None]
+        ret.norm_map = full.norm[None]
+        ret.rgb_map = full.rgb[None]
+        ret.acc_map = full.acc[None]
+        return ret
