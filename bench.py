@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s for a 512x512 full-relight frame (16x32 light probe, DFSS visibility)
+on synthetic weights, N GPUs of one node (one process per GPU, rays dealt round-robin, one RCCL
+all_gather per frame).  Prints ONE JSON line on rank 0 (see the contract in the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--mode relight|sphere|anisdf]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from relightableavatar_amd import synthetic, shard          # noqa: E402
+from relightableavatar_amd.config import make_cfg           # noqa: E402
+from relightableavatar_amd.networks import make_network     # noqa: E402
+from relightableavatar_amd.renderer import make_renderer    # noqa: E402
+
+F_SDF = 1_901_568          # algorithmic FLOP per fine distance query
+F_FULL = 3_934_208 + 197_632
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline(cfg, H, n_target=256):
+    """oracle (CPU port of the reference path) on a strided sample of the same frame's rays."""
+    from oracle import ra_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    batch = synthetic.make_batch(H, H, seed=0, posed=True)
+    P = batch.ray_o.shape[1]
+    stride = max(1, P // n_target)
+    for k in shard.RAY_KEYS:
+        batch[k] = batch[k][:, ::stride].contiguous()
+    n = batch.ray_o.shape[1]
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=bool(cfg.relighting), cfg=cfg), cfg)
+    t0 = time.perf_counter()
+    if cfg.renderer_module.endswith('base_renderer'):
+        O.render_volume(net, batch)
+    else:
+        O.render_sphere_tracing(net, batch)
+    dt = time.perf_counter() - t0
+    # rays outside the body's bounding box cost nothing on either side: scale to whole-frame rays
+    return dict(value=(n / P) * H * H / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'every {stride}th of the {P} in-box rays of the same {H}x{H} frame ({n} rays, {dt:.1f} s), '
+                       f'torch fp32 CPU restatement of the reference path (oracle/ra_oracle.py)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--mode', default='relight', choices=['relight', 'sphere_tracing', 'anisdf'])
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs MI355X GPUs (the render path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    H = args.size
+    cfg = make_cfg(args.mode, mlp_dtype=args.dtype)
+    relight = args.mode == 'relight'
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
+    net = net.to(dev).eval()
+    renderer = make_renderer(cfg, net)
+    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True), dev)
+    P = base.ray_o.shape[1]
+    wb0 = base.wbounds.clone()
+    eng = net.engine()
+
+    def step():
+        base.wbounds.copy_(wb0)     # a fresh batch per frame, as the reference's loader delivers
+        return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.reset_counters()
+    eng.enable_timing(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    eng.enable_timing(False)
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    cnt = eng.counters()
+    mlp_ms, mlp_launches = eng.mlp_time()
+    cnts = torch.tensor([cnt.n_fine_sdf, cnt.n_fine_full, cnt.n_coarse, cnt.n_hit_pixels, cnt.n_shadow_rays], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(cnts)
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        achieved = (cnt.n_fine_sdf * F_SDF) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        line = {
+            'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'xuzhen_12v_geo_fix_mat-shaped full relight, {H}x{H}, 16x32 light probe, DFSS visibility (4 iters), '
+                                   f'16-iter surface trace, synthetic weights/body' if relight else f'{args.mode} {H}x{H}',
+                       'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
+                       'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
+                       'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'rays round-robin over {world} GPU(s) + all_gather'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
+                         'traffic': None, 'kernel': 'mlp_sdf_kernel', 'launches': mlp_launches,
+                         'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': F_SDF,
+                         'units_per_launch': cnt.n_fine_sdf / max(mlp_launches, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg, H)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

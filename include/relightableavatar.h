@@ -54,6 +54,7 @@ typedef struct ra_config {
     int   lambert_only, glossy_only;          /* ablation switches (config.py:48-49)              */
     int   tonemapping;                        /* cfg.tonemapping_rendering                        */
     float bg_brightness;                      /* 0.0                                              */
+    int   mlp_f16;                            /* element type of the fused MLP kernels: 1 = IEEE half, 0 = bfloat16 (same MFMA rate) */
 } ra_config;
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 

@@ -21,7 +21,7 @@ class ra_config(C.Structure):
                 ('resd_limit', C.c_float), ('blend_radius', C.c_float), ('albedo_slope', C.c_float), ('albedo_bias', C.c_float),
                 ('roughness_slope', C.c_float), ('roughness_bias', C.c_float), ('fresnel_f0', C.c_float),
                 ('shading_albedo', C.c_float), ('albedo_multiplier', C.c_float), ('lambert_only', C.c_int),
-                ('glossy_only', C.c_int), ('tonemapping', C.c_int), ('bg_brightness', C.c_float)]
+                ('glossy_only', C.c_int), ('tonemapping', C.c_int), ('bg_brightness', C.c_float), ('mlp_f16', C.c_int)]
 
 
 class ra_frame(C.Structure):

@@ -97,7 +97,7 @@ def default_cfg() -> dotdict:
     c.test_light = ['main']
     c.vis_rotate_light = False
     # build-side knobs (not in the reference)
-    c.mlp_dtype = 'bf16'         # arithmetic type of the fused MLP kernels
+    c.mlp_dtype = 'f16'          # element type of the fused MLP kernels: 'f16' or 'bf16' (fp32 accumulate either way)
     return c
 
 

@@ -186,10 +186,10 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     MlpIO io{};
     io.bpts = bpts; io.idx = fine_idx; io.count = icnt(c, CNT_FINE); io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
-    io.counters = dcnt(c);
+    io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
-        launch_mlp_sdf(c->host.geo, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+        launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
     }
     return 0;
 }
@@ -220,7 +220,7 @@ int forward_pass(ra_ctx* c, const float* x, const float* v, int n, const int* n_
     io.counters = dcnt(c);
     {
         Timer t(c, s, 1);
-        launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+        launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
     }
     return 0;
 }
@@ -550,9 +550,9 @@ int ra_debug_mlp(ra_ctx* c, const float* bpts, int n, float* resd, float* sdf, f
     RA_HIP(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, s));
     RA_HIP(hipStreamSynchronize(s));
     MlpIO io{};
-    io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = nullptr; io.dist_th = 1.f; io.smooth = 0;
+    io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = nullptr; io.dist_th = 1.f; io.smooth = 0; io.resd_limit = c->cfg.resd_limit;
     io.dbg_resd = resd; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
-    launch_mlp_sdf(c->host.geo, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+    launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
     RA_HIP(hipGetLastError());
     return 0;
 }
@@ -580,7 +580,7 @@ int ra_debug_full(ra_ctx* c, const float* bpts, int n, float* grad, float* sdf, 
     io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
     io.relight = c->cfg.relight;
     io.dbg_grad = grad; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
-    launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.as<bf16x8>(), c->barena.as<float>(), c->fr, io, n, s);
+    launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
     RA_HIP(hipGetLastError());
     return 0;
 }

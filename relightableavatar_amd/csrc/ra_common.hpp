@@ -32,7 +32,8 @@ struct GeoNet {             // residual deformation + signed distance networks
     WideLayer r4b;          // PE part of the skip layer (bias unused)
     WideLayer rhead;        // 256 -> 3 (rows padded to 32)
     // sdf net (net_utils.py:1276-1352): l0 K=64 (PE8 padded), l1,l2, l3 (205 rows + 51 zero rows), l4..l7 (1/sqrt2 folded into l4), l8
-    WideLayer s[8];
+    WideLayer s[8];         // s[4] = the 205-wide part of the skip layer (cols 205..255 zero)
+    WideLayer s4b;          // [PE8 51 | lo 9 | pad 4] part of the skip layer, 1/sqrt2 folded (bias unused)
     WideLayer shead;        // row 0 = sdf
     WideLayer sfeat;        // rows = feat 0..255 (lin8 rows 1..256)
     // per-frame folded biases for r[0] and r[4] live in frame state (cond folded in)
@@ -80,6 +81,7 @@ struct MlpIO {
     float* sdf;             // per point: in = coarse smpl sdf, out = blended HDQ sdf
     float dist_th;
     int smooth;
+    float resd_limit;
     // debug / stage outputs (nullable)
     float* dbg_resd;        // n_slots x 3
     float* dbg_sdf;         // n_slots (raw network sdf)
@@ -106,10 +108,11 @@ struct FullIO {             // geometry + material / colour forward with tangent
     DevCounters* counters;  // nullable
 };
 
-void launch_mlp_sdf(const GeoNet& net, const bf16x8* warena, const float* barena, const FrameState& fr,
-                    const MlpIO& io, int max_slots, hipStream_t stream);
-void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const bf16x8* warena,
-                     const float* barena, const FrameState& fr, const FullIO& io, int max_slots, hipStream_t stream);
+// f16w: weights/activations are IEEE half (true) or bfloat16 (false); the arena was packed accordingly
+void launch_mlp_sdf(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr,
+                    const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
+void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const void* warena,
+                     const float* barena, const FrameState& fr, const FullIO& io, int max_slots, bool f16w, hipStream_t stream);
 
 // --- error plumbing ---------------------------------------------------------------------------
 void ra_set_error(const std::string& msg);

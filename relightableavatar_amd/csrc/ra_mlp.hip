@@ -32,10 +32,24 @@ namespace {
 
 constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2;
 constexpr float INV_2PI = 0.15915494309189535f;
+// forward-mode tangent columns are carried scaled by TS for fp16 headroom (everything acting on
+// them is linear); heads divide it back out.
+constexpr float TS = 1.f / 16.f;
 
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+// element type of weights/activations: bf16 or f16 (same MFMA rate, f16 has 3 more mantissa bits)
+template <typename E> struct Tr;
+template <> struct Tr<bf16> {
+    typedef bf16x8 x8; typedef bf16x4 x4;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Tr<f16> {
+    typedef f16x8 x8; typedef f16x4 x4;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 // y = act(z), dy = act'(z)
 template <int ACT>
@@ -56,23 +70,24 @@ __device__ __forceinline__ float act_fn(float z, float& dy) {
 }
 
 // acc[nt][mt] += W[64*wave + 32*nt .. +32, kcols] . X[32*mt .. +32, kcol0 .. kcol0 + 16*KS]^T
-template <int KS, int MT>
-__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[2][MT], const bf16x8* __restrict__ wl, const bf16* xs,
+template <typename E, int KS, int MT>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[2][MT], const typename Tr<E>::x8* __restrict__ wl, const E* xs,
                                           int kcol0, int wave, int lane) {
-    const bf16x8* a0p = wl + (size_t)((2 * wave + 0) * KS) * 64 + lane;
-    const bf16x8* a1p = wl + (size_t)((2 * wave + 1) * KS) * 64 + lane;
-    const bf16* bp = xs + (lane & 31) * XS + kcol0 + (lane >> 5) * 8;
+    typedef typename Tr<E>::x8 x8;
+    const x8* a0p = wl + (size_t)((2 * wave + 0) * KS) * 64 + lane;
+    const x8* a1p = wl + (size_t)((2 * wave + 1) * KS) * 64 + lane;
+    const E* bp = xs + (lane & 31) * XS + kcol0 + (lane >> 5) * 8;
 #pragma unroll 2
     for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 a0 = a0p[ks * 64];
-        const bf16x8 a1 = a1p[ks * 64];
-        bf16x8 b[MT];
+        const x8 a0 = a0p[ks * 64];
+        const x8 a1 = a1p[ks * 64];
+        x8 b[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const bf16x8*>(bp + mt * 32 * XS + ks * 16);
+        for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const x8*>(bp + mt * 32 * XS + ks * 16);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            acc[0][mt] = mfma32(a0, b[mt], acc[0][mt]);
-            acc[1][mt] = mfma32(a1, b[mt], acc[1][mt]);
+            acc[0][mt] = Tr<E>::mfma(a0, b[mt], acc[0][mt]);
+            acc[1][mt] = Tr<E>::mfma(a1, b[mt], acc[1][mt]);
         }
     }
 }
@@ -87,16 +102,17 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][MT]) {
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
 }
 
-__device__ __forceinline__ void store4(bf16* dst, float a, float b, float c, float d) {
-    bf16x4 v;
-    v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
-    *reinterpret_cast<bf16x4*>(dst) = v;
+template <typename E>
+__device__ __forceinline__ void store4(E* dst, float a, float b, float c, float d) {
+    typename Tr<E>::x4 v;
+    v[0] = (E)a; v[1] = (E)b; v[2] = (E)c; v[3] = (E)d;
+    *reinterpret_cast<typename Tr<E>::x4*>(dst) = v;
 }
 
 // write act(acc + bias) as bf16 into xs[:, 0..255]; GRAD: column group 0 is the primal,
 // groups 1..3 hold tangents and get act'(z_primal) * t (no bias).
-template <int ACT, bool GRAD, int MT>
-__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], const float* __restrict__ bias, bf16* xs,
+template <typename E, int ACT, bool GRAD, int MT>
+__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], const float* __restrict__ bias, E* xs,
                                               int wave, int lane) {
     const int mrow = lane & 31;
 #pragma unroll
@@ -129,34 +145,44 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], const 
 
 // <=32 output rows; wave w handles columns [32w, 32w+32). Lanes 0..31 end up with rows 0..3 of
 // column 32w+lane in acc[0..3].
-template <int KS>
-__device__ __forceinline__ f32x16 gemm_head(const bf16x8* __restrict__ wl, const bf16* xs, int kcol0, int colgrp, int lane) {
+template <typename E, int KS>
+__device__ __forceinline__ f32x16 gemm_head(const typename Tr<E>::x8* __restrict__ wl, const E* xs, int kcol0, int colgrp, int lane) {
+    typedef typename Tr<E>::x8 x8;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bf16x8* ap = wl + lane;
-    const bf16* bp = xs + (colgrp * 32 + (lane & 31)) * XS + kcol0 + (lane >> 5) * 8;
+    const x8* ap = wl + lane;
+    const E* bp = xs + (colgrp * 32 + (lane & 31)) * XS + kcol0 + (lane >> 5) * 8;
 #pragma unroll 4
     for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 a = ap[ks * 64];
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
-        acc = mfma32(a, b, acc);
+        const x8 a = ap[ks * 64];
+        const x8 b = *reinterpret_cast<const x8*>(bp + ks * 16);
+        acc = Tr<E>::mfma(a, b, acc);
     }
     return acc;
 }
 
 // positional encoding of one column into row[0 .. 3+6L) (embedder.py:26-37 channel order:
-// x, then per frequency the 3 sines then the 3 cosines), optional zero padding up to npad.
-// half h of the frequencies is written by this thread. jrow == nullptr: primal values;
-// otherwise the tangent: d channel / d b_j = channel'(x_c) * J[c][j] with jcol = J[:, j].
-template <int L>
-__device__ __forceinline__ void pe_write_col(bf16* row, const float x[3], const float* jcol, int h, int npad) {
+// x, then per frequency the 3 sines then the 3 cosines).  Thread half h writes half of the
+// frequencies.  jcol == nullptr: primal values; otherwise the (scaled) tangent
+//   d channel / d b_j = channel'(x_c) * J[c][j],  jcol = J[:, j] * TS.
+// LO: 9 extra columns [3+6L, 3+6L+9) carry the rounding residual v - E(v) of the identity and
+// frequency-0 channels (their weights are duplicated by the packer), so the first layer sees
+// those inputs at ~2x the element precision.  Columns up to npad are zero-filled.
+template <typename E, int L, bool LO>
+__device__ __forceinline__ void pe_write_col(E* row, const float x[3], const float* jcol, int h, int npad) {
     float rev[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) rev[c] = x[c] * INV_2PI;
+    constexpr int NB = 3 + 6 * L;
     if (h == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) row[c] = (bf16)(jcol ? jcol[c] : x[c]);
+        for (int c = 0; c < 3; ++c) {
+            const float v = jcol ? jcol[c] : x[c];
+            const E hi = (E)v;
+            row[c] = hi;
+            if (LO) row[NB + c] = (E)(jcol ? 0.f : v - (float)hi);
+        }
     }
     const int f0 = h * (L / 2), f1 = f0 + (L / 2);
 #pragma unroll
@@ -167,35 +193,41 @@ __device__ __forceinline__ void pe_write_col(bf16* row, const float x[3], const 
             const float a = rev[c] * sc;                  // revolutions; exact power-of-two scaling
             const float s = __builtin_amdgcn_sinf(a);
             const float co = __builtin_amdgcn_cosf(a);
-            if (jcol) {
-                row[3 + 6 * f + c] = (bf16)(sc * co * jcol[c]);
-                row[3 + 6 * f + 3 + c] = (bf16)(-sc * s * jcol[c]);
-            } else {
-                row[3 + 6 * f + c] = (bf16)s;
-                row[3 + 6 * f + 3 + c] = (bf16)co;
+            float vs, vc;
+            if (jcol) { vs = sc * co * jcol[c]; vc = -sc * s * jcol[c]; }
+            else { vs = s; vc = co; }
+            const E hs = (E)vs, hc = (E)vc;
+            row[3 + 6 * f + c] = hs;
+            row[3 + 6 * f + 3 + c] = hc;
+            if (LO && f == 0) {
+                row[NB + 3 + c] = (E)(jcol ? 0.f : vs - (float)hs);
+                row[NB + 6 + c] = (E)(jcol ? 0.f : vc - (float)hc);
             }
         }
     }
     if (h == 1)
-        for (int c = 3 + 6 * L; c < npad; ++c) row[c] = (bf16)0.f;
+        for (int c = NB + (LO ? 9 : 0); c < npad; ++c) row[c] = (E)0.f;
 }
 
+template <typename E>
 struct Smem {
-    bf16 xs[TM * XS];       // activation tile
+    E xs[TM * XS];          // activation tile
     float pts[TM * 4];      // big-pose point of each column (xyz, pad)
     float cpts[TM * 4];     // canonical point (bpts + resd)
     float misc[TM * 4];     // head outputs
-    float jac[32 * 12];     // full kernel: d cpts / d bpts per point (row-major 3x3 + pad)
+    float jac[32 * 12];     // full kernel: d cpts / d bpts per point (row-major 3x3)
     int count;
 };
 
 // =============================================================================================
 //  K3: HDQ fine query — resd + sdf (sdf only) on 128 points per tile, blend epilogue
 // =============================================================================================
-template <bool DEBUG>
-__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, const bf16x8* __restrict__ wa,
+template <typename E, bool DEBUG>
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, const void* __restrict__ wa_,
                                                                 const float* __restrict__ ba, FrameState fr, MlpIO io) {
-    __shared__ __attribute__((aligned(16))) Smem sm;
+    typedef typename Tr<E>::x8 x8;
+    const x8* __restrict__ wa = reinterpret_cast<const x8*>(wa_);
+    __shared__ __attribute__((aligned(16))) Smem<E> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sm.count = *io.count;
     __syncthreads();
@@ -216,36 +248,36 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, con
         const int pm = tid >> 1, ph = tid & 1;
         // ---- residual deformation net
         { const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
-          pe_write_col<10>(sm.xs + pm * XS, x, nullptr, ph, 64); }
+          pe_write_col<E, 10, false>(sm.xs + pm * XS, x, nullptr, ph, 64); }
         __syncthreads();
         zero_acc<4>(acc);
-        gemm_wide<4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
+        gemm_wide<E, 4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<ACT_RELU, false, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_RELU, false, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
             zero_acc<4>(acc);
-            gemm_wide<16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (l == 4) {   // skip: cat([x, input]) — re-encode the input into cols 0..63 and accumulate
                 const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
-                pe_write_col<10>(sm.xs + pm * XS, x, nullptr, ph, 64);
+                pe_write_col<E, 10, false>(sm.xs + pm * XS, x, nullptr, ph, 64);
                 __syncthreads();
-                gemm_wide<4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
-            epilogue_wide<ACT_RELU, false, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_RELU, false, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
             __syncthreads();
         }
-        {   // head: resd = tanh(z) * resd_limit (0.05); cpts = bpts + resd
-            const f32x16 h = gemm_head<16>(wa + net.rhead.w, sm.xs, 0, wave, lane);
+        {   // head: resd = tanh(z) * resd_limit; cpts = bpts + resd
+            const f32x16 h = gemm_head<E, 16>(wa + net.rhead.w, sm.xs, 0, wave, lane);
             if (lane < 32) {
                 const int m = wave * 32 + lane;
                 const float* b = ba + net.rhead.bias;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float resd = tanhf(h[c] + b[c]) * 0.05f;
+                    const float resd = tanhf(h[c] + b[c]) * io.resd_limit;
                     sm.cpts[4 * m + c] = sm.pts[4 * m + c] + resd;
                     if (DEBUG && io.dbg_resd && slot0 + m < count) io.dbg_resd[3 * (slot0 + m) + c] = resd;
                 }
@@ -254,32 +286,37 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, con
         __syncthreads();
         // ---- signed distance net
         { const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
-          pe_write_col<8>(sm.xs + pm * XS, x, nullptr, ph, 64); }
+          pe_write_col<E, 8, true>(sm.xs + pm * XS, x, nullptr, ph, 64); }
         __syncthreads();
         zero_acc<4>(acc);
-        gemm_wide<4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
+        gemm_wide<E, 4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<ACT_SOFTPLUS, false, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_SOFTPLUS, false, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
             zero_acc<4>(acc);
-            gemm_wide<16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<ACT_SOFTPLUS, false, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
-            __syncthreads();
-            if (l == 3) {   // skip: cat([x(205), input(51)]) / sqrt(2): input goes to cols 205..255
+            if (l == 4) {   // skip: cat([x(205), input(51)]) / sqrt(2): the input part is a second K=64 pass
                 const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
-                pe_write_col<8>(sm.xs + pm * XS + 205, x, nullptr, ph, 51);
+                pe_write_col<E, 8, true>(sm.xs + pm * XS, x, nullptr, ph, 64);
+                __syncthreads();
+                gemm_wide<E, 4, 4>(acc, wa + net.s4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
+            epilogue_wide<E, ACT_SOFTPLUS, false, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
+            __syncthreads();
         }
         if (DEBUG && io.dbg_feat) {     // feature rows of lin8 (test hook; the product path uses the full kernel)
             zero_acc<4>(acc);
-            gemm_wide<16, 4>(acc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 4>(acc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
             const float* b = ba + net.sfeat.bias;
+#pragma unroll
             for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int n = 64 * wave + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         const int s = slot0 + mt * 32 + (lane & 31);
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, con
                     }
         }
         {   // head: sdf, then the HDQ blend (base_network.py:374-382)
-            const f32x16 h = gemm_head<16>(wa + net.shead.w, sm.xs, 0, wave, lane);
+            const f32x16 h = gemm_head<E, 16>(wa + net.shead.w, sm.xs, 0, wave, lane);
             if (lane < 32) {
                 const int s = slot0 + wave * 32 + lane;
                 if (s < count) {
@@ -342,10 +379,13 @@ __device__ __forceinline__ float sdf_to_occ_dev(float sdf, float beta) {   // ne
     return 1.f - expf(-fmaxf(sigma, 0.f) * 0.005f);
 }
 
+template <typename E>
 __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, MatNet mat, ColNet col,
-                                                                 const bf16x8* __restrict__ wa, const float* __restrict__ ba,
+                                                                 const void* __restrict__ wa_, const float* __restrict__ ba,
                                                                  FrameState fr, FullIO io) {
-    __shared__ __attribute__((aligned(16))) Smem sm;
+    typedef typename Tr<E>::x8 x8;
+    const x8* __restrict__ wa = reinterpret_cast<const x8*>(wa_);
+    __shared__ __attribute__((aligned(16))) Smem<E> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sm.count = *io.count;
     __syncthreads();
@@ -361,48 +401,46 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
             const int s = slot0 + tid;
             float x = 0.f, y = 0.f, z = 0.f;
             if (s < count) { x = io.bpts[3 * s]; y = io.bpts[3 * s + 1]; z = io.bpts[3 * s + 2]; }
-            sm.pts[4 * tid] = x; sm.pts[4 * tid + 1] = y; sm.pts[4 * tid + 2] = z;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sm.jac[12 * tid + i] = (i % 4 == 0) ? 1.f : 0.f;   // identity for the resd PE
+            sm.pts[4 * tid] = x; sm.pts[4 * tid + 1] = y; sm.pts[4 * tid + 2] = z; sm.pts[4 * tid + 3] = 0.f;
         }
         __syncthreads();
         auto write_pe10 = [&]() {
             const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
-            if (pg == 0) pe_write_col<10>(sm.xs + pm * XS, x, nullptr, ph, 64);
-            else { const float jc[3] = {pg == 1 ? 1.f : 0.f, pg == 2 ? 1.f : 0.f, pg == 3 ? 1.f : 0.f};
-                   pe_write_col<10>(sm.xs + (pg * 32 + pm) * XS, x, jc, ph, 64); }
+            if (pg == 0) pe_write_col<E, 10, false>(sm.xs + pm * XS, x, nullptr, ph, 64);
+            else { const float jc[3] = {pg == 1 ? TS : 0.f, pg == 2 ? TS : 0.f, pg == 3 ? TS : 0.f};
+                   pe_write_col<E, 10, false>(sm.xs + (pg * 32 + pm) * XS, x, jc, ph, 64); }
         };
-        auto write_pe8 = [&](int col0, int npad) {
+        auto write_pe8 = [&]() {
             const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
-            if (pg == 0) pe_write_col<8>(sm.xs + pm * XS + col0, x, nullptr, ph, npad);
+            if (pg == 0) pe_write_col<E, 8, true>(sm.xs + pm * XS, x, nullptr, ph, 64);
             else { const float* J = sm.jac + 12 * pm; const int j = pg - 1;
-                   const float jc[3] = {J[0 + j], J[3 + j], J[6 + j]};
-                   pe_write_col<8>(sm.xs + (pg * 32 + pm) * XS + col0, x, jc, ph, npad); }
+                   const float jc[3] = {J[0 + j] * TS, J[3 + j] * TS, J[6 + j] * TS};
+                   pe_write_col<E, 8, true>(sm.xs + (pg * 32 + pm) * XS, x, jc, ph, 64); }
         };
         // ---- residual deformation net with tangents
         write_pe10();
         __syncthreads();
         zero_acc<4>(acc);
-        gemm_wide<4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
+        gemm_wide<E, 4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<ACT_RELU, true, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_RELU, true, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
             zero_acc<4>(acc);
-            gemm_wide<16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (l == 4) {
                 write_pe10();
                 __syncthreads();
-                gemm_wide<4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
-            epilogue_wide<ACT_RELU, true, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_RELU, true, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
             __syncthreads();
         }
-        {   // head: wave g holds z (g = 0) or dz/db_{g-1}
-            const f32x16 h = gemm_head<16>(wa + net.rhead.w, sm.xs, 0, wave, lane);
+        {   // head: wave g holds z (g = 0) or TS * dz/db_{g-1}
+            const f32x16 h = gemm_head<E, 16>(wa + net.rhead.w, sm.xs, 0, wave, lane);
             if (lane < 32) { sm.misc[4 * (wave * 32 + lane) + 0] = h[0]; sm.misc[4 * (wave * 32 + lane) + 1] = h[1];
                              sm.misc[4 * (wave * 32 + lane) + 2] = h[2]; }
         }
@@ -415,43 +453,51 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
                 const float resd = th * io.resd_limit;
                 sm.cpts[4 * tid + c] = sm.pts[4 * tid + c] + resd;
                 sm.pts[4 * tid + 3] = 0.f;
-                const float dth = (1.f - th * th) * io.resd_limit;
+                const float dth = (1.f - th * th) * io.resd_limit * (1.f / TS);
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     sm.jac[12 * tid + 3 * c + j] = (c == j ? 1.f : 0.f) + dth * sm.misc[4 * ((j + 1) * 32 + tid) + c];
+                sm.jac[12 * tid + 9 + c] = resd;
             }
         }
         __syncthreads();
         // ---- signed distance net with tangents
-        write_pe8(0, 64);
+        write_pe8();
         __syncthreads();
         zero_acc<4>(acc);
-        gemm_wide<4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
+        gemm_wide<E, 4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<ACT_SOFTPLUS, true, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_SOFTPLUS, true, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
             zero_acc<4>(acc);
-            gemm_wide<16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<ACT_SOFTPLUS, true, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
+            if (l == 4) {
+                write_pe8();
+                __syncthreads();
+                gemm_wide<E, 4, 4>(acc, wa + net.s4b.w, sm.xs, 0, wave, lane);
+                __syncthreads();
+            }
+            epilogue_wide<E, ACT_SOFTPLUS, true, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
             __syncthreads();
-            if (l == 3) { write_pe8(205, 51); __syncthreads(); }
         }
-        {   // sdf head on all four column groups: value and the three partials
-            const f32x16 h = gemm_head<16>(wa + net.shead.w, sm.xs, 0, wave, lane);
+        {   // sdf head on all four column groups: value and the three (scaled) partials
+            const f32x16 h = gemm_head<E, 16>(wa + net.shead.w, sm.xs, 0, wave, lane);
             if (lane < 32) sm.misc[4 * (wave * 32 + lane) + 3] = h[0];
         }
         // features (primal columns only) -> xs rows 0..31 as the next net's input
         f32x16 facc[2][1];
         zero_acc<1>(facc);
-        gemm_wide<16, 1>(facc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
+        gemm_wide<E, 16, 1>(facc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<ACT_NONE, false, 1>(facc, ba + net.sfeat.bias, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_NONE, false, 1>(facc, ba + net.sfeat.bias, sm.xs, wave, lane);
         if (io.dbg_feat) {
             const float* b = ba + net.sfeat.bias;
+#pragma unroll
             for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = 64 * wave + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int s = slot0 + (lane & 31);
@@ -464,7 +510,8 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
         float sdfv = 0.f, occ = 0.f;
         if (tid < 32) {
             sdfv = sm.misc[4 * tid + 3] + ba[net.shead.bias];
-            float g[3] = {sm.misc[4 * (32 + tid) + 3], sm.misc[4 * (64 + tid) + 3], sm.misc[4 * (96 + tid) + 3]};
+            float g[3] = {sm.misc[4 * (32 + tid) + 3] * (1.f / TS), sm.misc[4 * (64 + tid) + 3] * (1.f / TS),
+                          sm.misc[4 * (96 + tid) + 3] * (1.f / TS)};
             const int s = slot0 + tid;
             if (io.dbg_grad && s < count) { io.dbg_grad[3 * s] = g[0]; io.dbg_grad[3 * s + 1] = g[1]; io.dbg_grad[3 * s + 2] = g[2]; }
             if (io.dbg_sdf && s < count) io.dbg_sdf[s] = sdfv;
@@ -506,17 +553,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
         float o4[4] = {0.f, 0.f, 0.f, 0.f};
         if (io.relight) {
             zero_acc<1>(facc);
-            gemm_wide<16, 1>(facc, wa + mat.m0.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 1>(facc, wa + mat.m0.w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<ACT_SOFTPLUS, false, 1>(facc, ba + mat.m0.bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_SOFTPLUS, false, 1>(facc, ba + mat.m0.bias, sm.xs, wave, lane);
             __syncthreads();
             zero_acc<1>(facc);
-            gemm_wide<16, 1>(facc, wa + mat.m1.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 1>(facc, wa + mat.m1.w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<ACT_SOFTPLUS, false, 1>(facc, ba + mat.m1.bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_SOFTPLUS, false, 1>(facc, ba + mat.m1.bias, sm.xs, wave, lane);
             __syncthreads();
             if (wave == 0) {
-                const f32x16 h = gemm_head<16>(wa + mat.mhead.w, sm.xs, 0, 0, lane);
+                const f32x16 h = gemm_head<E, 16>(wa + mat.mhead.w, sm.xs, 0, 0, lane);
                 if (lane < 32) {
                     const float* b = ba + mat.mhead.bias;
 #pragma unroll
@@ -526,31 +573,31 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
             }
         } else {
             zero_acc<1>(facc);
-            gemm_wide<16, 1>(facc, wa + col.c0a.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 1>(facc, wa + col.c0a.w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (tid < 32) {     // [PE4(bvds) 27 | world normal 3 | pad 2] -> cols 0..31
-                bf16* row = sm.xs + tid * XS;
-                pe_write_col<4>(row, bv, nullptr, 0, 27);
-                pe_write_col<4>(row, bv, nullptr, 1, 27);
-                row[27] = (bf16)nrm[0]; row[28] = (bf16)nrm[1]; row[29] = (bf16)nrm[2];
-                row[30] = (bf16)0.f; row[31] = (bf16)0.f;
+                E* row = sm.xs + tid * XS;
+                pe_write_col<E, 4, false>(row, bv, nullptr, 0, 27);
+                pe_write_col<E, 4, false>(row, bv, nullptr, 1, 27);
+                row[27] = (E)nrm[0]; row[28] = (E)nrm[1]; row[29] = (E)nrm[2];
+                row[30] = (E)0.f; row[31] = (E)0.f;
             }
             __syncthreads();
-            gemm_wide<2, 1>(facc, wa + col.c0b.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 2, 1>(facc, wa + col.c0b.w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<ACT_RELU, false, 1>(facc, ba + col.c0a.bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_RELU, false, 1>(facc, ba + col.c0a.bias, sm.xs, wave, lane);
             __syncthreads();
-            const WideLayer cl[3] = {col.c1, col.c2, col.c3};
 #pragma unroll 1
             for (int l = 0; l < 3; ++l) {
+                const WideLayer cl = l == 0 ? col.c1 : (l == 1 ? col.c2 : col.c3);
                 zero_acc<1>(facc);
-                gemm_wide<16, 1>(facc, wa + cl[l].w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 16, 1>(facc, wa + cl.w, sm.xs, 0, wave, lane);
                 __syncthreads();
-                epilogue_wide<ACT_RELU, false, 1>(facc, l == 2 ? fr.bias_c3 : ba + cl[l].bias, sm.xs, wave, lane);
+                epilogue_wide<E, ACT_RELU, false, 1>(facc, l == 2 ? fr.bias_c3 : ba + cl.bias, sm.xs, wave, lane);
                 __syncthreads();
             }
             if (wave == 0) {
-                const f32x16 h = gemm_head<16>(wa + col.chead.w, sm.xs, 0, 0, lane);
+                const f32x16 h = gemm_head<E, 16>(wa + col.chead.w, sm.xs, 0, 0, lane);
                 if (lane < 32) {
                     const float* b = ba + col.chead.bias;
 #pragma unroll
@@ -567,7 +614,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
                 for (int c = 0; c < 3; ++c) {
                     o[c] = sm.cpts[4 * tid + c];
                     o[3 + c] = sm.pts[4 * tid + c];
-                    o[6 + c] = sm.cpts[4 * tid + c] - sm.pts[4 * tid + c];
+                    o[6 + c] = sm.jac[12 * tid + 9 + c];
                 }
                 if (io.relight) {
                     o[9] = o4[0]; o[10] = o4[1]; o[11] = o4[2]; o[12] = o4[3];
@@ -584,21 +631,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
 
 }  // namespace
 
-void launch_mlp_sdf(const GeoNet& net, const bf16x8* warena, const float* barena, const FrameState& fr, const MlpIO& io,
-                    int max_slots, hipStream_t stream) {
+void launch_mlp_sdf(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr, const MlpIO& io,
+                    int max_slots, bool f16w, hipStream_t stream) {
     if (max_slots <= 0) return;
     const int tiles = (max_slots + TM - 1) / TM;
     const int grid = tiles < 512 ? tiles : 512;     // 2 workgroups per CU x 256 CUs, persistent over tiles
-    if (io.dbg_resd || io.dbg_sdf || io.dbg_feat)
-        hipLaunchKernelGGL(mlp_sdf_kernel<true>, dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
-    else
-        hipLaunchKernelGGL(mlp_sdf_kernel<false>, dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+    const bool dbg = io.dbg_resd || io.dbg_sdf || io.dbg_feat;
+    if (f16w) {
+        if (dbg) hipLaunchKernelGGL((mlp_sdf_kernel<f16, true>), dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+        else hipLaunchKernelGGL((mlp_sdf_kernel<f16, false>), dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+    } else {
+        if (dbg) hipLaunchKernelGGL((mlp_sdf_kernel<bf16, true>), dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+        else hipLaunchKernelGGL((mlp_sdf_kernel<bf16, false>), dim3(grid), dim3(MLP_THREADS), 0, stream, net, warena, barena, fr, io);
+    }
 }
 
-void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const bf16x8* warena, const float* barena,
-                     const FrameState& fr, const FullIO& io, int max_slots, hipStream_t stream) {
+void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const void* warena, const float* barena,
+                     const FrameState& fr, const FullIO& io, int max_slots, bool f16w, hipStream_t stream) {
     if (max_slots <= 0) return;
     const int tiles = (max_slots + 31) / 32;
     const int grid = tiles < 512 ? tiles : 512;
-    hipLaunchKernelGGL(mlp_full_kernel, dim3(grid), dim3(MLP_THREADS), 0, stream, net, mat, col, warena, barena, fr, io);
+    if (f16w) hipLaunchKernelGGL((mlp_full_kernel<f16>), dim3(grid), dim3(MLP_THREADS), 0, stream, net, mat, col, warena, barena, fr, io);
+    else hipLaunchKernelGGL((mlp_full_kernel<bf16>), dim3(grid), dim3(MLP_THREADS), 0, stream, net, mat, col, warena, barena, fr, io);
 }

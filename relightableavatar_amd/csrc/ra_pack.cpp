@@ -1,4 +1,4 @@
-// Host-side weight packer: reference state_dict (fp32) -> bf16 MFMA fragment order.
+// Host-side weight packer: reference state_dict (fp32) -> f16/bf16 MFMA fragment order.
 //   weight_norm fold  W = g * v / |v|_row          lib/utils/net_utils.py:1326-1327, base_network.py:145-149
 //   SDF skip          cat([x, inputs]) / sqrt(2)   lib/utils/net_utils.py:1345-1346 (folded into lin4)
 //   resd skip         cat([x, input])              lib/utils/net_utils.py:1266-1267 (x first)
@@ -28,13 +28,22 @@ struct Mat {
     float at(int r, int c) const { return v[(size_t)r * cols + c]; }
 };
 
+uint16_t f2h(float f) {    // IEEE half, round to nearest even (clang's _Float16 conversion)
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
 struct Packer {
-    std::vector<uint16_t> w;    // bf16 arena (multiple of 8 elements)
+    std::vector<uint16_t> w;    // 16-bit element arena (multiple of 8 elements)
     std::vector<float> b;       // bias arena
+    bool half = false;          // f16 (true) or bf16 (false)
 
     // M: [rows<=256 or <=32][K], K multiple of 16 after padding
-    WideLayer add(const Mat& M, const std::vector<float>& bias, int n_rows_pad) {
-        const int K = (M.cols + 15) / 16 * 16;
+    WideLayer add(const Mat& M, const std::vector<float>& bias, int n_rows_pad, int k_min = 0) {
+        int K = (M.cols + 15) / 16 * 16;
+        if (K < k_min) K = k_min;
         const int KS = K / 16, NB = n_rows_pad / 32;
         WideLayer L;
         L.w = (uint32_t)(w.size() / 8);
@@ -49,7 +58,7 @@ struct Packer {
                         const int row = nb * 32 + (lane & 31), col = ks * 16 + (lane >> 5) * 8 + e;
                         float val = 0.f;
                         if (row < M.rows && col < M.cols) val = M.at(row, col);
-                        o[(((size_t)nb * KS + ks) * 64 + lane) * 8 + e] = f2bf(val);
+                        o[(((size_t)nb * KS + ks) * 64 + lane) * 8 + e] = half ? f2h(val) : f2bf(val);
                     }
         for (int r = 0; r < n_rows_pad; ++r) b.push_back(r < (int)bias.size() ? bias[r] : 0.f);
         while (b.size() % 4) b.push_back(0.f);
@@ -112,6 +121,7 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
     const int xyz_dim = 3 + 6 * c.xyz_res, sdf_dim = 3 + 6 * c.sdf_res, view_dim = 3 + 6 * c.view_res;
     if (c.xyz_res != 10 || c.sdf_res != 8 || c.view_res != 4) { err = "kernels are specialised for xyz_res=10, sdf_res=8, view_res=4 (configs/base.yaml:47-49)"; return 1; }
     Packer P;
+    P.half = c.mlp_f16 != 0;
     HostNets& H = ctx->host;
     // ---- residual deformation
     const std::string rp = "residual_deformation_network.mlp.linears.";
@@ -147,6 +157,22 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         std::vector<float> b;
         if (!get_wn(sd, sp + std::to_string(l), O, I, W, b, err)) return 1;
         if (l == 4) for (auto& x : W.v) x *= (float)(1.0 / std::sqrt(2.0));
+        // first-layer style inputs are [x 3 | PE8 48 | lo(x) 3 | lo(freq-0 sin,cos) 6 | pad]: duplicate the weights
+        auto with_lo = [&](const Mat& Wp) {
+            Mat o(Wp.rows, sdf_dim + 9);
+            for (int r = 0; r < Wp.rows; ++r) {
+                for (int k = 0; k < sdf_dim; ++k) o.at(r, k) = Wp.at(r, k);
+                for (int k = 0; k < 9; ++k) o.at(r, sdf_dim + k) = Wp.at(r, k);
+            }
+            return o;
+        };
+        if (l == 0) {
+            H.geo.s[0] = P.add(with_lo(W), b, 256);
+        } else if (l == 4) {
+            const int nx = 256 - sdf_dim;   // 205
+            H.geo.s[4] = P.add(slice_cols(W, 0, nx), b, 256, 256);         // K zero-padded to 256 (cols 205..255 of the tile hold junk)
+            H.geo.s4b = P.add(with_lo(slice_cols(W, nx, 256)), std::vector<float>(), 256);
+        } else
         if (l == 8) {
             H.geo.shead = P.add(slice_rows(W, 0, 1), std::vector<float>(b.begin(), b.begin() + 1), 32);
             H.geo.sfeat = P.add(slice_rows(W, 1, 257), std::vector<float>(b.begin() + 1, b.end()), 256);

@@ -21,7 +21,7 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
 
 
 class Engine:
-    def __init__(self, cfg, device=None):
+    def __init__(self, cfg, device=None, relight=False):
         if not torch.cuda.is_available():
             raise _lib.RaError('relightableavatar_amd needs a HIP device (MI355X); there is no CPU fallback for the render path')
         self.lib = _lib.lib()
@@ -29,13 +29,15 @@ class Engine:
         self.cfg = cfg
         self.ctx = C.c_void_p()
         check(self.lib.ra_ctx_create(C.byref(self.ctx), self.device.index or 0), 'ra_ctx_create')
-        self.relight = bool(cfg.relighting) or 'relight' in cfg.network_module
+        self.relight = bool(relight)      # RelightableAvatar heads (17-ch raw) vs AniSDF colour net (16-ch raw)
         c = ra_config(xyz_res=cfg.xyz_res, sdf_res=cfg.sdf_res, view_res=cfg.view_res, n_bones=cfg.n_bones, relight=int(self.relight),
                       resd_limit=cfg.resd_limit, blend_radius=cfg.blend_radius, albedo_slope=cfg.albedo_slope,
                       albedo_bias=cfg.albedo_bias, roughness_slope=cfg.roughness_slope, roughness_bias=cfg.roughness_bias,
                       fresnel_f0=cfg.fresnel_f0, shading_albedo=cfg.shading_albedo, albedo_multiplier=cfg.albedo_multiplier,
                       lambert_only=int(cfg.lambert_only), glossy_only=int(cfg.glossy_only),
-                      tonemapping=int(cfg.tonemapping_rendering), bg_brightness=cfg.bg_brightness)
+                      tonemapping=int(cfg.tonemapping_rendering), bg_brightness=cfg.bg_brightness,
+                      mlp_f16=int(cfg.mlp_dtype == 'f16'))
+        assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None
         self._keep = []

@@ -116,7 +116,7 @@ class Network(nn.Module):
             dev = next(self.parameters()).device
             if dev.type != 'cuda':
                 raise RuntimeError('relightableavatar_amd.Network must live on the GPU (call .cuda()); the render path has no CPU fallback')
-            self._engine = Engine(self.cfg, dev)
+            self._engine = Engine(self.cfg, dev, relight=hasattr(self, 'albedo_network'))
         if self._dirty:
             self._engine.load_state_dict(self.state_dict())
             self._dirty = False

@@ -25,8 +25,12 @@ def psnr(a, b):
     return float(-10 * torch.log10(torch.mean((a - b) ** 2)))
 
 
+DT = os.environ.get('RA_DTYPE', 'f16')
+print('mlp dtype', DT)
+
+
 def build(mode, **kw):
-    cfg = make_cfg(mode, **kw)
+    cfg = make_cfg(mode, mlp_dtype=DT, **kw)
     relight = mode in ('relight', 'novel_light')
     net = make_network(cfg)
     net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
