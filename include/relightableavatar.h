@@ -185,6 +185,9 @@ int ra_reset_counters(ra_ctx* ctx, void* stream);
  * events on `stream`; n_launches receives the launch count.  Synchronises. */
 int ra_get_mlp_time(ra_ctx* ctx, float* ms, int* n_launches, void* stream);
 int ra_enable_timing(ra_ctx* ctx, int on);
+/* 1 (default): exact 3-NN through the per-frame vertex BVH; 0: brute force over all vertices (validation path).
+ * Takes effect at the next ra_set_frame. Both return identical neighbours. */
+int ra_set_knn_mode(ra_ctx* ctx, int use_bvh);
 
 /* ---- test hooks: stage outputs for the parity tests (tests/test_gpu_*.py); not used by renderers ---- */
 /* resd + sdf MLPs on given big-pose points: resd n x 3, sdf n, feat n x 256 (any may be NULL) */

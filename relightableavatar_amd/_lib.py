@@ -75,6 +75,7 @@ SYMBOLS = {
     'ra_reset_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ra_get_mlp_time': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
     'ra_enable_timing': (C.c_int, [C.c_void_p, C.c_int]),
+    'ra_set_knn_mode': (C.c_int, [C.c_void_p, C.c_int]),
     'ra_debug_mlp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_full': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_hdq': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 7 + [C.POINTER(C.c_int), C.c_void_p]),

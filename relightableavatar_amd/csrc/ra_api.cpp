@@ -56,7 +56,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->warena, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
-                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters};
+                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs};
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : c->scratch) kv.second.release();
     for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -133,6 +133,12 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     RA_HIP(hipMemcpyAsync(c->ftverts.p, f->tverts, (size_t)nv * 12, hipMemcpyDeviceToDevice, s));
     launch_pack_verts(f->pverts, nv, c->fpverts4.as<float4>(), s);
     launch_vert_blend(f->weights, f->A, f->big_A, nv, nb, c->fvertA.as<float>(), s);
+    const int nleaf = c->use_bvh ? bvh_leaf_count(nv) : 0;
+    if (nleaf > 0) {
+        if (c->fbvh_pts.ensure((size_t)nv * 16) || c->fbvh_pairs.ensure((size_t)nleaf * (3 * 16 + 2 * 24))) return 1;
+        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float4>(), c->fbvh_pairs.as<float4>(), nleaf, s);
+        RA_HIP(hipGetLastError());
+    }
     launch_fold_bias(c->cond_r0.as<float>(), cond, 0, cond, f->poses, c->b_r0.as<float>(), c->fbias_r0.as<float>(), s);
     launch_fold_bias(c->cond_r4.as<float>(), cond, 0, cond, f->poses, c->b_r4.as<float>(), c->fbias_r4.as<float>(), s);
     if (c->host.has_color && f->cond_fix)
@@ -141,6 +147,8 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     fr.R = c->fR.as<float>(); fr.Th = c->fTh.as<float>(); fr.vertA = c->fvertA.as<float>(); fr.pverts4 = c->fpverts4.as<float4>();
     fr.pnorm = c->fpnorm.as<float>(); fr.tverts = c->ftverts.as<float>(); fr.bias_r0 = c->fbias_r0.as<float>();
     fr.bias_r4 = c->fbias_r4.as<float>(); fr.bias_c3 = c->fbias_c3.as<float>(); fr.n_verts = nv;
+    fr.bvh_pts = c->fbvh_pts.as<float4>(); fr.bvh_pairs = c->fbvh_pairs.as<float4>(); fr.bvh_leaves = nleaf;
+    fr.bvh_boxes = reinterpret_cast<const float*>(c->fbvh_pairs.as<float4>() + (size_t)3 * nleaf);
     c->have_frame = true;
     RA_HIP(hipGetLastError());
     return 0;
@@ -513,6 +521,13 @@ int ra_reset_counters(ra_ctx* c, void* stream) {
     c->n_coarse = 0;
     c->n_shaded = 0;
     c->ev_used = 0;
+    return 0;
+}
+
+int ra_set_knn_mode(ra_ctx* c, int use_bvh) {
+    RA_CHECK(c, "ra_set_knn_mode: null ctx");
+    c->use_bvh = use_bvh != 0;
+    c->have_frame = false;      // takes effect at the next ra_set_frame
     return 0;
 }
 

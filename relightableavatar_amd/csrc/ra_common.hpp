@@ -68,6 +68,11 @@ struct FrameState {         // device pointers owned by the ctx
     float* bias_r4;  // 256
     float* bias_c3;  // 256 (colour net, cond_fix)
     int n_verts;
+    // exact 3-NN acceleration: implicit complete binary tree over Morton-sorted vertices, 8 per leaf
+    const float4* bvh_pts;    // n_verts sorted points, w = original vertex index (int bits)
+    const float4* bvh_pairs;  // per internal node: 3 float4 = boxes of its two children
+    const float* bvh_boxes;   // per node (heap order): own box, 6 floats
+    int bvh_leaves;           // number of leaves (power of two); 0 -> brute force
 };
 
 struct DevCounters {       // device-side work counters (ra_get_counters)

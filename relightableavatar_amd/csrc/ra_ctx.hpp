@@ -33,7 +33,8 @@ struct ra_ctx {
     int n_lights = 0;
     // frame
     FrameState fr{};
-    DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond;
+    DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond, fbvh_pts, fbvh_pairs;
+    bool use_bvh = true;
     // scratch (grow-only)
     std::map<std::string, DevBuf> scratch;
     DevBuf dcounters;       // DevCounters + small int counters

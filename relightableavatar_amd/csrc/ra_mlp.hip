@@ -52,44 +52,82 @@ template <> struct Tr<f16> {
 };
 
 // y = act(z), dy = act'(z)
-template <int ACT>
+template <int ACT, bool NEED_DY>
 __device__ __forceinline__ float act_fn(float z, float& dy) {
     if (ACT == ACT_RELU) {
-        dy = z > 0.f ? 1.f : 0.f;
+        if (NEED_DY) dy = z > 0.f ? 1.f : 0.f;
         return fmaxf(z, 0.f);
-    } else if (ACT == ACT_SOFTPLUS) {       // nn.Softplus(beta=100, threshold=20)
-        const float u = 100.f * z;
-        if (u > 20.f) { dy = 1.f; return z; }
-        const float e = __expf(u);
-        dy = e / (1.f + e);
-        return 0.01f * __logf(1.f + e);
+    } else if (ACT == ACT_SOFTPLUS) {
+        // nn.Softplus(beta=100): log(1+exp(100 z))/100 = max(z,0) + ln2/100 * log2(1 + exp2(-|100 z log2e|)),
+        // overflow-free, two native base-2 transcendentals; torch's threshold=20 branch returns z where the
+        // correction term is < 2.1e-11, i.e. identical in fp32.
+        const float t = z * 144.26950408889634f;                  // 100 * log2(e)
+        const float e = __builtin_amdgcn_exp2f(-fabsf(t));
+        if (NEED_DY) dy = (t >= 0.f ? 1.f : e) / (1.f + e);       // sigmoid(100 z)
+        return fmaf(__builtin_amdgcn_logf(1.f + e), 0.0069314718055994531f, fmaxf(z, 0.f));
     } else {
-        dy = 1.f;
+        if (NEED_DY) dy = 1.f;
         return z;
     }
 }
 
+// A fragments (weights) of the first two k-steps of a wide layer, fetched ahead of time: issued
+// before the previous layer's epilogue so their L2 latency hides behind the VALU work.
+template <typename E> struct APre { typename Tr<E>::x8 a[2][2]; };
+
+template <typename E, int KS>
+__device__ __forceinline__ APre<E> gemm_prefetch(const typename Tr<E>::x8* __restrict__ wl, int wave, int lane) {
+    APre<E> p;
+    const typename Tr<E>::x8* a0p = wl + (size_t)((2 * wave + 0) * KS) * 64 + lane;
+    const typename Tr<E>::x8* a1p = wl + (size_t)((2 * wave + 1) * KS) * 64 + lane;
+    p.a[0][0] = a0p[0];
+    p.a[0][1] = a1p[0];
+    p.a[1][0] = a0p[KS > 1 ? 64 : 0];
+    p.a[1][1] = a1p[KS > 1 ? 64 : 0];
+    return p;
+}
+
 // acc[nt][mt] += W[64*wave + 32*nt .. +32, kcols] . X[32*mt .. +32, kcol0 .. kcol0 + 16*KS]^T
-template <typename E, int KS, int MT>
-__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[2][MT], const typename Tr<E>::x8* __restrict__ wl, const E* xs,
-                                          int kcol0, int wave, int lane) {
+// Software pipelined: the weight fragments of k-step ks+2 are requested (global -> VGPR, L2
+// resident, one coalesced 1 KiB load each) while k-step ks is multiplied, so two k-steps of loads
+// are always in flight (counted vmcnt, never a drain inside the loop).
+template <typename E, int MT>
+__device__ __forceinline__ void kstep(f32x16 (&acc)[2][MT], typename Tr<E>::x8 a0, typename Tr<E>::x8 a1, const E* bp) {
     typedef typename Tr<E>::x8 x8;
+    x8 b[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const x8*>(bp + mt * 32 * XS);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[0][mt] = Tr<E>::mfma(a0, b[mt], acc[0][mt]);
+        acc[1][mt] = Tr<E>::mfma(a1, b[mt], acc[1][mt]);
+    }
+}
+
+template <typename E, int KS, int MT>
+__device__ __forceinline__ void gemm_wide(f32x16 (&acc)[2][MT], const APre<E>& pre, const typename Tr<E>::x8* __restrict__ wl,
+                                          const E* xs, int kcol0, int wave, int lane) {
+    typedef typename Tr<E>::x8 x8;
+    static_assert(KS % 2 == 0, "k-steps are processed in pairs");
     const x8* a0p = wl + (size_t)((2 * wave + 0) * KS) * 64 + lane;
     const x8* a1p = wl + (size_t)((2 * wave + 1) * KS) * 64 + lane;
     const E* bp = xs + (lane & 31) * XS + kcol0 + (lane >> 5) * 8;
-#pragma unroll 2
-    for (int ks = 0; ks < KS; ++ks) {
-        const x8 a0 = a0p[ks * 64];
-        const x8 a1 = a1p[ks * 64];
-        x8 b[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const x8*>(bp + mt * 32 * XS + ks * 16);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[0][mt] = Tr<E>::mfma(a0, b[mt], acc[0][mt]);
-            acc[1][mt] = Tr<E>::mfma(a1, b[mt], acc[1][mt]);
-        }
+    x8 c0 = pre.a[0][0], c1 = pre.a[0][1], n0 = pre.a[1][0], n1 = pre.a[1][1];
+    // rolled loop, two k-steps per trip: the four fragment loads issued at the top of a trip are
+    // consumed in the NEXT trip, i.e. they stay in flight across 16 MFMAs (+ the co-resident wave's)
+#pragma unroll 1
+    for (int ks = 0; ks < KS - 2; ks += 2) {
+        const x8 f0 = a0p[(ks + 2) * 64];
+        const x8 f1 = a1p[(ks + 2) * 64];
+        const x8 g0 = a0p[(ks + 3) * 64];
+        const x8 g1 = a1p[(ks + 3) * 64];
+        __builtin_amdgcn_sched_barrier(0);      // keep the four loads at the top of the trip
+        kstep<E, MT>(acc, c0, c1, bp + ks * 16);
+        kstep<E, MT>(acc, n0, n1, bp + (ks + 1) * 16);
+        c0 = f0; c1 = f1; n0 = g0; n1 = g1;
     }
+    kstep<E, MT>(acc, c0, c1, bp + (KS - 2) * 16);
+    kstep<E, MT>(acc, n0, n1, bp + (KS - 1) * 16);
 }
 
 template <int MT>
@@ -109,22 +147,35 @@ __device__ __forceinline__ void store4(E* dst, float a, float b, float c, float 
     *reinterpret_cast<typename Tr<E>::x4*>(dst) = v;
 }
 
-// write act(acc + bias) as bf16 into xs[:, 0..255]; GRAD: column group 0 is the primal,
-// groups 1..3 hold tangents and get act'(z_primal) * t (no bias).
+// accumulators start at the bias of their row (primal columns) / at zero (tangent columns)
+template <int MT, bool GRAD>
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[2][MT], const float* __restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 64 * wave + 32 * nt + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][mt][4 * q + j] = (GRAD && mt > 0) ? 0.f : bv[j];
+        }
+}
+
+// write act(acc) as E into xs[:, 0..255] (the bias is already inside acc); GRAD: column group 0 is
+// the primal, groups 1..3 hold tangents and get act'(z_primal) * t.
 template <typename E, int ACT, bool GRAD, int MT>
-__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], const float* __restrict__ bias, E* xs,
-                                              int wave, int lane) {
+__device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], E* xs, int wave, int lane) {
     const int mrow = lane & 31;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n0 = 64 * wave + 32 * nt + 8 * q + 4 * (lane >> 5);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
             float y[4], dy[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = act_fn<ACT>(acc[nt][0][4 * q + j] + bv[j], dy[j]);
-            store4(xs + mrow * XS + n0, y[0], y[1], y[2], y[3]);
+            for (int j = 0; j < 4; ++j) y[j] = act_fn<ACT, GRAD>(acc[nt][0][4 * q + j], dy[j]);
+            store4<E>(xs + mrow * XS + n0, y[0], y[1], y[2], y[3]);
 #pragma unroll
             for (int mt = 1; mt < MT; ++mt) {
                 float o[4];
@@ -134,10 +185,10 @@ __device__ __forceinline__ void epilogue_wide(const f32x16 (&acc)[2][MT], const 
                         o[j] = acc[nt][mt][4 * q + j] * dy[j];
                     } else {
                         float d_;
-                        o[j] = act_fn<ACT>(acc[nt][mt][4 * q + j] + bv[j], d_);
+                        o[j] = act_fn<ACT, false>(acc[nt][mt][4 * q + j], d_);
                     }
                 }
-                store4(xs + (mt * 32 + mrow) * XS + n0, o[0], o[1], o[2], o[3]);
+                store4<E>(xs + (mt * 32 + mrow) * XS + n0, o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -235,8 +286,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, con
     if (blockIdx.x == 0 && tid == 0 && io.counters) atomicAdd(&io.counters->n_fine_sdf, (unsigned long long)count);
     f32x16 acc[2][4];
 
+    const x8* __restrict__ wa_base = wa;
     for (int tile = blockIdx.x; tile * TM < count; tile += gridDim.x) {
         const int slot0 = tile * TM;
+        // launder the weight base once per tile: the fragment loads are invariant across tiles and
+        // LICM would otherwise hoist (and spill) them out of the persistent loop
+        unsigned wz = 0;
+        asm volatile("" : "+s"(wz));          // opaque zero: keeps the global address space of the pointer
+        const x8* wa = wa_base + wz;
         // ---- load points
         if (tid < TM) {
             const int s = slot0 + tid;
@@ -247,27 +304,31 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, con
         __syncthreads();
         const int pm = tid >> 1, ph = tid & 1;
         // ---- residual deformation net
+        APre<E> pre = gemm_prefetch<E, 4>(wa + net.r[0].w, wave, lane);
         { const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
           pe_write_col<E, 10, false>(sm.xs + pm * XS, x, nullptr, ph, 64); }
         __syncthreads();
-        zero_acc<4>(acc);
-        gemm_wide<E, 4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
+        init_acc<4, false>(acc, fr.bias_r0, wave, lane);
+        gemm_wide<E, 4, 4>(acc, pre, wa + net.r[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<E, ACT_RELU, false, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
+        pre = gemm_prefetch<E, 16>(wa + net.r[1].w, wave, lane);
+        epilogue_wide<E, ACT_RELU, false, 4>(acc, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
-            zero_acc<4>(acc);
-            gemm_wide<E, 16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
+            init_acc<4, false>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, wave, lane);
+            gemm_wide<E, 16, 4>(acc, pre, wa + net.r[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (l == 4) {   // skip: cat([x, input]) — re-encode the input into cols 0..63 and accumulate
+                pre = gemm_prefetch<E, 4>(wa + net.r4b.w, wave, lane);
                 const float* p = sm.pts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
                 pe_write_col<E, 10, false>(sm.xs + pm * XS, x, nullptr, ph, 64);
                 __syncthreads();
-                gemm_wide<E, 4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 4, 4>(acc, pre, wa + net.r4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
-            epilogue_wide<E, ACT_RELU, false, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
+            if (l < 7) pre = gemm_prefetch<E, 16>(wa + net.r[l + 1].w, wave, lane);
+            epilogue_wide<E, ACT_RELU, false, 4>(acc, sm.xs, wave, lane);
             __syncthreads();
         }
         {   // head: resd = tanh(z) * resd_limit; cpts = bpts + resd
@@ -285,32 +346,36 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void mlp_sdf_kernel(GeoNet net, con
         }
         __syncthreads();
         // ---- signed distance net
+        pre = gemm_prefetch<E, 4>(wa + net.s[0].w, wave, lane);
         { const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
           pe_write_col<E, 8, true>(sm.xs + pm * XS, x, nullptr, ph, 64); }
         __syncthreads();
-        zero_acc<4>(acc);
-        gemm_wide<E, 4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
+        init_acc<4, false>(acc, ba + net.s[0].bias, wave, lane);
+        gemm_wide<E, 4, 4>(acc, pre, wa + net.s[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<E, ACT_SOFTPLUS, false, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
+        pre = gemm_prefetch<E, 16>(wa + net.s[1].w, wave, lane);
+        epilogue_wide<E, ACT_SOFTPLUS, false, 4>(acc, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
-            zero_acc<4>(acc);
-            gemm_wide<E, 16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
+            init_acc<4, false>(acc, ba + net.s[l].bias, wave, lane);
+            gemm_wide<E, 16, 4>(acc, pre, wa + net.s[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (l == 4) {   // skip: cat([x(205), input(51)]) / sqrt(2): the input part is a second K=64 pass
+                pre = gemm_prefetch<E, 4>(wa + net.s4b.w, wave, lane);
                 const float* p = sm.cpts + 4 * pm; const float x[3] = {p[0], p[1], p[2]};
                 pe_write_col<E, 8, true>(sm.xs + pm * XS, x, nullptr, ph, 64);
                 __syncthreads();
-                gemm_wide<E, 4, 4>(acc, wa + net.s4b.w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 4, 4>(acc, pre, wa + net.s4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
-            epilogue_wide<E, ACT_SOFTPLUS, false, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
+            if (l < 7) pre = gemm_prefetch<E, 16>(wa + net.s[l + 1].w, wave, lane);
+            epilogue_wide<E, ACT_SOFTPLUS, false, 4>(acc, sm.xs, wave, lane);
             __syncthreads();
         }
         if (DEBUG && io.dbg_feat) {     // feature rows of lin8 (test hook; the product path uses the full kernel)
             zero_acc<4>(acc);
-            gemm_wide<E, 16, 4>(acc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 16, 4>(acc, gemm_prefetch<E, 16>(wa + net.sfeat.w, wave, lane), wa + net.sfeat.w, sm.xs, 0, wave, lane);
             const float* b = ba + net.sfeat.bias;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -395,8 +460,12 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
     // PE mapping: point pm, column group pg (0 primal, 1..3 tangents), frequency half ph
     const int pm = tid & 31, pg = (tid >> 5) & 3, ph = tid >> 7;
 
+    const x8* __restrict__ wa_base = wa;
     for (int tile = blockIdx.x; tile * 32 < count; tile += gridDim.x) {
         const int slot0 = tile * 32;
+        unsigned wz = 0;
+        asm volatile("" : "+s"(wz));          // opaque zero: keeps the global address space of the pointer
+        const x8* wa = wa_base + wz;
         if (tid < 32) {
             const int s = slot0 + tid;
             float x = 0.f, y = 0.f, z = 0.f;
@@ -420,23 +489,23 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
         // ---- residual deformation net with tangents
         write_pe10();
         __syncthreads();
-        zero_acc<4>(acc);
-        gemm_wide<E, 4, 4>(acc, wa + net.r[0].w, sm.xs, 0, wave, lane);
+        init_acc<4, true>(acc, fr.bias_r0, wave, lane);
+        gemm_wide<E, 4, 4>(acc, gemm_prefetch<E, 4>(wa + net.r[0].w, wave, lane), wa + net.r[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<E, ACT_RELU, true, 4>(acc, fr.bias_r0, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_RELU, true, 4>(acc, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
-            zero_acc<4>(acc);
-            gemm_wide<E, 16, 4>(acc, wa + net.r[l].w, sm.xs, 0, wave, lane);
+            init_acc<4, true>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, wave, lane);
+            gemm_wide<E, 16, 4>(acc, gemm_prefetch<E, 16>(wa + net.r[l].w, wave, lane), wa + net.r[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (l == 4) {
                 write_pe10();
                 __syncthreads();
-                gemm_wide<E, 4, 4>(acc, wa + net.r4b.w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 4, 4>(acc, gemm_prefetch<E, 4>(wa + net.r4b.w, wave, lane), wa + net.r4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
-            epilogue_wide<E, ACT_RELU, true, 4>(acc, l == 4 ? fr.bias_r4 : ba + net.r[l].bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_RELU, true, 4>(acc, sm.xs, wave, lane);
             __syncthreads();
         }
         {   // head: wave g holds z (g = 0) or TS * dz/db_{g-1}
@@ -464,23 +533,23 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
         // ---- signed distance net with tangents
         write_pe8();
         __syncthreads();
-        zero_acc<4>(acc);
-        gemm_wide<E, 4, 4>(acc, wa + net.s[0].w, sm.xs, 0, wave, lane);
+        init_acc<4, true>(acc, ba + net.s[0].bias, wave, lane);
+        gemm_wide<E, 4, 4>(acc, gemm_prefetch<E, 4>(wa + net.s[0].w, wave, lane), wa + net.s[0].w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<E, ACT_SOFTPLUS, true, 4>(acc, ba + net.s[0].bias, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_SOFTPLUS, true, 4>(acc, sm.xs, wave, lane);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 8; ++l) {
-            zero_acc<4>(acc);
-            gemm_wide<E, 16, 4>(acc, wa + net.s[l].w, sm.xs, 0, wave, lane);
+            init_acc<4, true>(acc, ba + net.s[l].bias, wave, lane);
+            gemm_wide<E, 16, 4>(acc, gemm_prefetch<E, 16>(wa + net.s[l].w, wave, lane), wa + net.s[l].w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (l == 4) {
                 write_pe8();
                 __syncthreads();
-                gemm_wide<E, 4, 4>(acc, wa + net.s4b.w, sm.xs, 0, wave, lane);
+                gemm_wide<E, 4, 4>(acc, gemm_prefetch<E, 4>(wa + net.s4b.w, wave, lane), wa + net.s4b.w, sm.xs, 0, wave, lane);
                 __syncthreads();
             }
-            epilogue_wide<E, ACT_SOFTPLUS, true, 4>(acc, ba + net.s[l].bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_SOFTPLUS, true, 4>(acc, sm.xs, wave, lane);
             __syncthreads();
         }
         {   // sdf head on all four column groups: value and the three (scaled) partials
@@ -489,10 +558,10 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
         }
         // features (primal columns only) -> xs rows 0..31 as the next net's input
         f32x16 facc[2][1];
-        zero_acc<1>(facc);
-        gemm_wide<E, 16, 1>(facc, wa + net.sfeat.w, sm.xs, 0, wave, lane);
+        init_acc<1, false>(facc, ba + net.sfeat.bias, wave, lane);
+        gemm_wide<E, 16, 1>(facc, gemm_prefetch<E, 16>(wa + net.sfeat.w, wave, lane), wa + net.sfeat.w, sm.xs, 0, wave, lane);
         __syncthreads();
-        epilogue_wide<E, ACT_NONE, false, 1>(facc, ba + net.sfeat.bias, sm.xs, wave, lane);
+        epilogue_wide<E, ACT_NONE, false, 1>(facc, sm.xs, wave, lane);
         if (io.dbg_feat) {
             const float* b = ba + net.sfeat.bias;
 #pragma unroll
@@ -501,7 +570,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
                 for (int r = 0; r < 16; ++r) {
                     const int n = 64 * wave + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int s = slot0 + (lane & 31);
-                    if (s < count) io.dbg_feat[(size_t)s * 256 + n] = facc[nt][0][r] + b[n];
+                    if (s < count) io.dbg_feat[(size_t)s * 256 + n] = facc[nt][0][r];   // bias already inside facc
                 }
         }
         __syncthreads();
@@ -552,15 +621,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
         // ---- heads on the 32 primal columns
         float o4[4] = {0.f, 0.f, 0.f, 0.f};
         if (io.relight) {
-            zero_acc<1>(facc);
-            gemm_wide<E, 16, 1>(facc, wa + mat.m0.w, sm.xs, 0, wave, lane);
+            init_acc<1, false>(facc, ba + mat.m0.bias, wave, lane);
+            gemm_wide<E, 16, 1>(facc, gemm_prefetch<E, 16>(wa + mat.m0.w, wave, lane), wa + mat.m0.w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<E, ACT_SOFTPLUS, false, 1>(facc, ba + mat.m0.bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_SOFTPLUS, false, 1>(facc, sm.xs, wave, lane);
             __syncthreads();
-            zero_acc<1>(facc);
-            gemm_wide<E, 16, 1>(facc, wa + mat.m1.w, sm.xs, 0, wave, lane);
+            init_acc<1, false>(facc, ba + mat.m1.bias, wave, lane);
+            gemm_wide<E, 16, 1>(facc, gemm_prefetch<E, 16>(wa + mat.m1.w, wave, lane), wa + mat.m1.w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<E, ACT_SOFTPLUS, false, 1>(facc, ba + mat.m1.bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_SOFTPLUS, false, 1>(facc, sm.xs, wave, lane);
             __syncthreads();
             if (wave == 0) {
                 const f32x16 h = gemm_head<E, 16>(wa + mat.mhead.w, sm.xs, 0, 0, lane);
@@ -572,8 +641,8 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
                 }
             }
         } else {
-            zero_acc<1>(facc);
-            gemm_wide<E, 16, 1>(facc, wa + col.c0a.w, sm.xs, 0, wave, lane);
+            init_acc<1, false>(facc, ba + col.c0a.bias, wave, lane);
+            gemm_wide<E, 16, 1>(facc, gemm_prefetch<E, 16>(wa + col.c0a.w, wave, lane), wa + col.c0a.w, sm.xs, 0, wave, lane);
             __syncthreads();
             if (tid < 32) {     // [PE4(bvds) 27 | world normal 3 | pad 2] -> cols 0..31
                 E* row = sm.xs + tid * XS;
@@ -583,17 +652,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, Ma
                 row[30] = (E)0.f; row[31] = (E)0.f;
             }
             __syncthreads();
-            gemm_wide<E, 2, 1>(facc, wa + col.c0b.w, sm.xs, 0, wave, lane);
+            gemm_wide<E, 2, 1>(facc, gemm_prefetch<E, 2>(wa + col.c0b.w, wave, lane), wa + col.c0b.w, sm.xs, 0, wave, lane);
             __syncthreads();
-            epilogue_wide<E, ACT_RELU, false, 1>(facc, ba + col.c0a.bias, sm.xs, wave, lane);
+            epilogue_wide<E, ACT_RELU, false, 1>(facc, sm.xs, wave, lane);
             __syncthreads();
 #pragma unroll 1
             for (int l = 0; l < 3; ++l) {
                 const WideLayer cl = l == 0 ? col.c1 : (l == 1 ? col.c2 : col.c3);
-                zero_acc<1>(facc);
-                gemm_wide<E, 16, 1>(facc, wa + cl.w, sm.xs, 0, wave, lane);
+                init_acc<1, false>(facc, l == 2 ? fr.bias_c3 : ba + cl.bias, wave, lane);
+                gemm_wide<E, 16, 1>(facc, gemm_prefetch<E, 16>(wa + cl.w, wave, lane), wa + cl.w, sm.xs, 0, wave, lane);
                 __syncthreads();
-                epilogue_wide<E, ACT_RELU, false, 1>(facc, l == 2 ? fr.bias_c3 : ba + cl.bias, sm.xs, wave, lane);
+                epilogue_wide<E, ACT_RELU, false, 1>(facc, sm.xs, wave, lane);
                 __syncthreads();
             }
             if (wave == 0) {

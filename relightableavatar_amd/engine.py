@@ -164,6 +164,10 @@ class Engine:
     def reset_counters(self):
         check(self.lib.ra_reset_counters(self.ctx, self.stream), 'ra_reset_counters')
 
+    def set_knn_mode(self, use_bvh=True):
+        check(self.lib.ra_set_knn_mode(self.ctx, int(use_bvh)), 'ra_set_knn_mode')
+        self._frame_key = None
+
     def enable_timing(self, on=True):
         check(self.lib.ra_enable_timing(self.ctx, int(on)), 'ra_enable_timing')
 

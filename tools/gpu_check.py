@@ -60,6 +60,16 @@ stat('bpts', o.bpts.cpu()[m], T('warp_bpts')[m])
 stat('tpts', o.tpts.cpu()[m], T('warp_tpts')[m])
 stat('A_bw', o.mats.cpu()[m][:, :12], T('warp_A_bw')[m][:, :3, :].reshape(-1, 12))
 stat('big_A_bw', o.mats.cpu()[m][:, 12:], T('warp_big_A_bw')[m][:, :3, :].reshape(-1, 12))
+eng.set_knn_mode(False); eng.set_frame(body, force=True)
+ob = eng.debug_hdq(x, 0.125)
+eng.set_knn_mode(True); eng.set_frame(body, force=True)
+print('bvh vs brute: nn mismatch', int((ob.nn_batch != o.nn_batch).sum()), 'd2 maxdiff', float((ob.d2 - o.d2).abs().max()), 'bpts maxdiff', float((ob.bpts - o.bpts).abs().max()))
+xr = (torch.rand(200000, 3, device=dev) - 0.5) * 3.0
+o1 = eng.debug_hdq(xr, 0.125)
+eng.set_knn_mode(False); eng.set_frame(body, force=True)
+o2 = eng.debug_hdq(xr, 0.125)
+eng.set_knn_mode(True); eng.set_frame(body, force=True)
+print('bvh vs brute (200k pts in a 3 m cube): nn mismatch', int((o1.nn_batch != o2.nn_batch).sum()), 'sdf maxdiff', float((o1.sdf_coarse - o2.sdf_coarse).abs().max()), 'fine', o1.fine_count, o2.fine_count)
 print('== hdq')
 s = net.inference_world_distance_field(x[None], body, smooth_transition=True, dist_th=0.125)
 stat('hdq_sdf', s[0], T('hdq_sdf'))
