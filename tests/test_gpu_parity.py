@@ -1,0 +1,313 @@
+"""GPU parity: the HIP path (through the C ABI) vs the golden fixtures generated from the reference
+(tests/golden/*.npz) and vs the oracle on the same seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is fp32):
+  coarse level / LBS warp ............ 1e-6 absolute (fp32, different summation order only), exact 3-NN indices
+  resd, sdf, feat (MLP outputs) ...... 3e-4 abs (sdf), 2e-4 (feat); measured mean 4.5e-5 / 1.6e-5
+  HDQ sdf ............................ 3e-4 abs
+  normals (forward-mode tangents) .... 8e-3 abs per component, mean < 6e-4
+  albedo / roughness / occ ........... 1e-4 abs
+  traced surfaces .................... median |st err| < 2e-4; rays whose 16-iteration trace has not converged
+                                       amplify sdf noise (occ = 500 d / t), so frame maps are judged by the
+                                       fraction of pixels within tolerance + PSNR, not by max error
+  frames ............................. rgb PSNR >= 40 dB (relight/novel), >= 50 dB (sphere), >= 80 dB (volume)
+bf16 operands are available (cfg.mlp_dtype='bf16'); they are ~10x noisier (sdf mean err 5e-4) and tested loosely.
+"""
+import numpy as np
+import pytest
+import torch
+
+from relightableavatar_amd import synthetic
+from relightableavatar_amd.config import make_cfg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def build(mode, dtype='f16', **kw):
+    from relightableavatar_amd.networks import make_network
+    dev = _dev()
+    cfg = make_cfg(mode, mlp_dtype=dtype, **kw)
+    relight = mode in ('relight', 'novel_light')
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
+    return cfg, net.to(dev).eval(), dev
+
+
+def err(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    same = (a == b) | (a.isnan() & b.isnan())
+    return torch.where(same, torch.zeros_like(a), (a - b).abs())
+
+
+def psnr(a, b):
+    e = err(a, b)
+    return float(-10 * torch.log10(torch.mean(e ** 2)))
+
+
+@pytest.fixture(scope='module')
+def ops(golden):
+    return {k: T(v) for k, v in golden('ops.npz').items()}
+
+
+@pytest.fixture(scope='module')
+def relight():
+    cfg, net, dev = build('relight')
+    body = synthetic.to_device(synthetic.make_body(0, posed=True), dev)
+    eng = net.set_frame(body)
+    return cfg, net, dev, body, eng
+
+
+def test_native_library_is_loaded(relight):
+    """the path under test is the in-tree HIP extension, not a torch fallback"""
+    maps = open('/proc/self/maps').read()
+    assert 'librelightableavatar_hip.so' in maps
+
+
+def test_mlp_stage(ops, relight):
+    _, _, dev, _, eng = relight
+    resd, sdf, feat = eng.debug_mlp(ops['mlp_bpts'].to(dev))
+    assert float(err(resd, ops['mlp_resd']).max()) < 5e-6
+    e = err(sdf[:, None], ops['mlp_sdf'])
+    assert float(e.max()) < 3e-4 and float(e.mean()) < 8e-5
+    e = err(feat, ops['mlp_feat'])
+    assert float(e.max()) < 2e-4 and float(e.mean()) < 3e-5
+
+
+def test_mlp_stage_bf16(ops):
+    cfg, net, dev = build('relight', dtype='bf16')
+    eng = net.set_frame(synthetic.to_device(synthetic.make_body(0, posed=True), dev))
+    resd, sdf, feat = eng.debug_mlp(ops['mlp_bpts'].to(dev))
+    e = err(sdf[:, None], ops['mlp_sdf'])
+    assert float(e.max()) < 5e-3 and float(e.mean()) < 1e-3
+
+
+def test_coarse_level_and_warp(ops, relight):
+    _, _, dev, body, eng = relight
+    o = eng.debug_hdq(ops['hdq_x'].to(dev), 0.125)
+    m = ops['knn_fine']
+    assert o.fine_count == int(m.sum())
+    assert int((o.nn_batch.cpu().long() != ops['knn_nn_batch']).sum()) == 0        # exact 3-NN + geodesic rule
+    assert float(err(o.sdf_batch, ops['knn_sdf_batch']).max()) < 1e-6
+    assert float(err(o.bpts.cpu()[m], ops['warp_bpts'][m]).max()) < 2e-6
+    assert float(err(o.tpts.cpu()[m], ops['warp_tpts'][m]).max()) < 2e-6
+    assert float(err(o.mats.cpu()[m][:, :12], ops['warp_A_bw'][m][:, :3].reshape(-1, 12)).max()) < 2e-6
+    assert float(err(o.mats.cpu()[m][:, 12:], ops['warp_big_A_bw'][m][:, :3].reshape(-1, 12)).max()) < 2e-6
+
+
+def test_bvh_equals_brute_force(relight):
+    """the per-frame vertex BVH must return the same neighbours as the O(N) scan, also far from the body"""
+    _, _, dev, body, eng = relight
+    g = torch.Generator().manual_seed(7)
+    x = ((torch.rand(100000, 3, generator=g) - 0.5) * 3.0).to(dev)
+    a = eng.debug_hdq(x, 0.125)
+    eng.set_knn_mode(False)
+    eng.set_frame(body, force=True)
+    b = eng.debug_hdq(x, 0.125)
+    eng.set_knn_mode(True)
+    eng.set_frame(body, force=True)
+    assert int((a.nn_batch != b.nn_batch).sum()) == 0
+    assert float((a.sdf_coarse - b.sdf_coarse).abs().max()) == 0.0
+    assert a.fine_count == b.fine_count
+
+
+def test_hdq_sdf(ops, relight):
+    _, net, dev, body, _ = relight
+    x = ops['hdq_x'].to(dev)
+    s = net.inference_world_distance_field(x[None], body, smooth_transition=True, dist_th=0.125)
+    assert s.shape == (1, x.shape[0], 1)
+    assert float(err(s[0], ops['hdq_sdf']).max()) < 3e-4
+    s = net.inference_world_distance_field(x[None], body, smooth_transition=False, dist_th=0.125)
+    assert float(err(s[0], ops['hdq_sdf_nosmooth']).max()) < 3e-4
+    coarse = ~ops['knn_fine']
+    assert float(err(s[0], ops['hdq_sdf_nosmooth'])[coarse].max()) < 1e-6         # coarse-only points are pure fp32
+
+
+def test_forward_raw(ops, relight):
+    _, net, dev, body, _ = relight
+    raw = net(ops['fwd_x'][None].to(dev), None, 0.005, body).raw[0]
+    ref = ops['fwd_raw']
+    assert raw.shape == ref.shape == (300, 17)
+    assert float(err(raw[:, 0:9], ref[:, 0:9]).max()) < 5e-6                       # cpts, bpts, resd
+    assert float(err(raw[:, 9:13], ref[:, 9:13]).max()) < 1e-4                     # albedo, roughness
+    assert float(err(raw[:, 16], ref[:, 16]).max()) < 1e-4                         # occ
+    e = err(raw[:, 13:16], ref[:, 13:16])
+    assert float(e.max()) < 8e-3 and float(e.mean()) < 6e-4                        # world normals
+
+
+def test_forward_zero_outside_dist_th(relight):
+    _, net, dev, body, _ = relight
+    x = torch.tensor([[[5.0, 5.0, 5.0], [0.0, 0.0, 3.0]]], device=dev)
+    assert float(net(x, None, 0.005, body).raw.abs().max()) == 0.0
+
+
+def test_sphere_tracing(ops, relight):
+    cfg, _, dev, _, eng = relight
+    p = eng.trace_params(cfg.sphere_tracing, cfg.dist_th, False)
+    surf, occ, st, ot = eng.sphere_trace(ops['st_o'].to(dev), ops['st_d'].to(dev), ops['st_near'].to(dev), ops['st_far'].to(dev), p)
+    assert int(((occ.cpu() < 1) != (ops['st_occ'][:, 0] < 1)).sum()) <= 2           # hit mask
+    e = err(st[:, None], ops['st_st'])
+    assert float(e.median()) < 2e-4 and float((e < 3e-3).float().mean()) > 0.97
+    p = eng.trace_params(cfg.obj_lvis, 0.125, True)
+    n = ops['sh_o'].shape[0]
+    _, occ, _, _ = eng.sphere_trace(ops['sh_o'].to(dev), ops['sh_d'].to(dev), torch.full((n,), 0.02, device=dev),
+                                    torch.full((n,), 0.8, device=dev), p, tan_i=ops['sh_tan_i'].to(dev))
+    e = err(occ[:, None], ops['sh_occ'])
+    assert float(e.mean()) < 5e-3 and float((e < 2e-2).float().mean()) > 0.97
+
+
+def _frame(mode, fname, golden, **kw):
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden(fname)
+    if mode == 'anisdf':
+        kw['n_samples'] = int(ref['n_samples'])
+    cfg, net, dev = build(mode, **kw)
+    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']),
+                                                     n_novel_lights=3 if mode == 'novel_light' else 0), dev)
+    return make_renderer(cfg, net).render(batch), ref, batch, net
+
+
+def within(out, ref, key, tol, frac):
+    e = err(out[key], ref[key])
+    ok = float((e <= tol).float().mean())
+    assert ok >= frac, f'{key}: only {ok * 100:.1f}% of elements within {tol}'
+
+
+def test_frame_anisdf_volume(golden):
+    out, ref, _, _ = _frame('anisdf', 'frame_anisdf.npz', golden)
+    for k, tol in (('acc_map', 5e-4), ('depth_map', 1e-3), ('cpts_map', 2e-4), ('resd_map', 1e-5), ('norm_map', 2e-3), ('rgb_map', 3e-4)):
+        within(out, ref, k, tol, 1.0)
+    assert psnr(out.rgb_map, ref['rgb_map']) > 80
+
+
+def test_frame_sphere_tracing(golden):
+    out, ref, _, _ = _frame('sphere_tracing', 'frame_sphere.npz', golden)
+    hit, hit_ref = out.acc_map.cpu() > 0, T(ref['acc_map']) > 0
+    assert float((hit == hit_ref).float().mean()) > 0.99
+    within(out, ref, 'acc_map', 2e-2, 0.98)
+    within(out, ref, 'surf_map', 2e-3, 0.98)
+    within(out, ref, 'norm_map', 2e-2, 0.97)
+    within(out, ref, 'rgb_map', 5e-3, 0.98)
+    assert psnr(out.rgb_map, ref['rgb_map']) > 50
+
+
+def test_frame_relight(golden):
+    out, ref, batch, net = _frame('relight', 'frame_relight.npz', golden, vis_specular_map=True)
+    np.testing.assert_allclose(batch.wbounds.cpu().numpy(), ref['wbounds_after'], atol=1e-6)     # in-place bbox growth quirk
+    assert bool(((out.acc_map.cpu() > 0) == (T(ref['acc_map']) > 0)).all())
+    within(out, ref, 'albedo_map', 5e-4, 0.99)
+    within(out, ref, 'roughness_map', 5e-4, 0.99)
+    within(out, ref, 'surf_map', 1e-3, 0.98)
+    within(out, ref, 'norm_map', 2e-2, 0.97)
+    within(out, ref, 'shade_map', 2e-2, 0.97)
+    within(out, ref, 'spec_map', 5e-3, 0.97)
+    within(out, ref, 'rgb_map', 1e-2, 0.97)
+    assert psnr(out.rgb_map, ref['rgb_map']) > 40
+    c = net.engine().counters()
+    assert c.n_hit_pixels == 256 and c.n_shadow_rays > 0 and c.n_fine_sdf > c.n_shadow_rays
+
+
+def test_frame_novel_light(golden):
+    out, ref, batch, _ = _frame('novel_light', 'frame_novel.npz', golden)
+    assert set(out.keys()) == {'main', 'diff', *batch.novel_lights.keys()}
+    within(out.main, {k[5:]: v for k, v in ref.items() if k.startswith('main.')}, 'rgb_map', 1e-2, 0.97)
+    for n in batch.novel_lights:
+        sub = {k[len(n) + 1:]: v for k, v in ref.items() if k.startswith(n + '.')}
+        within(out[n], sub, 'rgb_map', 1e-2, 0.97)
+        within(out[n], sub, 'shade_map', 2e-2, 0.97)
+        within(out[n], sub, 'spec_map', 5e-3, 0.97)
+        assert psnr(out[n].rgb_map, sub['rgb_map']) > 40
+
+
+def test_reshade_is_linear_in_the_probe(relight):
+    """size-independent property: shade (linear radiance sum) is linear in the probe; batched == one by one"""
+    cfg, net, dev, body, eng = relight
+    g = torch.Generator().manual_seed(3)
+    P = 5000
+    ro = torch.randn(P, 3, generator=g).to(dev) + torch.tensor([0.0, 0.0, -2.0], device=dev)
+    surf = (torch.rand(P, 3, generator=g) - 0.5).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    alb, rgh = torch.rand(P, 3, generator=g).to(dev), (torch.rand(P, generator=g) * 0.9 + 0.09).to(dev)
+    lvis, ldot = torch.rand(P, 512, generator=g).to(dev), (torch.rand(P, 512, generator=g) * 2 - 1).to(dev)
+    p1, p2 = torch.rand(16, 32, 3, generator=g).to(dev), torch.rand(16, 32, 3, generator=g).to(dev) * 3
+    probes = torch.stack([p1, p2, p1 + 2 * p2] + [p1 * k for k in range(2, 9)])         # 10 probes -> two launches
+    rgb, shade, spec = eng.reshade(ro, surf, nrm, alb, rgh, lvis, ldot, probes)
+    assert rgb.shape == (10, P, 3)
+    assert float((shade[2] - (shade[0] + 2 * shade[1])).abs().max()) < 2e-4 * float(shade[2].abs().max())
+    assert float((spec[5] - 4 * spec[0]).abs().max()) <= 1e-5 * float(spec[5].abs().max()) + 1e-7
+    r1, s1, _ = eng.reshade(ro, surf, nrm, alb, rgh, lvis, ldot, probes[1:2])
+    assert float((r1[0] - rgb[1]).abs().max()) == 0.0 and float((s1[0] - shade[1]).abs().max()) == 0.0
+
+
+def test_full_size_properties():
+    """BASELINE size (512x512 relight): chunking / sharding invariance, determinism, bounds"""
+    from relightableavatar_amd import shard
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight')
+    rend = make_renderer(cfg, net)
+    H = 512
+    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True), dev)
+    wb0 = base.wbounds.clone()
+    out = rend.render(base)
+    rgb, acc = out.rgb_map.clone(), out.acc_map.clone()
+    assert torch.isfinite(rgb).all() and float(rgb.min()) >= 0 and float(rgb.max()) <= 1.0 + 1e-6
+    assert float(acc.min()) >= 0 and float(acc.max()) <= 1.0
+    hit = acc > 0
+    assert 0.2 < float(hit.float().mean()) < 0.9
+    assert float(rgb[~hit].abs().max()) == 0.0                                 # zeros outside the silhouette
+    n = out.norm_map[hit] / acc[hit][:, None]
+    assert float((n.norm(dim=-1) - 1).abs().max()) < 1e-3                      # premultiplied unit normals
+    # determinism: same frame again -> bit identical
+    base.wbounds.copy_(wb0)
+    out2 = rend.render(base)
+    assert float((out2.rgb_map - rgb).abs().max()) == 0.0
+    # rays are independent: rendering two interleaved shards and merging gives the same image
+    parts = []
+    for r in range(2):
+        base.wbounds.copy_(wb0)
+        parts.append(rend.render(shard.shard_batch(base, r, 2)).rgb_map[0])
+    P = rgb.shape[1]
+    merged = torch.zeros_like(rgb[0])
+    merged[0::2], merged[1::2] = parts[0], parts[1]
+    assert float((merged - rgb[0]).abs().max()) == 0.0
+    c = net.engine().counters()
+    assert c.n_fine_sdf > 100 * c.n_hit_pixels                                 # ~1000 fine queries per hit pixel
+
+
+def test_edge_cases(relight):
+    cfg, net, dev, body, eng = relight
+    from relightableavatar_amd.renderer import make_renderer
+    rend = make_renderer(cfg, net)
+    # empty ray set (chunkify's zero-length case)
+    b = synthetic.to_device(synthetic.make_batch(64, 64, seed=0, posed=True), dev)
+    for k in ('ray_o', 'ray_d', 'near', 'far'):
+        b[k] = b[k][:, :0]
+    out = rend.render(b)
+    assert out.rgb_map.shape == (1, 0, 3)
+    # rays that all miss the body
+    b = synthetic.to_device(synthetic.make_batch(64, 64, seed=0, posed=True), dev)
+    b.ray_d = torch.nn.functional.normalize(b.ray_d * torch.tensor([1.0, 1.0, -1.0], device=dev), dim=-1)
+    out = rend.render(b)
+    assert float(out.acc_map.abs().max()) == 0.0 and float(out.rgb_map.abs().max()) == 0.0
+    # ragged size (not a multiple of any tile) through the operator API
+    x = (torch.rand(1, 1237, 3, device=dev) - 0.5)
+    s = net.inference_world_distance_field(x, body, smooth_transition=True)
+    assert s.shape == (1, 1237, 1) and torch.isfinite(s).all()
+
+
+def test_errors_are_python_exceptions():
+    from relightableavatar_amd import _lib
+    from relightableavatar_amd.engine import Engine
+    dev = _dev()
+    eng = Engine(make_cfg('relight'), dev, relight=True)
+    with pytest.raises(_lib.RaError, match='weights not finalized'):
+        eng.hdq_sdf(torch.zeros(4, 3, device=dev), 0.1, True)
+    with pytest.raises(_lib.RaError, match='missing weight'):
+        eng.load_state_dict({'residual_deformation_network.mlp.linears.0.weight': torch.zeros(256, 219)})

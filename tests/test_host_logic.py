@@ -1,0 +1,129 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side mirror classes
+keep the reference's state_dict keys, chunking/sharding logic (incl. a world_size-2 gloo run)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from relightableavatar_amd import _lib, shard, synthetic
+from relightableavatar_amd.config import make_cfg
+from relightableavatar_amd.renderer.chunking import chunks
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.lib()
+    hdr = open(os.path.join(REPO, 'include', 'relightableavatar.h')).read()
+    declared = set(re.findall(r'^(?:int|const char\*)\s+(ra_[a-z0-9_]+)\s*\(', hdr, flags=re.M))
+    assert declared, 'no declarations found'
+    for name in declared:
+        assert hasattr(L, name), f'{name} declared in the header but not exported'
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert L.ra_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from relightableavatar_amd.engine import Engine
+    with pytest.raises(_lib.RaError, match='no CPU fallback'):
+        Engine(make_cfg('relight'))
+    from relightableavatar_amd.networks import make_network
+    net = make_network(make_cfg('relight'))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net.inference_world_distance_field(torch.zeros(1, 4, 3), synthetic.make_body(0))
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'relightableavatar_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                imports = [l for l in src.split('\n') if re.match(r'\s*(from|import)\s', l)]
+                assert not any('oracle' in l for l in imports), f'{f} imports the oracle'
+
+
+@pytest.mark.parametrize('mode,relight,n', [('anisdf', False, 64), ('relight', True, 82)])
+def test_state_dict_keys_match_reference(mode, relight, n):
+    from relightableavatar_amd.networks import make_network
+    cfg = make_cfg(mode)
+    net = make_network(cfg)
+    sd = synthetic.make_state_dict(0, relight=relight, cfg=cfg)     # keys validated against the reference in make_golden.py
+    assert len(net.state_dict()) == n
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert net.signed_distance_network.mlp.lin3.weight_v.shape == (205, 256)
+    assert net.signed_distance_network.mlp.lin8.weight_v.shape == (257, 256)
+    assert net.residual_deformation_network.mlp.linears[4].weight.shape == (256, 475)
+    assert net.render_network.l3.weight_v.shape == (256, 412)
+    if relight:
+        assert net.global_env_map.shape == (32, 64, 3) and net.light_xyz.shape == (16, 32, 3)
+        assert abs(float(net.light_area.sum()) - 4 * 3.14159265) < 1e-4
+
+
+def test_chunk_rule():
+    assert chunks(0, 8192) == []
+    assert chunks(100, 8192) == [(0, 100)]
+    assert chunks(262144, 65536) == [(0, 65536), (65536, 131072), (131072, 196608), (196608, 262144)]
+    c = chunks(150000, 65536)          # ceil(150000 / 3) = 50000
+    assert c == [(0, 50000), (50000, 100000), (100000, 150000)]
+
+
+def test_make_cfg_modes():
+    c = make_cfg('relight')
+    assert c.dist_th == 0.125 and c.obj_lvis.dist_th == 0.125 and c.n_samples == 3 and c.render_chunk_size == 65536
+    assert c.renderer_module.endswith('sphere_tracing_renderer') and c.network_module.endswith('relight_network')
+    c = make_cfg('anisdf')
+    assert c.n_samples == 128 and c.render_chunk_size == 8192 and c.dist_th == 0.1
+    assert make_cfg('novel_light').renderer_module.endswith('novel_light_sphere_tracing')
+    with pytest.raises(ValueError):
+        make_cfg('nope')
+
+
+def test_shard_roundtrip_single_process():
+    P, world = 1003, 4
+    x = torch.arange(P * 3, dtype=torch.float32).view(1, P, 3)
+    idx = [shard.shard_indices(P, r, world) for r in range(world)]
+    assert sorted(torch.cat(idx).tolist()) == list(range(P))
+    b = synthetic.make_batch(32, 32, seed=0)
+    s0 = shard.shard_batch(b, 0, 2)
+    assert s0.ray_o.shape[1] == (b.ray_o.shape[1] + 1) // 2 and s0.wbounds is not b.wbounds
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from relightableavatar_amd import shard
+from relightableavatar_amd.base_utils import dotdict
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+P = 1001
+g = torch.Generator().manual_seed(0)
+ray = torch.rand(1, P, 3, generator=g)
+batch = dotdict(ray_o=ray, ray_d=ray * 2, near=ray[..., 0], far=ray[..., 1], wbounds=torch.zeros(1, 2, 3))
+class FakeRenderer:                       # per-ray function of the inputs: stands in for the GPU renderer
+    def render(self, b):
+        return dotdict(rgb_map=b.ray_o * 3 + b.ray_d, acc_map=b.near + b.far)
+out = shard.render_sharded(FakeRenderer(), batch, ('rgb_map', 'acc_map'), rank, world)
+ref = FakeRenderer().render(batch)
+assert out.rgb_map.shape == (1, P, 3) and out.acc_map.shape == (1, P)
+assert torch.equal(out.rgb_map, ref.rgb_map) and torch.equal(out.acc_map, ref.acc_map)
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_sharded_render_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29611', str(script), REPO], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('ok') == 2
