@@ -25,10 +25,10 @@ F_FULL = 3_934_208 + 197_632
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
-def cpu_baseline(cfg, H, n_target=256):
+def cpu_baseline(cfg, H, n_target=96, threads=16):
     """oracle (CPU port of the reference path) on a strided sample of the same frame's rays."""
     from oracle import ra_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, threads))   # more threads than this only add sync overhead here
     batch = synthetic.make_batch(H, H, seed=0, posed=True)
     P = batch.ray_o.shape[1]
     stride = max(1, P // n_target)

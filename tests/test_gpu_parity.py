@@ -309,5 +309,5 @@ def test_errors_are_python_exceptions():
     eng = Engine(make_cfg('relight'), dev, relight=True)
     with pytest.raises(_lib.RaError, match='weights not finalized'):
         eng.hdq_sdf(torch.zeros(4, 3, device=dev), 0.1, True)
-    with pytest.raises(_lib.RaError, match='missing weight'):
+    with pytest.raises(_lib.RaError, match='missing'):
         eng.load_state_dict({'residual_deformation_network.mlp.linears.0.weight': torch.zeros(256, 219)})
