@@ -25,7 +25,7 @@ F_FULL = 3_934_208 + 197_632
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
-def cpu_baseline(cfg, H, n_target=96, threads=16):
+def cpu_baseline(cfg, H, n_target=768, threads=16):
     """oracle (CPU port of the reference path) on a strided sample of the same frame's rays."""
     from oracle import ra_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, threads))   # more threads than this only add sync overhead here
