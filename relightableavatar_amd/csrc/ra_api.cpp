@@ -134,9 +134,11 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     launch_pack_verts(f->pverts, nv, c->fpverts4.as<float4>(), s);
     launch_vert_blend(f->weights, f->A, f->big_A, nv, nb, c->fvertA.as<float>(), s);
     const int nleaf = c->use_bvh ? bvh_leaf_count(nv) : 0;
+    const int nsuper = bvh_super_count(nleaf);
     if (nleaf > 0) {
-        if (c->fbvh_pts.ensure((size_t)nv * 16) || c->fbvh_pairs.ensure((size_t)nleaf * (3 * 16 + 2 * 24))) return 1;
-        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float4>(), c->fbvh_pairs.as<float4>(), nleaf, s);
+        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * 16) || c->fbvh_pairs.ensure((size_t)(nleaf + nsuper) * 32)) return 1;
+        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float4>(), c->fbvh_pairs.as<float4>(),
+                         c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf, nleaf, nsuper, s);
         RA_HIP(hipGetLastError());
     }
     launch_fold_bias(c->cond_r0.as<float>(), cond, 0, cond, f->poses, c->b_r0.as<float>(), c->fbias_r0.as<float>(), s);
@@ -147,8 +149,8 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     fr.R = c->fR.as<float>(); fr.Th = c->fTh.as<float>(); fr.vertA = c->fvertA.as<float>(); fr.pverts4 = c->fpverts4.as<float4>();
     fr.pnorm = c->fpnorm.as<float>(); fr.tverts = c->ftverts.as<float>(); fr.bias_r0 = c->fbias_r0.as<float>();
     fr.bias_r4 = c->fbias_r4.as<float>(); fr.bias_c3 = c->fbias_c3.as<float>(); fr.n_verts = nv;
-    fr.bvh_pts = c->fbvh_pts.as<float4>(); fr.bvh_pairs = c->fbvh_pairs.as<float4>(); fr.bvh_leaves = nleaf;
-    fr.bvh_boxes = reinterpret_cast<const float*>(c->fbvh_pairs.as<float4>() + (size_t)3 * nleaf);
+    fr.bvh_pts = c->fbvh_pts.as<float4>(); fr.bvh_lbox = c->fbvh_pairs.as<float4>();
+    fr.bvh_sbox = c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf; fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
     c->have_frame = true;
     RA_HIP(hipGetLastError());
     return 0;
@@ -614,7 +616,7 @@ int ra_debug_hdq(ra_ctx* c, const float* x, int n, float th, float* sdf_coarse, 
     HdqOut out{};
     out.sdf = sdf_coarse; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = fb;
     out.dbg_sdf_batch = sdf_batch; out.dbg_nn_batch = nn_batch; out.dbg_d2 = d2; out.dbg_bpts = bpts; out.dbg_tpts = tpts; out.dbg_mats = mats;
-    out.counters = nullptr;
+    out.counters = dcnt(c);
     RA_HIP(hipMemsetAsync(bpts, 0, (size_t)n * 12, s));
     RA_HIP(hipMemsetAsync(tpts, 0, (size_t)n * 12, s));
     RA_HIP(hipMemsetAsync(mats, 0, (size_t)n * 96, s));

@@ -68,11 +68,12 @@ struct FrameState {         // device pointers owned by the ctx
     float* bias_r4;  // 256
     float* bias_c3;  // 256 (colour net, cond_fix)
     int n_verts;
-    // exact 3-NN acceleration: implicit complete binary tree over Morton-sorted vertices, 8 per leaf
+    // exact 3-NN acceleration: Morton-sorted vertices, boxes of 32-point leaves and of 8-leaf groups
     const float4* bvh_pts;    // n_verts sorted points, w = original vertex index (int bits)
-    const float4* bvh_pairs;  // per internal node: 3 float4 = boxes of its two children
-    const float* bvh_boxes;   // per node (heap order): own box, 6 floats
-    int bvh_leaves;           // number of leaves (power of two); 0 -> brute force
+    const float4* bvh_lbox;   // per leaf: lo, hi
+    const float4* bvh_sbox;   // per super box: lo, hi
+    int bvh_leaves;           // 0 -> brute force
+    int bvh_supers;
 };
 
 struct DevCounters {       // device-side work counters (ra_get_counters)

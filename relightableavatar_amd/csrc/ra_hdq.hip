@@ -15,6 +15,7 @@
 // Skinning: A_bw = sum_k w_k * (sum_j weights[nn_k][j] A_j); the inner sum is a per-vertex table
 // built once per frame (vert_blend_kernel), so a point gathers 3x24 floats instead of 3x52.
 #include "ra_kernels.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -73,13 +74,18 @@ __global__ void fold_bias_kernel(const float* __restrict__ W, int ld, int col0, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// BVH over the posed vertices, rebuilt per frame on the stream by ONE workgroup:
+// Vertex boxes for the exact 3-NN, rebuilt per frame on the stream by ONE workgroup:
 //   bbox -> 30-bit Morton codes -> bitonic sort in LDS -> sorted float4 (xyz, index) ->
-//   leaf boxes (8 points) -> upper levels of an implicit complete binary tree (heap order).
+//   leaf boxes (32 consecutive points) -> super boxes (8 consecutive leaves).
+// A flat, wide, 3-level structure on purpose: queries are swept through it with wave-uniform
+// control flow (hdq_coarse_kernel), so there are no dependent-load chains to wait on.
 // ---------------------------------------------------------------------------------------------
 constexpr int BVH_THREADS = 1024;
-constexpr int BVH_LEAF = 8;
+constexpr int BVH_LEAF = 32;
+constexpr int BVH_FAN = 8;
 constexpr int BVH_MAXN = 16384;
+constexpr int BVH_MAXL = BVH_MAXN / BVH_LEAF;          // 512 leaves
+constexpr int BVH_MAXS = BVH_MAXL / BVH_FAN;           // 64 super boxes
 
 __device__ __forceinline__ unsigned expand10(unsigned v) {
     v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -90,15 +96,13 @@ __device__ __forceinline__ unsigned expand10(unsigned v) {
 }
 
 __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __restrict__ pv, int n, float4* __restrict__ pts,
-                                                                float* __restrict__ boxes /* 2*nl x 6 scratch */,
-                                                                float4* __restrict__ pairs, int nl) {
+                                                                float4* __restrict__ lbox, float4* __restrict__ sbox, int nl, int ns) {
     __shared__ unsigned long long keys[BVH_MAXN];     // code << 32 | index (static: 128 KB of the CU's 160 KB)
     __shared__ float red[6][BVH_THREADS / 64];
     __shared__ float bb[6];
     const int tid = threadIdx.x;
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    // bbox
     float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
     for (int i = tid; i < n; i += BVH_THREADS) {
         const float4 v = pv[i];
@@ -117,7 +121,6 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         bb[tid] = a;
     }
     __syncthreads();
-    // Morton keys
     for (int i = tid; i < np2; i += BVH_THREADS) {
         unsigned long long k = ~0ull;
         if (i < n) {
@@ -135,7 +138,6 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         keys[i] = k;
     }
     __syncthreads();
-    // bitonic sort (ascending)
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += BVH_THREADS) {
@@ -148,44 +150,43 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
             }
             __syncthreads();
         }
-    // sorted points + leaf boxes
-    for (int i = tid; i < n; i += BVH_THREADS) {
-        const unsigned id = (unsigned)(keys[i] & 0xffffffffull);
-        float4 v = pv[id];
-        v.w = __int_as_float((int)id);
-        pts[i] = v;
+    for (int i = tid; i < nl * BVH_LEAF; i += BVH_THREADS) {
+        float4 v = make_float4(__int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7fffffff));
+        if (i < n) {
+            const unsigned id = (unsigned)(keys[i] & 0xffffffffull);
+            v = pv[id];
+            v.w = __int_as_float((int)id);
+        }
+        pts[i] = v;        // padded with +inf points: (p - inf)^2 = inf never beats a finite bound
     }
-    __syncthreads();
+    // leaf boxes into LDS scratch (reuse red-sized arrays is too small -> reuse keys' tail? keep simple: global + LDS copy)
+    __shared__ float lb[BVH_MAXL][6];
     for (int l = tid; l < nl; l += BVH_THREADS) {
         float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
         for (int e = 0; e < BVH_LEAF; ++e) {
             const int i = l * BVH_LEAF + e;
             if (i < n) {
-                const unsigned id = (unsigned)(keys[i] & 0xffffffffull);
-                const float4 v = pv[id];
+                const float4 v = pv[(unsigned)(keys[i] & 0xffffffffull)];
                 lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
                 hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
             }
         }
-        float* b = boxes + (size_t)(nl + l) * 6;
-        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+        lbox[2 * l] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        lbox[2 * l + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lb[l][c] = lo[c]; lb[l][3 + c] = hi[c]; }
     }
     __syncthreads();
-    __threadfence_block();
-    for (int lvl = nl >> 1; lvl >= 1; lvl >>= 1) {      // nodes [lvl, 2*lvl)
-        for (int k = tid; k < lvl; k += BVH_THREADS) {
-            const int node = lvl + k;
-            const float* a = boxes + (size_t)(2 * node) * 6;
-            const float* c = a + 6;
-            float* b = boxes + (size_t)node * 6;
+    for (int sidx = tid; sidx < ns; sidx += BVH_THREADS) {
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        for (int e = 0; e < BVH_FAN; ++e) {
+            const int l = sidx * BVH_FAN + e;
+            if (l < nl)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { b[d] = fminf(a[d], c[d]); b[3 + d] = fmaxf(a[3 + d], c[3 + d]); }
-            pairs[3 * node + 0] = make_float4(a[0], a[1], a[2], a[3]);
-            pairs[3 * node + 1] = make_float4(a[4], a[5], c[0], c[1]);
-            pairs[3 * node + 2] = make_float4(c[2], c[3], c[4], c[5]);
+                for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], lb[l][c]); hi[c] = fmaxf(hi[c], lb[l][3 + c]); }
         }
-        __syncthreads();
-        __threadfence_block();
+        sbox[2 * sidx] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        sbox[2 * sidx + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
 }
 
@@ -196,16 +197,22 @@ __device__ __forceinline__ float box_dist2(const float p[3], float lx, float ly,
     return dx * dx + dy * dy + dz * dz;
 }
 
-// top-3 insertion; ties resolved towards the lower vertex index (what an ascending scan gives)
+// top-3 insertion; ties resolved towards the lower vertex index (what an ascending scan gives).
+// Pure value selects under one wave-uniform guard: keeps the six state words in VGPRs (a 3-way
+// branchy version made LLVM spill them to scratch behind a computed store address).
 __device__ __forceinline__ void knn_insert(float d, int id, float& d0, float& d1, float& d2, int& i0, int& i1, int& i2) {
-    if (d < d2 || (d == d2 && id < i2)) {
-        if (d < d0 || (d == d0 && id < i0)) { d2 = d1; i2 = i1; d1 = d0; i1 = i0; d0 = d; i0 = id; }
-        else if (d < d1 || (d == d1 && id < i1)) { d2 = d1; i2 = i1; d1 = d; i1 = id; }
-        else { d2 = d; i2 = id; }
-    }
+    const bool c2 = d < d2 || (d == d2 && id < i2);
+    if (__ballot(c2) == 0ull) return;
+    const bool c1 = d < d1 || (d == d1 && id < i1);
+    const bool c0 = d < d0 || (d == d0 && id < i0);
+    const float nd2 = c1 ? d1 : (c2 ? d : d2);
+    const int ni2 = c1 ? i1 : (c2 ? id : i2);
+    const float nd1 = c0 ? d0 : (c1 ? d : d1);
+    const int ni1 = c0 ? i0 : (c1 ? id : i1);
+    d0 = c0 ? d : d0;
+    i0 = c0 ? id : i0;
+    d1 = nd1; i1 = ni1; d2 = nd2; i2 = ni2;
 }
-
-constexpr int BVH_STACK = 14;     // depth of a 2048-leaf tree + 2
 
 __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
     if (rs.mode == 0) {
@@ -226,8 +233,9 @@ __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
 
 template <bool BVH>
 __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
-                                                                  HdqOut out) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? 16 : VT * 16];   // brute force: a vertex tile
+                                                                  HdqOut out, int dbg) {
+    // BVH: super + leaf boxes (2 float4 each); brute force: a vertex tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? (BVH_MAXS + BVH_MAXL) * 32 : VT * 16];
     const int n = rs.n_dev ? min(*rs.n_dev, n_launch) : n_launch;
     const int base = blockIdx.x * KNN_THREADS;
     if (base >= n) return;               // whole block idle (uniform)
@@ -244,52 +252,75 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
 
     float d0 = 3.0e38f, d1 = 3.0e38f, d2 = 3.0e38f;
     int i0 = 0, i1 = 0, i2 = 0;    // valid indices also for idle lanes (they run the table look-ups below)
-    if (BVH) {
-        // exact 3-NN by a WAVE-COOPERATIVE nearest-first traversal: the 64 queries of a wave are
-        // neighbouring rays, so they share one stack (held across the lanes of a VGPR: entry i
-        // lives in lane i, read with v_readlane, written with a lane-select) and every node / leaf is loaded once
-        // per wave with a wave-uniform address; a subtree is entered when ANY lane still needs it.
-        const int lane = threadIdx.x & 63;
-        const int nl = fr.bvh_leaves;
+    if (dbg & 1) { d0 = 1e-4f; d1 = 2e-4f; d2 = 3e-4f; i0 = 0; i1 = 1; i2 = 2; }
+    else if (BVH) {
+        // exact 3-NN by WAVE-UNIFORM sweeps over the flat box structure (the 64 queries of a wave
+        // are neighbouring rays): a box is opened when ANY lane may still find a closer vertex in it
+        // (conservative box distance vs the lane's current third-best), all loads have wave-uniform
+        // addresses and no load depends on another one.  Seed: the leaf nearest to the wave's first
+        // live lane is scanned first so that every lane starts with a finite bound.
+        float4* sb = reinterpret_cast<float4*>(smem);                 // [ns][2] then [nl][2]
+        const int nl = fr.bvh_leaves, ns = fr.bvh_supers;
+        float4* lbx = sb + 2 * ns;
+        for (int j = threadIdx.x; j < 2 * ns; j += KNN_THREADS) sb[j] = fr.bvh_sbox[j];
+        for (int j = threadIdx.x; j < 2 * nl; j += KNN_THREADS) lbx[j] = fr.bvh_lbox[j];
+        __syncthreads();
         if (!live) { d0 = d1 = d2 = -1.f; }            // idle lanes: every test fails, nothing is inserted
-        int vstk = 1;                                    // lane 0 holds the root
-        int sp = 1;
-        while (sp > 0) {
-            sp = __builtin_amdgcn_readfirstlane(sp) - 1;
-            const int node = __builtin_amdgcn_readlane(vstk, sp);
-            if (node >= nl) {
-                const float* bx = fr.bvh_boxes + (size_t)node * 6;
-                const float db = box_dist2(p, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
-                if (__ballot(db * 0.99999f <= d2) == 0ull) continue;
-                const int b = (node - nl) * BVH_LEAF;
-                const int ne = min(BVH_LEAF, fr.n_verts - b);
-                for (int k = 0; k < ne; ++k) {
-                    const float4 v = fr.bvh_pts[b + k];
-                    const float dx = p[0] - v.x, dy = p[1] - v.y, dz = p[2] - v.z;
-                    const float d = dx * dx + dy * dy + dz * dz;
-                    knn_insert(d, __float_as_int(v.w), d0, d1, d2, i0, i1, i2);
-                }
-                continue;
+        const unsigned long long lm = __ballot(live);
+        const int first = lm ? __ffsll((long long)lm) - 1 : 0;
+        const int lane = threadIdx.x & 63;
+        // one coalesced load per leaf (lane k holds point k; the array is padded with +inf to whole
+        // leaves), then 32 register broadcasts: no per-point memory latency
+        auto scan_leaf = [&](int l) {
+            const float4 mine = fr.bvh_pts[l * BVH_LEAF + (lane & (BVH_LEAF - 1))];
+            const int mi = __float_as_int(mine.w);
+#pragma unroll
+            for (int k = 0; k < BVH_LEAF; ++k) {
+                const float vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), k));
+                const float vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), k));
+                const float vz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), k));
+                const int id = __builtin_amdgcn_readlane(mi, k);
+                const float dx = p[0] - vx, dy = p[1] - vy, dz = p[2] - vz;
+                const float d = dx * dx + dy * dy + dz * dz;
+                knn_insert(d, id, d0, d1, d2, i0, i1, i2);
             }
-            const float4 a = fr.bvh_pairs[3 * node], b4 = fr.bvh_pairs[3 * node + 1], c4 = fr.bvh_pairs[3 * node + 2];
-            const float dl = box_dist2(p, a.x, a.y, a.z, a.w, b4.x, b4.y);
-            const float dr = box_dist2(p, b4.z, b4.w, c4.x, c4.y, c4.z, c4.w);
-            const bool wl = dl * 0.99999f <= d2, wr = dr * 0.99999f <= d2;
-            const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
-            if (ml != 0ull && mr != 0ull) {
-                const int votes_l = __popcll(__ballot(wl && (dl <= dr || !wr)));
-                const int votes_r = __popcll(__ballot(wr && (dr < dl || !wl)));
-                const int nearc = votes_l >= votes_r ? 2 * node : 2 * node + 1;
-                vstk = (lane == sp) ? (nearc ^ 1) : vstk;
-                vstk = (lane == sp + 1) ? nearc : vstk;
-                sp += 2;
-            } else if (ml != 0ull) {
-                vstk = (lane == sp) ? 2 * node : vstk;
-                sp += 1;
-            } else if (mr != 0ull) {
-                vstk = (lane == sp) ? 2 * node + 1 : vstk;
-                sp += 1;
+        };
+        auto sdist = [&](int j) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
+        auto ldist = [&](int j) { const float4 lo = lbx[2 * j], hi = lbx[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
+        // --- seed: nearest super box, then nearest leaf in it, as seen by the first live lane
+        int seed;
+        {
+            float best = 3.4e38f;
+            int bi = 0;
+            for (int j = 0; j < ns; ++j) { const float d = sdist(j); if (d < best) { best = d; bi = j; } }
+            bi = __builtin_amdgcn_readlane(bi, first);
+            best = 3.4e38f;
+            int bl = bi * BVH_FAN;
+            const int l1 = min(nl, (bi + 1) * BVH_FAN);
+            for (int l = bi * BVH_FAN; l < l1; ++l) { const float d = ldist(l); if (d < best) { best = d; bl = l; } }
+            seed = __builtin_amdgcn_readlane(bl, first);
+        }
+        int n_scan = 1, n_open = 0;
+        scan_leaf(seed);
+        // --- which super boxes can still matter to some lane (BVH_MAXS <= 64 -> one 64-bit mask)
+        unsigned long long open = 0ull;
+        for (int j = 0; j < ns; ++j)
+            if (__ballot(sdist(j) * 0.99999f <= d2) != 0ull) open |= 1ull << j;
+        while (open) {
+            const int sidx = __ffsll((long long)open) - 1;
+            open &= open - 1ull;
+            ++n_open;
+            const int l1 = min(nl, (sidx + 1) * BVH_FAN);
+            for (int l = sidx * BVH_FAN; l < l1; ++l) {
+                if (l == seed) continue;
+                if (__ballot(ldist(l) * 0.99999f <= d2) == 0ull) continue;
+                scan_leaf(l);
+                ++n_scan;
             }
+        }
+        if ((dbg & 4) && out.counters && lane == 0) {
+            atomicAdd(&out.counters->n_shadow_rays, (unsigned long long)n_scan);      // profiling aid: leaves scanned
+            atomicAdd(&out.counters->n_hit_pixels, (unsigned long long)n_open);       //                supers opened
         }
     } else {
         // brute force: vertices stream through LDS, all lanes read the same vertex (broadcast)
@@ -304,10 +335,11 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
                 const float4 v = sv[j];
                 const float dx = p[0] - v.x, dy = p[1] - v.y, dz = p[2] - v.z;
                 const float d = dx * dx + dy * dy + dz * dz;
-                if (d < d2) knn_insert(d, v0 + j, d0, d1, d2, i0, i1, i2);
+                knn_insert(d, v0 + j, d0, d1, d2, i0, i1, i2);
             }
         }
     }
+    if (dbg & 2) { if (live) out.sdf[i] = d0 + d1 + d2 + (float)(i0 + i1 + i2); return; }
     // signed coarse distances (sample_utils.py:124-128) and the geodesic neighbour rule (:148-160)
     float dk[3] = {d0, d1, d2};
     int ik[3] = {i0, i1, i2};
@@ -407,18 +439,14 @@ void launch_fold_bias(const float* W, int ld, int col0, int ncond, const float* 
 }
 
 int bvh_leaf_count(int n_verts) {
-    if (n_verts > BVH_MAXN) return 0;     // node ids must fit 12 bits + the sort must fit LDS
-    int nl = 1;
-    while (nl * BVH_LEAF < n_verts) nl <<= 1;
-    return nl;
+    if (n_verts > BVH_MAXN) return 0;     // the sort must fit LDS; larger meshes fall back to the O(N) scan
+    return (n_verts + BVH_LEAF - 1) / BVH_LEAF;
 }
+int bvh_super_count(int n_leaves) { return (n_leaves + BVH_FAN - 1) / BVH_FAN; }
 
-void launch_bvh_build(const float4* pverts4, int n_verts, float4* bvh_pts, float4* bvh_pairs, int n_leaves, hipStream_t s) {
-    int np2 = 1;
-    while (np2 < n_verts) np2 <<= 1;
-    // boxes scratch lives behind the pairs array (3 float4 per node for 2*nl nodes, boxes need 2*nl*6 floats)
-    float* boxes = reinterpret_cast<float*>(bvh_pairs + (size_t)3 * n_leaves);
-    hipLaunchKernelGGL(bvh_build_kernel, dim3(1), dim3(BVH_THREADS), 0, s, pverts4, n_verts, bvh_pts, boxes, bvh_pairs, n_leaves);
+void launch_bvh_build(const float4* pverts4, int n_verts, float4* bvh_pts, float4* lbox, float4* sbox, int n_leaves, int n_supers,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(bvh_build_kernel, dim3(1), dim3(BVH_THREADS), 0, s, pverts4, n_verts, bvh_pts, lbox, sbox, n_leaves, n_supers);
 }
 
 void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
@@ -427,6 +455,7 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     if (n <= 0) return;
     const float inv2r2 = 1.f / (2.f * blend_radius * blend_radius);
     const dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS);
-    if (fr.bvh_leaves > 0) hipLaunchKernelGGL(hdq_coarse_kernel<true>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out);
-    else hipLaunchKernelGGL(hdq_coarse_kernel<false>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out);
+    static const int dbg = getenv("RA_COARSE_DBG") ? atoi(getenv("RA_COARSE_DBG")) : 0;   // profiling aid: 1 skip the search, 2 skip everything after it
+    if (fr.bvh_leaves > 0) hipLaunchKernelGGL(hdq_coarse_kernel<true>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, dbg);
+    else hipLaunchKernelGGL(hdq_coarse_kernel<false>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, dbg);
 }
