@@ -349,6 +349,16 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     int* hit_count = icnt(c, CNT_HIT);
     launch_surface_finish(ray_o, ray_d, ts.st, ts.occ, P, surf, depth, acc, hit_idx, hit_count, s);
     launch_accumulate(hit_count, &dcnt(c)->n_hit_pixels, s);
+    if (relit) {   // spatially coherent hit order for the shadow trace (results are scattered back, so order-free)
+        const size_t tb = sort_hits_temp_bytes(P);
+        unsigned* k0 = c->buf<unsigned>("hs_k0", P, &err);
+        unsigned* k1 = c->buf<unsigned>("hs_k1", P, &err);
+        int* v0 = c->buf<int>("hs_v0", P, &err);
+        char* tmp = c->buf<char>("hs_tmp", tb + 16, &err);
+        if (err) return 1;
+        const float bmin[3] = {bbox[0], bbox[1], bbox[2]};
+        if (launch_sort_hits(surf, acc, P, bmin, k0, k1, v0, hit_idx, tmp, tb, s)) { ra_set_error("ra_render_sphere_chunk: radix sort failed"); return 1; }
+    }
     // ---- material query on S samples around each hit (render_human :602-620)
     float* xs = c->buf<float>("mt_x", (size_t)P * S * 3, &err);
     float* vs = c->buf<float>("mt_v", (size_t)P * S * 3, &err);

@@ -89,6 +89,10 @@ struct ShadowGen {
     int* ray_count;
 };
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s);
+// reorder the hit list so that 64 consecutive hit pixels have neighbouring surface points (radix sort by Morton key)
+size_t sort_hits_temp_bytes(int P);
+int launch_sort_hits(const float* surf, const float* acc, int P, const float* bbox_min, unsigned* keys_in, unsigned* keys_out,
+                     int* vals_in, int* hit_idx_out, void* temp, size_t temp_bytes, hipStream_t s);
 void launch_shadow_scatter(const float* occ, const int* ray_slot, const int* ray_count, int max_rays, float* lvis, hipStream_t s);
 
 struct ShadeIn {

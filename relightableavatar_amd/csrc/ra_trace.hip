@@ -9,6 +9,7 @@
 //              volume_rendering      lib/utils/net_utils.py:970-999
 //              base_renderer         lib/networks/renderer/base_renderer.py:15-113
 #include "ra_kernels.hpp"
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -125,6 +126,32 @@ __global__ void surface_finish_kernel(const float* __restrict__ ro, const float*
     if (hit) hit_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
+__device__ __forceinline__ unsigned expand10t(unsigned v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// sort key of a ray: Morton code of its surface point on a 1/256 m grid inside the box (hit) or
+// 0xffffffff (miss) -> after the sort the first hit_count values are the hit rays in an order where
+// 64 consecutive pixels see neighbouring surface points (coherent waves for the shadow trace).
+__global__ void hit_keys_kernel(const float* __restrict__ surf, const float* __restrict__ acc, int P, float bx, float by, float bz,
+                                unsigned* __restrict__ keys, int* __restrict__ vals) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= P) return;
+    unsigned k = 0xffffffffu;
+    if (acc[i] > 0.f) {
+        const unsigned qx = (unsigned)fminf(fmaxf((surf[3 * i] - bx) * 256.f, 0.f), 1023.f);
+        const unsigned qy = (unsigned)fminf(fmaxf((surf[3 * i + 1] - by) * 256.f, 0.f), 1023.f);
+        const unsigned qz = (unsigned)fminf(fmaxf((surf[3 * i + 2] - bz) * 256.f, 0.f), 1023.f);
+        k = (expand10t(qx) << 2) | (expand10t(qy) << 1) | expand10t(qz);
+    }
+    keys[i] = k;
+    vals[i] = i;
+}
+
 __global__ void surface_samples_kernel(const float* __restrict__ surf, const float* __restrict__ rd, const int* __restrict__ hit_idx,
                                        const int* __restrict__ hit_count, int S, float range, float* __restrict__ x,
                                        float* __restrict__ v, int* __restrict__ n_out) {
@@ -205,13 +232,17 @@ __global__ void shadow_gen_kernel(ShadowGen g) {
     bool trace = false;
     int h = 0, l = 0, r = 0;
     float nr = 0.f, fr = 0.f;
-    if (k < (long long)nh * g.L) {
-        h = (int)(k / g.L);
-        l = (int)(k - (long long)h * g.L);
+    // thread -> (group of 64 hit slots, light, slot in group): a wave = ONE light x 64 neighbouring pixels
+    const long long grp = k / (64LL * g.L);
+    const int rem = (int)(k - grp * 64LL * g.L);
+    l = rem >> 6;
+    h = (int)(grp * 64 + (rem & 63));
+    if (h < nh && l < g.L) {
         r = g.hit_idx[h];
         const float dx = g.ldir[3 * l], dy = g.ldir[3 * l + 1], dz = g.ldir[3 * l + 2];
         const float ldot = dx * g.norm[3 * h] + dy * g.norm[3 * h + 1] + dz * g.norm[3 * h + 2];     // :292
-        g.ldot[k] = ldot;
+        const long long kk = (long long)h * g.L + l;          // output slot: [hit slot][light]
+        g.ldot[kk] = ldot;
         float lv;
         if (g.no_visibility) lv = 1.f;
         else if (g.local_visibility) lv = ldot > 0.f ? 1.f : 0.f;
@@ -236,7 +267,7 @@ __global__ void shadow_gen_kernel(ShadowGen g) {
                 lv = 1.f;           // outside the box: visible (:341); traced rays are overwritten later
             }
         }
-        g.lvis[k] = lv;
+        g.lvis[kk] = lv;
     }
     const unsigned long long m = __ballot(trace);
     if (m == 0ull) return;
@@ -248,7 +279,7 @@ __global__ void shadow_gen_kernel(ShadowGen g) {
         const int s = base + __popcll(m & ((1ull << lane) - 1ull));
         g.ray_pix[s] = r;
         g.ray_light[s] = l;
-        g.ray_slot[s] = (int)k;
+        g.ray_slot[s] = h * g.L + l;
         g.near_[s] = nr;
         g.far_[s] = fr;
     }
@@ -549,7 +580,21 @@ void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s) {
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s) {
     hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
     if (P <= 0) return;
-    hipLaunchKernelGGL(shadow_gen_kernel, grid_for((long long)P * g.L), dim3(TPB), 0, s, g);
+    const long long groups = ((long long)P + 63) / 64;
+    hipLaunchKernelGGL(shadow_gen_kernel, grid_for(groups * 64 * g.L), dim3(TPB), 0, s, g);
+}
+
+size_t sort_hits_temp_bytes(int P) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, P);
+    return bytes;
+}
+
+int launch_sort_hits(const float* surf, const float* acc, int P, const float* bbox_min, unsigned* keys_in, unsigned* keys_out,
+                     int* vals_in, int* hit_idx_out, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(hit_keys_kernel, grid_for(P), dim3(TPB), 0, s, surf, acc, P, bbox_min[0], bbox_min[1], bbox_min[2], keys_in, vals_in);
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, hit_idx_out, P, 0, 32, s) == hipSuccess ? 0 : 1;
 }
 
 void launch_shadow_scatter(const float* occ, const int* ray_slot, const int* ray_count, int max_rays, float* lvis, hipStream_t s) {
