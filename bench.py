@@ -54,7 +54,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--mode', default='relight', choices=['relight', 'sphere_tracing', 'anisdf'])
+    ap.add_argument('--mode', default='relight', choices=['relight', 'sphere_tracing', 'anisdf', 'novel_light'])
+    ap.add_argument('--probes', type=int, default=8, help='novel_light: number of 16x32 probes re-shaded per frame')
     ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -72,18 +73,22 @@ def main():
 
     H = args.size
     cfg = make_cfg(args.mode, mlp_dtype=args.dtype)
-    relight = args.mode == 'relight'
+    relight = args.mode in ('relight', 'novel_light')
     net = make_network(cfg)
     net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
     net = net.to(dev).eval()
     renderer = make_renderer(cfg, net)
-    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True), dev)
+    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0), dev)
     P = base.ray_o.shape[1]
     wb0 = base.wbounds.clone()
     eng = net.engine()
 
     def step():
         base.wbounds.copy_(wb0)     # a fresh batch per frame, as the reference's loader delivers
+        if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
+            out = renderer.render(shard.shard_batch(base, rank, world))
+            rgb = torch.cat([out[n].rgb_map for n in base.novel_lights], dim=-1)
+            return shard.gather_maps(rgb, P, rank, world)
         return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world)
 
     def sync():
@@ -121,7 +126,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'xuzhen_12v_geo_fix_mat-shaped full relight, {H}x{H}, 16x32 light probe, DFSS visibility (4 iters), '
-                                   f'16-iter surface trace, synthetic weights/body' if relight else f'{args.mode} {H}x{H}',
+                                   f'16-iter surface trace, synthetic weights/body' + (f', {args.probes} novel probes re-shaded' if args.mode == 'novel_light' else '') if relight else f'{args.mode} {H}x{H}',
                        'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
                        'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
                        'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'rays round-robin over {world} GPU(s) + all_gather'},

@@ -4,6 +4,7 @@
 #include "ra_ctx.hpp"
 
 #include <cstring>
+#include <cstdlib>
 
 static thread_local std::string g_err;
 void ra_set_error(const std::string& msg) { g_err = msg; }
@@ -199,7 +200,9 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
-        launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+        static const int gen = getenv("RA_MLP_GEN") ? atoi(getenv("RA_MLP_GEN")) : 2;     // 1: first-generation kernel (A/B, fallback)
+        if (gen == 2) launch_mlp_sdf_pipe(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+        else launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
     }
     return 0;
 }

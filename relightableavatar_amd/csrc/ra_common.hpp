@@ -117,6 +117,9 @@ struct FullIO {             // geometry + material / colour forward with tangent
 // f16w: weights/activations are IEEE half (true) or bfloat16 (false); the arena was packed accordingly
 void launch_mlp_sdf(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr,
                     const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
+// second-generation K3 (ra_mlp_pipe.hip): one 8-wave workgroup per CU, epilogue interleaved with the MFMA stream
+void launch_mlp_sdf_pipe(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr,
+                         const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
 void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const void* warena,
                      const float* barena, const FrameState& fr, const FullIO& io, int max_slots, bool f16w, hipStream_t stream);
 

@@ -302,6 +302,40 @@ def test_edge_cases(relight):
     assert s.shape == (1, 1237, 1) and torch.isfinite(s).all()
 
 
+def test_multi_chunk_matches_oracle():
+    """chunkify + the per-chunk in-place bbox growth (quirk 1): 3 chunks on the GPU vs the oracle with the same chunking"""
+    from oracle import ra_oracle as O
+    from relightableavatar_amd.renderer import make_renderer
+    torch.set_num_threads(16)
+    cfg, net, dev = build('relight', render_chunk_size=24)
+    b_cpu = synthetic.make_batch(128, 128, seed=0, posed=True, crop=8)
+    assert b_cpu.ray_o.shape[1] == 64
+    out = make_renderer(cfg, net).render(synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True, crop=8), dev))
+    ref = O.render_sphere_tracing(O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg), b_cpu)
+    # 64 rays / ceil(64/24)=3 chunks -> the box grew three times
+    np.testing.assert_allclose(b_cpu.wbounds.numpy()[0, 1] - synthetic.make_body(0).wbounds.numpy()[0, 1], 0.75, atol=1e-6)
+    assert bool(((out.acc_map.cpu() > 0) == (ref.acc_map > 0)).all())
+    within(out, ref, 'albedo_map', 5e-4, 0.98)
+    within(out, ref, 'shade_map', 2e-2, 0.95)
+    within(out, ref, 'rgb_map', 1e-2, 0.95)
+    assert psnr(out.rgb_map, ref.rgb_map) > 38
+
+
+def test_anisdf_sphere_tracing_vs_oracle_other_pose():
+    """a second body pose / seed than the golden fixtures (identity pose: A = big_A = I, R = I)"""
+    from oracle import ra_oracle as O
+    from relightableavatar_amd.renderer import make_renderer
+    torch.set_num_threads(16)
+    cfg, net, dev = build('sphere_tracing')
+    b_cpu = synthetic.make_batch(96, 96, seed=3, posed=False, crop=16)
+    out = make_renderer(cfg, net).render(synthetic.to_device(synthetic.make_batch(96, 96, seed=3, posed=False, crop=16), dev))
+    ref = O.render_sphere_tracing(O.OracleNet(synthetic.make_state_dict(0, relight=False, cfg=cfg), cfg), b_cpu)
+    assert float(((out.acc_map.cpu() > 0) == (ref.acc_map > 0)).float().mean()) > 0.99
+    within(out, ref, 'rgb_map', 5e-3, 0.97)
+    within(out, ref, 'norm_map', 2e-2, 0.95)
+    assert psnr(out.rgb_map, ref.rgb_map) > 45
+
+
 def test_errors_are_python_exceptions():
     from relightableavatar_amd import _lib
     from relightableavatar_amd.engine import Engine
