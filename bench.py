@@ -131,7 +131,7 @@ def main():
                        'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
                        'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'rays round-robin over {world} GPU(s) + all_gather'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
-                         'traffic': None, 'kernel': 'mlp_sdf_kernel', 'launches': mlp_launches,
+                         'traffic': None, 'kernel': 'mlp_sdf_pipe_kernel' if os.environ.get('RA_MLP_GEN', '2') == '2' else 'mlp_sdf_kernel', 'launches': mlp_launches,
                          'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': F_SDF,
                          'units_per_launch': cnt.n_fine_sdf / max(mlp_launches, 1)},
         }

@@ -29,4 +29,4 @@ void run(int blocks, const char* name) {
     printf("%s: %d blocks x 4 waves, %d accumulators: %.3f ms, %.0f TFLOP/s\n", name, blocks, NACC, ms, flop / ms * 1e-9);
     hipFree(d);
 }
-int main() { run<8>(256, "1 wave/SIMD"); run<8>(512, "2 waves/SIMD"); run<4>(1024, "4 waves/SIMD"); run<8>(512, "2 waves/SIMD (again)"); return 0; }
+int main() { run<8>(256, "1 wave/SIMD"); run<8>(512, "2 waves/SIMD"); run<4>(1024, "4 waves/SIMD"); run<2>(512, "2 waves/SIMD, 2 acc"); run<1>(512, "2 waves/SIMD, 1 acc"); run<2>(256, "1 wave/SIMD, 2 acc"); run<8>(512, "2 waves/SIMD (again)"); return 0; }
