@@ -333,6 +333,24 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     const int S = p->n_samples, C = c->cfg.relight ? 17 : 16, L = c->n_lights;
+    // ---- spatially coherent ray order (per-ray results are order-free; outputs go back through perm)
+    const int* perm = nullptr;
+    if (bbox) {
+        const size_t tb = sort_hits_temp_bytes(P);
+        unsigned* k0 = c->buf<unsigned>("hs_k0", P, &err);
+        unsigned* k1 = c->buf<unsigned>("hs_k1", P, &err);
+        int* v0 = c->buf<int>("hs_v0", P, &err);
+        int* pm_ = c->buf<int>("rs_perm", P, &err);
+        char* tmp = c->buf<char>("hs_tmp", tb + 16, &err);
+        float* so = c->buf<float>("rs_o", (size_t)P * 3, &err);
+        float* sd = c->buf<float>("rs_d", (size_t)P * 3, &err);
+        float* sn = c->buf<float>("rs_n", P, &err);
+        float* sf = c->buf<float>("rs_f", P, &err);
+        if (err) return 1;
+        const float bmin[3] = {bbox[0], bbox[1], bbox[2]};
+        if (launch_sort_rays(ray_o, ray_d, near_, far_, P, bmin, k0, k1, v0, pm_, tmp, tb, so, sd, sn, sf, s)) { ra_set_error("ra_render_sphere_chunk: radix sort failed"); return 1; }
+        ray_o = so; ray_d = sd; near_ = sn; far_ = sf; perm = pm_;
+    }
     // ---- surface trace (HOT LOOP A)
     TraceState ts = alloc_trace(c, "sf_", P, false, &err);
     float* sdf = c->buf<float>("sf_sdf", P, &err);
@@ -437,7 +455,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     auto scat = [&](float* dst, const float* src, int Cc, bool premul, bool src_full) {
         if (!dst) return;
         hipMemsetAsync(dst, 0, (size_t)P * Cc * sizeof(float), s);
-        launch_scatter_maps(hit_idx, hit_count, P, premul ? 1 : 0, acc, src, Cc, dst, src_full ? 1 : 0, s);
+        launch_scatter_maps(hit_idx, hit_count, P, premul ? 1 : 0, acc, src, Cc, dst, src_full ? 1 : 0, perm, s);
     };
     scat(out->acc, acc, 1, false, true);
     scat(out->depth, depth, 1, pm, true);

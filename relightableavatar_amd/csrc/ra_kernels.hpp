@@ -115,7 +115,11 @@ void launch_shade(const ShadeIn& in, const ra_config& cfg, hipStream_t s);
 // scatter hit-slot maps into full-ray outputs (zeros elsewhere), optional premultiplication by acc
 // src_full: src is indexed by ray (like dst) instead of by hit slot
 void launch_scatter_maps(const int* hit_idx, const int* hit_count, int P, int premultiply, const float* acc_full,
-                         const float* src, int C, float* dst, int src_full, hipStream_t s);
+                         const float* src, int C, float* dst, int src_full, const int* perm, hipStream_t s);
+// Morton-sort the primary rays of a chunk by their entry point and gather them into so/sd/sn/sf; perm[i] = caller index of sorted ray i
+int launch_sort_rays(const float* ro, const float* rd, const float* nr, const float* fr, int P, const float* bbox_min, unsigned* keys_in,
+                     unsigned* keys_out, int* vals_in, int* perm, void* temp, size_t temp_bytes, float* so, float* sd, float* sn, float* sf,
+                     hipStream_t s);
 void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s);
 
 // volume path

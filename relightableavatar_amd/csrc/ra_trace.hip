@@ -152,6 +152,32 @@ __global__ void hit_keys_kernel(const float* __restrict__ surf, const float* __r
     vals[i] = i;
 }
 
+// sort key of a primary ray: Morton code of its entry point (o + near d) on a 1/256 m grid inside the box, so that
+// the 64 rays of a wave start (and stay) close together -> compact box sweeps in the coarse level
+__global__ void ray_keys_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr, int P,
+                                float bx, float by, float bz, unsigned* __restrict__ keys, int* __restrict__ vals) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= P) return;
+    const float t = nr[i];
+    const unsigned qx = (unsigned)fminf(fmaxf((ro[3 * i] + t * rd[3 * i] - bx) * 256.f, 0.f), 1023.f);
+    const unsigned qy = (unsigned)fminf(fmaxf((ro[3 * i + 1] + t * rd[3 * i + 1] - by) * 256.f, 0.f), 1023.f);
+    const unsigned qz = (unsigned)fminf(fmaxf((ro[3 * i + 2] + t * rd[3 * i + 2] - bz) * 256.f, 0.f), 1023.f);
+    keys[i] = (expand10t(qx) << 2) | (expand10t(qy) << 1) | expand10t(qz);
+    vals[i] = i;
+}
+
+__global__ void gather_rays_kernel(const int* __restrict__ perm, int P, const float* __restrict__ ro, const float* __restrict__ rd,
+                                   const float* __restrict__ nr, const float* __restrict__ fr, float* __restrict__ so, float* __restrict__ sd,
+                                   float* __restrict__ sn, float* __restrict__ sf) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= P) return;
+    const int r = perm[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { so[3 * i + c] = ro[3 * r + c]; sd[3 * i + c] = rd[3 * r + c]; }
+    sn[i] = nr[r];
+    sf[i] = fr[r];
+}
+
 __global__ void surface_samples_kernel(const float* __restrict__ surf, const float* __restrict__ rd, const int* __restrict__ hit_idx,
                                        const int* __restrict__ hit_count, int S, float range, float* __restrict__ x,
                                        float* __restrict__ v, int* __restrict__ n_out) {
@@ -460,7 +486,7 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
 // ------------------------------------------------------------------------------------------ scatter
 __global__ void scatter_maps_kernel(const int* __restrict__ hit_idx, const int* __restrict__ hit_count, int premultiply,
                                     const float* __restrict__ acc_full, const float* __restrict__ src, int C, float* __restrict__ dst,
-                                    int src_full) {
+                                    int src_full, const int* __restrict__ perm) {
     const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
     const int nh = *hit_count;
     if (k >= (long long)nh * C) return;
@@ -468,7 +494,7 @@ __global__ void scatter_maps_kernel(const int* __restrict__ hit_idx, const int* 
     const int r = hit_idx[h];
     float v = src_full ? src[(size_t)r * C + c] : src[k];
     if (premultiply) v *= acc_full[r];
-    dst[(size_t)r * C + c] = v;
+    dst[(size_t)(perm ? perm[r] : r) * C + c] = v;      // perm: internal (sorted) ray -> caller's ray index
 }
 
 __global__ void gather_rows_kernel(const int* __restrict__ hit_idx, const int* __restrict__ hit_count, const float* __restrict__ src,
@@ -608,9 +634,19 @@ void launch_shade(const ShadeIn& in, const ra_config& cfg, hipStream_t s) {
 }
 
 void launch_scatter_maps(const int* hit_idx, const int* hit_count, int P, int premultiply, const float* acc_full, const float* src,
-                         int C, float* dst, int src_full, hipStream_t s) {
+                         int C, float* dst, int src_full, const int* perm, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(scatter_maps_kernel, grid_for((long long)P * C), dim3(TPB), 0, s, hit_idx, hit_count, premultiply, acc_full, src, C, dst, src_full);
+    hipLaunchKernelGGL(scatter_maps_kernel, grid_for((long long)P * C), dim3(TPB), 0, s, hit_idx, hit_count, premultiply, acc_full, src, C, dst, src_full, perm);
+}
+
+int launch_sort_rays(const float* ro, const float* rd, const float* nr, const float* fr, int P, const float* bbox_min, unsigned* keys_in,
+                     unsigned* keys_out, int* vals_in, int* perm, void* temp, size_t temp_bytes, float* so, float* sd, float* sn, float* sf,
+                     hipStream_t s) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(ray_keys_kernel, grid_for(P), dim3(TPB), 0, s, ro, rd, nr, P, bbox_min[0], bbox_min[1], bbox_min[2], keys_in, vals_in);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, perm, P, 0, 32, s) != hipSuccess) return 1;
+    hipLaunchKernelGGL(gather_rays_kernel, grid_for(P), dim3(TPB), 0, s, perm, P, ro, rd, nr, fr, so, sd, sn, sf);
+    return 0;
 }
 
 void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s) {
