@@ -67,8 +67,10 @@ def main():
         raise SystemExit('bench.py needs MI355X GPUs (the render path has no CPU fallback)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ       # under torchrun the RCCL path runs even at world size 1
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
     H = args.size
@@ -93,7 +95,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -110,13 +112,13 @@ def main():
     dt = time.perf_counter() - t0
     eng.enable_timing(False)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     cnt = eng.counters()
     mlp_ms, mlp_launches = eng.mlp_time()
     cnts = torch.tensor([cnt.n_fine_sdf, cnt.n_fine_full, cnt.n_coarse, cnt.n_hit_pixels, cnt.n_shadow_rays], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(cnts)
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -128,17 +130,18 @@ def main():
             'config': {'workload': f'xuzhen_12v_geo_fix_mat-shaped full relight, {H}x{H}, 16x32 light probe, DFSS visibility (4 iters), '
                                    f'16-iter surface trace, synthetic weights/body' + (f', {args.probes} novel probes re-shaded' if args.mode == 'novel_light' else '') if relight else f'{args.mode} {H}x{H}',
                        'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
-                       'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
+                       'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'full_queries_per_frame': int(cnts[1].item() / args.steps),
+                       'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
                        'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'rays round-robin over {world} GPU(s) + all_gather'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
-                         'traffic': None, 'kernel': 'mlp_sdf_pipe_kernel' if os.environ.get('RA_MLP_GEN', '2') == '2' else 'mlp_sdf_kernel', 'launches': mlp_launches,
+                         'traffic': None, 'kernel': {'1': 'mlp_sdf_kernel', '2': 'mlp_sdf_pipe_kernel'}.get(os.environ.get('RA_MLP_GEN', '3'), 'mlp_sdf_stream_kernel'), 'launches': mlp_launches,
                          'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': F_SDF,
                          'units_per_launch': cnt.n_fine_sdf / max(mlp_launches, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, H)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

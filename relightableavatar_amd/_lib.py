@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librelightableavatar_hip.so')
+LIB_PATH = os.environ.get('RA_LIB_PATH') or os.path.join(_HERE, 'librelightableavatar_hip.so')    # override: kernel experiments (tools/)
 _lib = None
 
 

@@ -55,7 +55,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    DevBuf* bufs[] = {&c->warena, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
+    DevBuf* bufs[] = {&c->warena, &c->sarena, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
                       &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs};
     for (DevBuf* b : bufs) b->release();
@@ -94,6 +94,7 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
     if (ra_pack_weights(c, err)) { ra_set_error("ra_finalize_weights: " + err); return 1; }
     HostNets& H = c->host;
     if (upload(c->warena, H.warena.data(), H.warena.size() * 2, s)) return 1;
+    if (upload(c->sarena, H.sarena.data(), H.sarena.size() * 2, s)) return 1;
     if (upload(c->barena, H.barena.data(), H.barena.size() * 4, s)) return 1;
     if (upload(c->cond_r0, H.cond_r0.data(), H.cond_r0.size() * 4, s)) return 1;
     if (upload(c->cond_r4, H.cond_r4.data(), H.cond_r4.size() * 4, s)) return 1;
@@ -200,8 +201,9 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
-        static const int gen = getenv("RA_MLP_GEN") ? atoi(getenv("RA_MLP_GEN")) : 2;     // 1: first-generation kernel (A/B, fallback)
-        if (gen == 2) launch_mlp_sdf_pipe(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+        static const int gen = getenv("RA_MLP_GEN") ? atoi(getenv("RA_MLP_GEN")) : 3;     // 1, 2: earlier generations (A/B)
+        if (gen == 3) launch_mlp_sdf_stream(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+        else if (gen == 2) launch_mlp_sdf_pipe(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
         else launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
     }
     return 0;

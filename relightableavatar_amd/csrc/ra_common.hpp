@@ -120,6 +120,9 @@ void launch_mlp_sdf(const GeoNet& net, const void* warena, const float* barena, 
 // second-generation K3 (ra_mlp_pipe.hip): one 8-wave workgroup per CU, epilogue interleaved with the MFMA stream
 void launch_mlp_sdf_pipe(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr,
                          const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
+// third-generation K3 (ra_mlp_stream.hip): activations stay in registers, weights stream through LDS (sarena: ra_pack.cpp StreamBuilder)
+void launch_mlp_sdf_stream(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr,
+                           const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
 void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const void* warena,
                      const float* barena, const FrameState& fr, const FullIO& io, int max_slots, bool f16w, hipStream_t stream);
 

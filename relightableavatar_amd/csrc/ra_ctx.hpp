@@ -9,6 +9,7 @@ struct HostNets {
     bool has_color = false;
     float beta = 0.1f;
     std::vector<uint16_t> warena;
+    std::vector<uint16_t> sarena;      // gen-3 K3 weight stream (consumption order, 1952 fragments of 1 KB)
     std::vector<float> barena;
     std::vector<float> cond_r0, b_r0, cond_r4, b_r4, cond_c3, b_c3;   // fp32 cond slices [256][cond]
     std::vector<float> light_xyz, light_area, light_sharp;
@@ -29,7 +30,7 @@ struct ra_ctx {
     std::map<std::string, std::vector<float>> state_dict;
     HostNets host;
     // device copies
-    DevBuf warena, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
+    DevBuf warena, sarena, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
     int n_lights = 0;
     // frame
     FrameState fr{};

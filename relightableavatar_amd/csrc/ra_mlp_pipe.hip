@@ -36,8 +36,13 @@ template <> struct Tr<f16> {
     static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <int ACT>
+#ifndef RA_ABL
+#define RA_ABL 0
+#endif
+
+template <int ACT_>
 __device__ __forceinline__ float act(float z) {
+    constexpr int ACT = (RA_ABL == 1 && ACT_ == ACT_SOFTPLUS) ? ACT_RELU : (RA_ABL == 2 ? ACT_NONE : ACT_);
     if (ACT == ACT_RELU) return fmaxf(z, 0.f);
     if (ACT == ACT_SOFTPLUS) {     // identical expression to ra_mlp.hip act_fn
         const float t = z * 144.26950408889634f;
@@ -155,10 +160,12 @@ __device__ __forceinline__ void step(f32x16 (&accP)[2], const f32x16 (&accE)[2],
             nb0 = *reinterpret_cast<const x8*>(bp + (ks + 1) * 16);
             nb1 = *reinterpret_cast<const x8*>(bp + 32 * XS + (ks + 1) * 16);
         }
+        if (RA_ABL != 5) {
         accP[0] = Tr<E>::mfma(A[ks], b0, accP[0]);
         accP[1] = Tr<E>::mfma(A[ks], b1, accP[1]);
-        if (RELOAD) A[ks] = np[ks * 64];
-        if (EPI && (ks & 1) == 0) {
+        } else { accP[0][ks] += (float)b0[0] * (float)A[ks][0]; accP[1][ks] += (float)b1[0]; }
+        if (RELOAD && RA_ABL != 4) A[ks] = np[ks * 64];
+        if (EPI && RA_ABL != 3 && (ks & 1) == 0) {
             const int g = ks >> 1;
             epi_group<E, ACT>(accE[g >> 2], g & 3, op + (g >> 2) * 32 * XS);
         }

@@ -66,6 +66,52 @@ struct Packer {
     }
 };
 
+// ---- gen-3 K3 weight stream (ra_mlp_stream.hip): fragments in the exact order the kernel consumes them,
+// [layer][row block rb][k-step][lane][8], K indices permuted so that the packed D fragment of one layer IS the
+// B fragment of the next (no LDS round trip for activations):
+//   hidden k-step ks, lane half h, slot j  <->  feature 32*(ks>>1) + 16*(ks&1) + 8*(j>>2) + 4*h + (j&3)
+//   PE k-step (first layers / skip part), q = 8*ks + j  <->  channel chan(q, h) (see pe_chan_*)
+struct StreamBuilder {
+    std::vector<uint16_t> w;
+    bool half = false;
+    uint16_t cv(float v) const { return half ? f2h(v) : f2bf(v); }
+    static int hidden_feature(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+    // rows_pad/32 row blocks; per row block: 16 hidden k-steps of Mh (may be null) then 4 PE k-steps of Mp (may be null)
+    template <typename ChanFn>
+    void add(const Mat* Mh, const Mat* Mp, ChanFn chan, int rows_pad, float pe_scale) {
+        for (int rb = 0; rb < rows_pad / 32; ++rb) {
+            if (Mh)
+                for (int ks = 0; ks < 16; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = rb * 32 + (lane & 31), col = hidden_feature(ks, lane >> 5, j);
+                            w.push_back(cv(row < Mh->rows && col < Mh->cols ? Mh->at(row, col) : 0.f));
+                        }
+            if (Mp)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = rb * 32 + (lane & 31), col = chan(8 * ks + j, lane >> 5);
+                            w.push_back(cv(row < Mp->rows && col >= 0 && col < Mp->cols ? Mp->at(row, col) * pe_scale : 0.f));
+                        }
+        }
+    }
+};
+
+// PE10 (63 channels: x | per frequency sin xyz, cos xyz): slot q < 30 -> frequency q/3, axis q%3, sin (h=0) / cos (h=1)
+int pe_chan_resd(int q, int h) {
+    if (q < 30) return 3 + 6 * (q / 3) + 3 * h + q % 3;
+    if (q == 30) return h ? 1 : 0;
+    return h ? -1 : 2;
+}
+// PE8 + residual ("lo") columns of with_lo(): 0..50 PE, 51..53 lo(x), 54..56 lo(sin f0), 57..59 lo(cos f0)
+int pe_chan_sdf(int q, int h) {
+    if (q < 24) return 3 + 6 * (q / 3) + 3 * h + q % 3;
+    if (q < 27) return h ? 51 + (q - 24) : (q - 24);
+    if (q < 30) return h ? 57 + (q - 27) : 54 + (q - 27);
+    return -1;
+}
+
 Mat slice_cols(const Mat& M, int c0, int c1) {
     Mat o(M.rows, c1 - c0);
     for (int r = 0; r < M.rows; ++r)
@@ -123,6 +169,7 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
     Packer P;
     P.half = c.mlp_f16 != 0;
     HostNets& H = ctx->host;
+    Mat Rm[8], Rpe4, Rhead, Sm[8], Spe4, Shead;     // kept for the gen-3 weight stream
     // ---- residual deformation
     const std::string rp = "residual_deformation_network.mlp.linears.";
     const int in_ch = xyz_dim + cond;
@@ -135,17 +182,22 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         if (!get(sd, rp + std::to_string(i) + ".bias", b) || (int)b.size() != O) { err = "missing/bad " + rp + std::to_string(i) + ".bias"; return 1; }
         if (i == 0) {
             H.geo.r[0] = P.add(slice_cols(W, 0, xyz_dim), b, 256);
+            Rm[0] = slice_cols(W, 0, xyz_dim);
             H.cond_r0 = slice_cols(W, xyz_dim, in_ch).v;
             H.b_r0 = b;
         } else if (i == 4) {
             H.geo.r[4] = P.add(slice_cols(W, 0, 256), b, 256);
             H.geo.r4b = P.add(slice_cols(W, 256, 256 + xyz_dim), std::vector<float>(), 256);
+            Rm[4] = slice_cols(W, 0, 256);
+            Rpe4 = slice_cols(W, 256, 256 + xyz_dim);
             H.cond_r4 = slice_cols(W, 256 + xyz_dim, 256 + in_ch).v;
             H.b_r4 = b;
         } else if (i == 8) {
             H.geo.rhead = P.add(W, b, 32);
+            Rhead = W;
         } else {
             H.geo.r[i] = P.add(W, b, 256);
+            Rm[i] = W;
         }
     }
     // ---- signed distance
@@ -168,16 +220,21 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         };
         if (l == 0) {
             H.geo.s[0] = P.add(with_lo(W), b, 256);
+            Sm[0] = with_lo(W);
         } else if (l == 4) {
             const int nx = 256 - sdf_dim;   // 205
             H.geo.s[4] = P.add(slice_cols(W, 0, nx), b, 256, 256);         // K zero-padded to 256 (cols 205..255 of the tile hold junk)
             H.geo.s4b = P.add(with_lo(slice_cols(W, nx, 256)), std::vector<float>(), 256);
+            Sm[4] = slice_cols(W, 0, nx);
+            Spe4 = with_lo(slice_cols(W, nx, 256));
         } else
         if (l == 8) {
             H.geo.shead = P.add(slice_rows(W, 0, 1), std::vector<float>(b.begin(), b.begin() + 1), 32);
             H.geo.sfeat = P.add(slice_rows(W, 1, 257), std::vector<float>(b.begin() + 1, b.end()), 256);
+            Shead = slice_rows(W, 0, 1);
         } else {
             H.geo.s[l] = P.add(W, b, 256);
+            Sm[l] = W;
         }
     }
     {
@@ -232,6 +289,18 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         H.mat.mhead = P.add(mh, bh, 32);
         if (!get(sd, "light_xyz_", H.light_xyz) || !get(sd, "light_area", H.light_area) || !get(sd, "light_sharp", H.light_sharp)) { err = "missing light_xyz_/light_area/light_sharp"; return 1; }
         if (H.light_xyz.size() != H.light_area.size() * 3 || H.light_area.size() != H.light_sharp.size() || H.light_area.size() > RA_N_LIGHTS_MAX) { err = "bad light buffer shapes"; return 1; }
+    }
+    {   // gen-3 stream: resd L0..L7, head, sdf L0..L7, head.  The softplus layers work in the scaled domain
+        // y' = y * beta*log2(e) (beta = 100): only the layers fed by the unscaled encoding carry the factor.
+        StreamBuilder S;
+        S.half = P.half;
+        const float sp = 144.26950408889634f;
+        for (int i = 0; i < 8; ++i) S.add(i == 0 ? nullptr : &Rm[i], i == 0 ? &Rm[0] : (i == 4 ? &Rpe4 : nullptr), pe_chan_resd, 256, 1.f);
+        S.add(&Rhead, nullptr, pe_chan_resd, 32, 1.f);
+        for (int l = 0; l < 8; ++l) S.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
+        S.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
+        if (S.w.size() != (size_t)1952 * 512) { err = "internal: weight stream has " + std::to_string(S.w.size() / 512) + " fragments, expected 1952"; return 1; }
+        H.sarena = S.w;
     }
     H.warena = P.w;
     H.barena = P.b;

@@ -31,9 +31,10 @@ def shard_batch(batch, rank: int, world: int):
     return out
 
 
-def gather_maps(local: torch.Tensor, P: int, rank: int, world: int, group=None) -> torch.Tensor:
-    """local: (1, P_local, C) or (1, P_local) maps of this rank's rays -> (1, P, C) on every rank."""
-    if world == 1:
+def gather_maps(local: torch.Tensor, P: int, rank: int, world: int, group=None, force_collective=False) -> torch.Tensor:
+    """local: (1, P_local, C) or (1, P_local) maps of this rank's rays -> (1, P, C) on every rank.
+    `force_collective` runs the all_gather even at world size 1 (exercises the RCCL path on a 1-GPU box)."""
+    if world == 1 and not force_collective:
         return local
     squeeze = local.ndim == 2
     x = local[0] if not squeeze else local[0, :, None]

@@ -13,6 +13,8 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
   frames ............................. rgb PSNR >= 40 dB (relight/novel), >= 50 dB (sphere), >= 80 dB (volume)
 bf16 operands are available (cfg.mlp_dtype='bf16'); they are ~10x noisier (sdf mean err 5e-4) and tested loosely.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -345,3 +347,22 @@ def test_errors_are_python_exceptions():
         eng.hdq_sdf(torch.zeros(4, 3, device=dev), 0.1, True)
     with pytest.raises(_lib.RaError, match='missing'):
         eng.load_state_dict({'residual_deformation_network.mlp.linears.0.weight': torch.zeros(256, 219)})
+
+
+@pytest.mark.gpu
+def test_rccl_path_world1_under_torchrun():
+    """the launcher contract of bench.py (torch.distributed.run, nccl == RCCL) at the world size a 1-GPU box allows:
+    process-group init on the device, the frame all_gather, barrier + MAX all_reduce, and the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1']
+    r = subprocess.run(base + ['--master-port', '29631', os.path.join(root, 'tools', 'nccl_world1.py')],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert 'NCCL_WORLD1_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(base + ['--master-port', '29632', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
+                               '--size', '128', '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=600)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['roofline']['achieved'] > 0, r.stdout[-2000:] + r.stderr[-2000:]
