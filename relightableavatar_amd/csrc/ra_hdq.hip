@@ -271,7 +271,7 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
         const int lane = threadIdx.x & 63;
         // one coalesced load per leaf (lane k holds point k; the array is padded with +inf to whole
         // leaves), then 32 register broadcasts: no per-point memory latency
-        auto scan_leaf = [&](int l) {
+        auto scan_leaf = [&](int l) __attribute__((always_inline)) {
             const float4 mine = fr.bvh_pts[l * BVH_LEAF + (lane & (BVH_LEAF - 1))];
             const int mi = __float_as_int(mine.w);
 #pragma unroll
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
                 knn_insert(d, id, d0, d1, d2, i0, i1, i2);
             }
         };
-        auto sdist = [&](int j) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
-        auto ldist = [&](int j) { const float4 lo = lbx[2 * j], hi = lbx[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
+        auto sdist = [&](int j) __attribute__((always_inline)) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
+        auto ldist = [&](int j) __attribute__((always_inline)) { const float4 lo = lbx[2 * j], hi = lbx[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
         // --- seed: nearest super box, then nearest leaf in it, as seen by the first live lane
         int seed;
         {
@@ -371,15 +371,22 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
             for (int k = 0; k < 3; ++k) { out.dbg_sdf_batch[3 * i + k] = sk[k]; out.dbg_nn_batch[3 * i + k] = ik[k]; out.dbg_d2[3 * i + k] = dk[k]; }
         }
     }
-    // compaction: one atomic per wave
+    // compaction: one atomic per workgroup (same-address atomics serialise in L2: per wave they cost as much as the
+    // whole post-processing), wave offsets through LDS
+    __shared__ int wcount[KNN_THREADS / 64 + 1];
     const unsigned long long m = __ballot(fine);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    int wbase = 0;
-    if (lane == 0) wbase = atomicAdd(out.fine_count, __popcll(m));
-    wbase = __shfl(wbase, 0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wcount[wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < KNN_THREADS / 64; ++w) { const int cnt = wcount[w]; wcount[w] = tot; tot += cnt; }
+        wcount[KNN_THREADS / 64] = tot ? atomicAdd(out.fine_count, tot) : 0;
+    }
+    __syncthreads();
     if (!fine) return;
-    const int slot = wbase + __popcll(m & ((1ull << lane) - 1ull));
+    const int slot = wcount[KNN_THREADS / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
     // gaussian-weighted blend of the per-vertex transforms (base_network.py:287-296)
     float w[3], ws = 0.f;
 #pragma unroll
