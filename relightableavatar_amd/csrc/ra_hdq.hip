@@ -201,8 +201,8 @@ __device__ __forceinline__ float box_dist2(const float p[3], float lx, float ly,
 // Pure value selects under one wave-uniform guard: keeps the six state words in VGPRs (a 3-way
 // branchy version made LLVM spill them to scratch behind a computed store address).
 __device__ __forceinline__ void knn_insert(float d, int id, float& d0, float& d1, float& d2, int& i0, int& i1, int& i2) {
+    if (__builtin_expect(__ballot(d <= d2) == 0ull, 1)) return;      // common case: one compare + one scalar branch per candidate
     const bool c2 = d < d2 || (d == d2 && id < i2);
-    if (__ballot(c2) == 0ull) return;
     const bool c1 = d < d1 || (d == d1 && id < i1);
     const bool c0 = d < d0 || (d == d0 && id < i0);
     const float nd2 = c1 ? d1 : (c2 ? d : d2);
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
                 const float vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), k));
                 const float vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), k));
                 const float vz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), k));
-                const int id = __builtin_amdgcn_readlane(mi, k);
                 const float dx = p[0] - vx, dy = p[1] - vy, dz = p[2] - vz;
                 const float d = dx * dx + dy * dy + dz * dz;
-                knn_insert(d, id, d0, d1, d2, i0, i1, i2);
+                if (__builtin_expect(__ballot(d <= d2) != 0ull, 0))          // the vertex id is only needed on the rare insert path
+                    knn_insert(d, __builtin_amdgcn_readlane(mi, k), d0, d1, d2, i0, i1, i2);
             }
         };
         auto sdist = [&](int j) __attribute__((always_inline)) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
         sk[k] = sqrtf(dk[k]) * sgn(dot);
     }
     const float th2 = th * th;
-    {
+    if (!(dbg & 32)) {
         const float* t0 = fr.tverts + 3 * (size_t)ik[0];
 #pragma unroll
         for (int k = 1; k < 3; ++k) {
@@ -382,10 +382,10 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
         int tot = 0;
 #pragma unroll
         for (int w = 0; w < KNN_THREADS / 64; ++w) { const int cnt = wcount[w]; wcount[w] = tot; tot += cnt; }
-        wcount[KNN_THREADS / 64] = tot ? atomicAdd(out.fine_count, tot) : 0;
+        wcount[KNN_THREADS / 64] = (dbg & 8) ? base : (tot ? atomicAdd(out.fine_count, tot) : 0);
     }
     __syncthreads();
-    if (!fine) return;
+    if (!fine || (dbg & 16)) return;
     const int slot = wcount[KNN_THREADS / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
     // gaussian-weighted blend of the per-vertex transforms (base_network.py:287-296)
     float w[3], ws = 0.f;
@@ -463,6 +463,13 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     const float inv2r2 = 1.f / (2.f * blend_radius * blend_radius);
     const dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS);
     static const int dbg = getenv("RA_COARSE_DBG") ? atoi(getenv("RA_COARSE_DBG")) : 0;   // profiling aid: 1 skip the search, 2 skip everything after it
-    if (fr.bvh_leaves > 0) hipLaunchKernelGGL(hdq_coarse_kernel<true>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, dbg);
-    else hipLaunchKernelGGL(hdq_coarse_kernel<false>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, dbg);
+    // profiling aid: an extra launch in ablation mode `probe` on the SAME inputs before every real launch (the real
+    // launch then overwrites its outputs), so that the ablated time can be read from a kernel trace (odd/even calls)
+    static const int probe = getenv("RA_COARSE_PROBE") ? atoi(getenv("RA_COARSE_PROBE")) : 0;
+    for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
+        const int d = pass == 0 ? probe : dbg;
+        if (fr.bvh_leaves > 0) hipLaunchKernelGGL(hdq_coarse_kernel<true>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
+        else hipLaunchKernelGGL(hdq_coarse_kernel<false>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
+        if (pass == 0) hipMemsetAsync(out.fine_count, 0, sizeof(int), s);
+    }
 }
