@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--probes', type=int, default=8, help='novel_light: number of 16x32 probes re-shaded per frame')
     ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--emulate-world', type=int, default=0, help='tuning aid: render only rank 0\'s shard of an N-rank job on one GPU (no collective); value is then NOT a whole-job rate')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -90,7 +91,9 @@ def main():
         if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
             out = renderer.render(shard.shard_batch(base, rank, world))
             rgb = torch.cat([out[n].rgb_map for n in base.novel_lights], dim=-1)
-            return shard.gather_maps(rgb, P, rank, world)
+            return shard.gather_maps(rgb, P, rank, world, batch=base)
+        if args.emulate_world > 1:
+            return renderer.render(shard.shard_batch(base, 0, args.emulate_world))
         return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world)
 
     def sync():

@@ -231,17 +231,22 @@ __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
     }
 }
 
-template <bool BVH>
+// SPLIT > 1 (small launches, < 1 wave per SIMD: the serial sweep of one wave IS the launch time): the SPLIT waves of a
+// workgroup serve the SAME 64 queries and share out the opened super boxes; their three-bests are merged through LDS.
+// Each wave prunes against its own (weaker) bound, which is still conservative, so the merged result is exact.
+template <bool BVH, int SPLIT>
 __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
                                                                   HdqOut out, int dbg) {
+    static_assert(SPLIT == 1 || (BVH && SPLIT == KNN_THREADS / 64), "SPLIT is all waves of the workgroup or none");
     // BVH: super + leaf boxes (2 float4 each); brute force: a vertex tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? (BVH_MAXS + BVH_MAXL) * 32 : VT * 16];
     const int n = rs.n_dev ? min(*rs.n_dev, n_launch) : n_launch;
-    const int base = blockIdx.x * KNN_THREADS;
+    const int base = blockIdx.x * (SPLIT == 1 ? KNN_THREADS : 64);
     if (base >= n) return;               // whole block idle (uniform)
     if (blockIdx.x == 0 && threadIdx.x == 0 && out.counters) atomicAdd(&out.counters->n_coarse, (unsigned long long)n);
-    const int i = base + threadIdx.x;
-    const bool live = i < n;
+    const int i = base + (SPLIT == 1 ? threadIdx.x : (threadIdx.x & 63));
+    const bool live_q = i < n;
+    bool live = live_q;
     float x[3] = {0.f, 0.f, 0.f};
     if (live) ray_point(rs, i, x);
     // world -> pose: (x - Th) R   (blend_utils.py:252-261)
@@ -306,9 +311,11 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
         unsigned long long open = 0ull;
         for (int j = 0; j < ns; ++j)
             if (__ballot(sdist(j) * 0.99999f <= d2) != 0ull) open |= 1ull << j;
+        int ord = 0;
         while (open) {
             const int sidx = __ffsll((long long)open) - 1;
             open &= open - 1ull;
+            if (SPLIT > 1 && (ord++ % SPLIT) != (int)(threadIdx.x >> 6)) continue;
             ++n_open;
             const int l1 = min(nl, (sidx + 1) * BVH_FAN);
             for (int l = sidx * BVH_FAN; l < l1; ++l) {
@@ -316,6 +323,29 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
                 if (__ballot(ldist(l) * 0.99999f <= d2) == 0ull) continue;
                 scan_leaf(l);
                 ++n_scan;
+            }
+        }
+        if (SPLIT > 1) {
+            __shared__ float md[KNN_THREADS / 64 - 1][3][64];
+            __shared__ int mi[KNN_THREADS / 64 - 1][3][64];
+            const int wv = threadIdx.x >> 6;
+            if (wv > 0) {
+                md[wv - 1][0][lane] = d0; md[wv - 1][1][lane] = d1; md[wv - 1][2][lane] = d2;
+                mi[wv - 1][0][lane] = i0; mi[wv - 1][1][lane] = i1; mi[wv - 1][2][lane] = i2;
+            }
+            __syncthreads();
+            if (wv == 0) {
+#pragma unroll
+                for (int w = 0; w < KNN_THREADS / 64 - 1; ++w)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        // every wave scanned the seed leaf (for its bound): a vertex may come back more than once
+                        const int id = mi[w][k][lane];
+                        const bool dup = id == i0 || id == i1 || id == i2;
+                        knn_insert(dup ? 3.4e38f : md[w][k][lane], id, d0, d1, d2, i0, i1, i2);
+                    }
+            } else {
+                live = false;           // waves 1.. only helped with the search
             }
         }
         if ((dbg & 4) && out.counters && lane == 0) {
@@ -466,10 +496,14 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     // profiling aid: an extra launch in ablation mode `probe` on the SAME inputs before every real launch (the real
     // launch then overwrites its outputs), so that the ablated time can be read from a kernel trace (odd/even calls)
     static const int probe = getenv("RA_COARSE_PROBE") ? atoi(getenv("RA_COARSE_PROBE")) : 0;
+    // launches below ~1.5 waves per SIMD are latency-bound: spread each group of 64 queries over the 4 waves of a workgroup
+    static const int split_max = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 98304;
     for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
         const int d = pass == 0 ? probe : dbg;
-        if (fr.bvh_leaves > 0) hipLaunchKernelGGL(hdq_coarse_kernel<true>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
-        else hipLaunchKernelGGL(hdq_coarse_kernel<false>, grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
+        if (fr.bvh_leaves > 0 && n <= split_max)
+            hipLaunchKernelGGL((hdq_coarse_kernel<true, KNN_THREADS / 64>), dim3((n + 63) / 64), dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
+        else if (fr.bvh_leaves > 0) hipLaunchKernelGGL((hdq_coarse_kernel<true, 1>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
+        else hipLaunchKernelGGL((hdq_coarse_kernel<false, 1>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
         if (pass == 0) hipMemsetAsync(out.fine_count, 0, sizeof(int), s);
     }
 }

@@ -1,10 +1,15 @@
 """Ray sharding across the GPUs of one node + the one exchange step of the path.
 
 Rays are independent units (no cross-ray reduction anywhere in the path), but their cost varies
-~1000x between a miss and a hit pixel and hits are spatially clustered, so rays are dealt to ranks
-round-robin (ray i -> rank i % world).  Every rank renders its shard with the single-GPU pipeline;
-one all_gather of fixed-size shards (RCCL over xGMI; `nccl` backend on ROCm) assembles the frame on
-every rank.  The reference has no multi-GPU inference (run.py is single-process); this is new.
+~1000x between a miss and a hit pixel and hits are spatially clustered, so pixels are dealt to ranks
+in small tiles, round-robin: 8x8 pixel tiles when the batch carries `mask_at_box` + `meta.H/W`
+(the in-box rays are the mask's pixels in row-major order), runs of 64 consecutive rays otherwise.
+Tiles — not single pixels — because the coarse level of the distance query sweeps its vertex boxes
+per wave of 64 neighbouring rays: a rank that owned every N-th pixel would spread each wave over an
+N times larger image area and lose most of the pruning (measured: 6.4 ms instead of 1.3 ms of
+coarse-level time per frame for a 1/8 shard).  Every rank renders its shard with the single-GPU
+pipeline; one all_gather of fixed-size shards (RCCL over xGMI; `nccl` backend on ROCm) assembles the
+frame on every rank.  The reference has no multi-GPU inference (run.py is single-process); this is new.
 """
 import torch
 import torch.distributed as dist
@@ -12,10 +17,56 @@ import torch.distributed as dist
 from .base_utils import dotdict
 
 RAY_KEYS = ('ray_o', 'ray_d', 'near', 'far')
+TILE = 8          # pixels per tile side
+RUN = 64          # rays per run when pixel coordinates are unknown
 
 
-def shard_indices(P: int, rank: int, world: int) -> torch.Tensor:
-    return torch.arange(rank, P, world)
+_PLANS = {}
+
+
+def _owner(P: int, world: int, batch, device) -> torch.Tensor:
+    mask = None if batch is None else batch.get('mask_at_box', None)
+    meta = None if batch is None else batch.get('meta', None)
+    if mask is not None and meta is not None and 'H' in meta and 'W' in meta:
+        H, W = int(torch.as_tensor(meta['H']).reshape(-1)[0]), int(torch.as_tensor(meta['W']).reshape(-1)[0])
+        m = mask.reshape(-1).to(device)
+        if m.numel() == H * W:
+            pix = m.nonzero()[:, 0]
+            if pix.numel() == P:
+                ty, tx = (pix // W) // TILE, (pix % W) // TILE
+                return (ty + tx) % world      # diagonal stripes: horizontally AND vertically adjacent tiles differ
+    return (torch.arange(P, device=device) // RUN) % world
+
+
+def plan(P: int, world: int, batch=None, device=None) -> dotdict:
+    """who owns which ray, and the index vectors of the exchange (identical on all ranks; cached per mask buffer)."""
+    device = torch.device('cpu') if device is None else torch.device(device)
+    mask = None if batch is None else batch.get('mask_at_box', None)
+    key = (P, world, str(device), None if mask is None else (mask.data_ptr(), mask._version))
+    pl = _PLANS.get(key)
+    if pl is not None:
+        return pl
+    owner = _owner(P, world, batch, device)
+    counts = torch.bincount(owner, minlength=world)
+    n_max = int(counts.max()) if P else 0
+    order = torch.argsort(owner, stable=True)                 # rays grouped by owner, original order inside
+    starts = torch.cumsum(counts, 0) - counts
+    slot = torch.arange(P, device=device) - starts[owner[order]]
+    pl = dotdict(owner=owner, counts=counts, n_max=n_max, order=order, src=owner[order] * n_max + slot,
+                 idx=[order[int(starts[r]):int(starts[r]) + int(counts[r])] for r in range(world)])
+    if len(_PLANS) > 16:
+        _PLANS.clear()
+    _PLANS[key] = pl
+    return pl
+
+
+def ray_owner(P: int, world: int, batch=None) -> torch.Tensor:
+    """(P,) int64: owning rank of every in-box ray."""
+    return plan(P, world, batch).owner
+
+
+def shard_indices(P: int, rank: int, world: int, batch=None, device=None) -> torch.Tensor:
+    return plan(P, world, batch, device).idx[rank]
 
 
 def shard_batch(batch, rank: int, world: int):
@@ -23,7 +74,7 @@ def shard_batch(batch, rank: int, world: int):
     if world == 1:
         return batch
     P = batch.ray_o.shape[1]
-    idx = shard_indices(P, rank, world).to(batch.ray_o.device)
+    idx = shard_indices(P, rank, world, batch, batch.ray_o.device)
     out = dotdict(batch)
     for k in RAY_KEYS:
         out[k] = batch[k][:, idx].contiguous()
@@ -31,20 +82,20 @@ def shard_batch(batch, rank: int, world: int):
     return out
 
 
-def gather_maps(local: torch.Tensor, P: int, rank: int, world: int, group=None, force_collective=False) -> torch.Tensor:
+def gather_maps(local: torch.Tensor, P: int, rank: int, world: int, group=None, force_collective=False, batch=None) -> torch.Tensor:
     """local: (1, P_local, C) or (1, P_local) maps of this rank's rays -> (1, P, C) on every rank.
     `force_collective` runs the all_gather even at world size 1 (exercises the RCCL path on a 1-GPU box)."""
     if world == 1 and not force_collective:
         return local
     squeeze = local.ndim == 2
     x = local[0] if not squeeze else local[0, :, None]
-    n_max = (P + world - 1) // world
-    buf = x.new_zeros(n_max, x.shape[-1])
+    pl = plan(P, world, batch, x.device)
+    buf = x.new_zeros(pl.n_max, x.shape[-1])
     buf[:x.shape[0]] = x
-    out = x.new_empty(world * n_max, x.shape[-1])
+    out = x.new_empty(world * pl.n_max, x.shape[-1])
     dist.all_gather_into_tensor(out, buf, group=group)
-    # rank r, slot j  ->  ray j * world + r
-    full = out.view(world, n_max, -1).permute(1, 0, 2).reshape(world * n_max, -1)[:P]
+    full = x.new_empty(P, x.shape[-1])
+    full[pl.order] = out[pl.src]             # rank r, slot j  ->  the j-th ray owned by r
     full = full[None]
     return full[..., 0] if squeeze else full
 
@@ -59,7 +110,7 @@ def render_sharded(renderer, batch, keys=('rgb_map', 'acc_map'), rank=None, worl
         return dotdict({k: out[k] for k in keys})
     parts = [out[k] if out[k].ndim == 3 else out[k][..., None] for k in keys]
     widths = [p.shape[-1] for p in parts]
-    packed = gather_maps(torch.cat(parts, dim=-1), P, rank, world, group)
+    packed = gather_maps(torch.cat(parts, dim=-1), P, rank, world, group, batch=batch)
     res, c = dotdict(), 0
     for k, w, p in zip(keys, widths, parts):
         v = packed[..., c:c + w]

@@ -109,15 +109,17 @@ def test_bvh_equals_brute_force(relight):
     _, _, dev, body, eng = relight
     g = torch.Generator().manual_seed(7)
     x = ((torch.rand(100000, 3, generator=g) - 0.5) * 3.0).to(dev)
-    a = eng.debug_hdq(x, 0.125)
-    eng.set_knn_mode(False)
-    eng.set_frame(body, force=True)
-    b = eng.debug_hdq(x, 0.125)
-    eng.set_knn_mode(True)
-    eng.set_frame(body, force=True)
-    assert int((a.nn_batch != b.nn_batch).sum()) == 0
-    assert float((a.sdf_coarse - b.sdf_coarse).abs().max()) == 0.0
-    assert a.fine_count == b.fine_count
+    # 100 000 queries: one wave per 64 queries; 40 000: the small-launch variant (4 waves share 64 queries and merge)
+    for n in (100000, 40000):
+        a = eng.debug_hdq(x[:n].contiguous(), 0.125)
+        eng.set_knn_mode(False)
+        eng.set_frame(body, force=True)
+        b = eng.debug_hdq(x[:n].contiguous(), 0.125)
+        eng.set_knn_mode(True)
+        eng.set_frame(body, force=True)
+        assert int((a.nn_batch != b.nn_batch).sum()) == 0
+        assert float((a.sdf_coarse - b.sdf_coarse).abs().max()) == 0.0
+        assert a.fine_count == b.fine_count
 
 
 def test_hdq_sdf(ops, relight):
@@ -270,14 +272,15 @@ def test_full_size_properties():
     base.wbounds.copy_(wb0)
     out2 = rend.render(base)
     assert float((out2.rgb_map - rgb).abs().max()) == 0.0
-    # rays are independent: rendering two interleaved shards and merging gives the same image
+    # rays are independent: rendering the two tile-interleaved shards of a 2-rank job and merging gives the same image
     parts = []
     for r in range(2):
         base.wbounds.copy_(wb0)
         parts.append(rend.render(shard.shard_batch(base, r, 2)).rgb_map[0])
     P = rgb.shape[1]
     merged = torch.zeros_like(rgb[0])
-    merged[0::2], merged[1::2] = parts[0], parts[1]
+    for r in range(2):
+        merged[shard.shard_indices(P, r, 2, base, merged.device)] = parts[r]
     assert float((merged - rgb[0]).abs().max()) == 0.0
     c = net.engine().counters()
     assert c.n_fine_sdf > 100 * c.n_hit_pixels                                 # ~1000 fine queries per hit pixel

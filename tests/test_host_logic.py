@@ -93,7 +93,34 @@ def test_shard_roundtrip_single_process():
     assert sorted(torch.cat(idx).tolist()) == list(range(P))
     b = synthetic.make_batch(32, 32, seed=0)
     s0 = shard.shard_batch(b, 0, 2)
-    assert s0.ray_o.shape[1] == (b.ray_o.shape[1] + 1) // 2 and s0.wbounds is not b.wbounds
+    assert abs(s0.ray_o.shape[1] - b.ray_o.shape[1] / 2) <= 64 and s0.wbounds is not b.wbounds
+
+
+def test_shard_tiles_partition_the_frame():
+    """pixels are dealt to ranks in 8x8 tiles (waves of 64 neighbouring rays stay compact on every rank); the
+    shards partition the in-box rays and are balanced"""
+    b = synthetic.make_batch(128, 128, seed=0)
+    P = b.ray_o.shape[1]
+    H = W = 128
+    for world in (2, 4, 8):
+        owner = shard.ray_owner(P, world, b)
+        pix = b.mask_at_box.reshape(-1).nonzero()[:, 0]
+        tile = ((pix // W) // shard.TILE) * (W // shard.TILE) + (pix % W) // shard.TILE
+        for t in tile.unique()[:50].tolist():
+            assert owner[tile == t].unique().numel() == 1            # a tile never straddles ranks
+        idx = [shard.shard_indices(P, r, world, b) for r in range(world)]
+        assert sorted(torch.cat(idx).tolist()) == list(range(P))
+        sizes = torch.tensor([i.numel() for i in idx], dtype=torch.float32)
+        assert float(sizes.max() / sizes.mean()) < 1.25
+        x = torch.rand(1, P, 3)
+        parts = [x[:, i] for i in idx]                               # what each rank would hold
+        pl = shard.plan(P, world, b)
+        stacked = torch.zeros(world * pl.n_max, 3)
+        for r in range(world):
+            stacked[r * pl.n_max:r * pl.n_max + parts[r].shape[1]] = parts[r][0]
+        full = torch.empty(P, 3)
+        full[pl.order] = stacked[pl.src]
+        assert torch.equal(full, x[0])                               # the exchange's index vectors invert the sharding
 
 
 WORKER = r'''
