@@ -43,8 +43,7 @@ constexpr int ACT_RELU = 1, ACT_SOFTPLUS = 2;
 constexpr float INV_2PI = 0.15915494309189535f;
 constexpr float SP_SCALE = 144.26950408889634f;     // beta * log2(e), beta = 100 (net_utils.py:1298)
 constexpr float SP_INV = 0.0069314718055994531f;    // ln(2) / beta
-constexpr int ST_THREADS = 512;
-constexpr int ST_TM = 256;                          // points per workgroup tile (8 waves x 32)
+constexpr int ST_MAXW = 8;                          // waves per workgroup: 8 (tile = 256 points), or 4 / 2 for small launches
 constexpr int ST_RING = 8;                          // ring stages
 constexpr int ST_STAGE_BYTES = 16384;               // 16 fragments of 1 KB
 constexpr int ST_FRAGS = 1952;                      // fragments per tile
@@ -105,14 +104,16 @@ __device__ __forceinline__ void glds16x2(const char* sbase, unsigned voff, unsig
                  : "=&s"(keep) : "v"(voff), "v"(voff2), "s"(sbase), "s"(lds_dst) : "memory", "scc");
 }
 
-// the weight stream as seen by one wave
-template <typename E>
+// the weight stream as seen by one wave of an NW-wave workgroup (each wave moves 16 / NW fragments of every stage)
+template <typename E, int NW>
 struct Pipe {
+    static constexpr int FPW = 16 / NW;
     const char* g;          // weight stream (uniform)
-    unsigned voff;          // per lane: wave * 2048 + lane * 16
+    unsigned voff;          // per lane: wave * FPW * 1024 + lane * 16
     const char* ring;       // LDS ring (generic pointer), + lane * 16
-    unsigned ring_addr;     // LDS byte address of the ring + wave * 2048 (wave-uniform)
+    unsigned ring_addr;     // LDS byte address of the ring + wave * FPW * 1024 (wave-uniform)
     unsigned slot;          // ring slot of the stage being read (wave-uniform)
+    int sstage;             // its position in the tile's stream, 0 .. ST_STAGES-1 (wave-uniform)
     const char* rd;         // ring + slot * 16 KB + lane * 16
     typename Tr<E>::x8 af[ST_PF];
 
@@ -120,23 +121,30 @@ struct Pipe {
         const char* sb = g;
         asm volatile("" : "+s"(sb));            // keeps the 244 per-stage addresses from being precomputed (and spilled)
         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + ring_slot * ST_STAGE_BYTES);
-        if (RA_ABL != 5 && RA_ABL != 6) glds16x2(sb + (size_t)(RA_ABL == 7 ? (stream_stage & 1) : stream_stage) * ST_STAGE_BYTES, voff, voff + 1024, dst);
+        const char* src = sb + (size_t)(RA_ABL == 7 ? (stream_stage & 1) : stream_stage) * ST_STAGE_BYTES;
+        if (RA_ABL != 5 && RA_ABL != 6) {
+#pragma unroll
+            for (int j = 0; j < FPW / 2; ++j) glds16x2(src, voff + j * 2048, voff + j * 2048 + 1024, dst + j * 2048);
+        }
     }
-    // stage `st` of the tile becomes readable; the slot of stage st-1 is refilled with stage st+7
-    template <int ST>
+    // the next stage of the stream becomes readable; the ring slot two stages back is refilled ST_AHEAD stages ahead.
+    // The stage position is run-time state (SGPRs), so the code below only depends on a fragment's position in its stage.
     __device__ __forceinline__ void sync_stage() {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (ST_AHEAD - 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1)) : "memory");
         if (RA_ABL != 4 && RA_ABL != 6) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ST > 0) slot = (slot + 1) & (ST_RING - 1);
-        issue((ST + ST_AHEAD) % ST_STAGES, (slot + ST_AHEAD) & (ST_RING - 1));
+        slot = (slot + 1) & (ST_RING - 1);
+        sstage = sstage + 1 == ST_STAGES ? 0 : sstage + 1;
+        int ahead = sstage + ST_AHEAD;
+        ahead = ahead >= ST_STAGES ? ahead - ST_STAGES : ahead;
+        issue(ahead, (slot + ST_AHEAD) & (ST_RING - 1));
         rd = ring + slot * ST_STAGE_BYTES;
     }
-    template <int F>
+    // FM: position of the fragment in its 16-fragment stage
+    template <int FM>
     __device__ __forceinline__ void fetch() {
-        if (F >= ST_FRAGS) return;
-        if (F % 16 == 0) sync_stage<F / 16>();
-        af[F % ST_PF] = *reinterpret_cast<const typename Tr<E>::x8*>(rd + (F % 16) * 1024);
+        if (FM == 0) sync_stage();
+        af[FM % ST_PF] = *reinterpret_cast<const typename Tr<E>::x8*>(rd + FM * 1024);
     }
 };
 
@@ -155,16 +163,16 @@ __device__ __forceinline__ void init_acc(f32x16& acc, const float* bias_rb, int 
 // One row block: KS MFMAs (fragments F0.. of the tile's stream) into `acc`, interleaved with the pending epilogue
 // of `accPrev` (activation ACT_PREV) into the B fragments o0, o1.  Bm: hidden-part B fragments (KS >= 16),
 // Bp: encoding B fragments (KS == 4 or the last 4 k-steps of KS == 20).
-template <typename E, int F0, int KS, int ACT_PREV, bool PENDING, bool EARLY>
-__device__ __forceinline__ void row_block(Pipe<E>& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4],
+template <typename E, int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL>
+__device__ __forceinline__ void row_block(Pipe<E, NW>& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4],
                                           u32x4& o0, u32x4& o1, const float* bias_rb, int h) {
     init_acc(acc, bias_rb, h);
     float ta[16], tb[16];
     static_for<0, KS>([&](auto ks_) {
         constexpr int ks = decltype(ks_)::value;
         const u32x4 bw = (KS == 4) ? Bp[ks & 3] : (ks < 16 ? Bm[ks & 15] : Bp[ks & 3]);
-        acc = Tr<E>::mfma(P.af[(F0 + ks) % ST_PF], __builtin_bit_cast(X8<E>, bw), acc);
-        P.template fetch<F0 + ks + ST_PF>();
+        acc = Tr<E>::mfma(P.af[(FM0 + ks) % ST_PF], __builtin_bit_cast(X8<E>, bw), acc);
+        if constexpr (!(TAIL && ks + ST_PF >= KS)) P.template fetch<(FM0 + ks + ST_PF) % 16>();
         if constexpr (PENDING) {
             // Pending row block, element by element.  The softplus chain exp2 -> +1 -> log2 -> +max is software-pipelined
             // over four MFMA slots so that no VALU op waits on one issued in the same slot (in-order issue: a stalled
@@ -201,17 +209,17 @@ __device__ __forceinline__ void row_block(Pipe<E>& P, f32x16& acc, const f32x16&
 
 // a 256-row layer: 8 row blocks; on entry `accB` holds the pending last row block of the previous layer (if PEND_IN,
 // activation ACT_IN, destination Bm[14], Bm[15]); on exit accB holds this layer's pending row block 7.
-template <typename E, int F0, int KS, int ACT, int ACT_IN, bool PEND_IN>
-__device__ __forceinline__ void layer(Pipe<E>& P, f32x16& accA, f32x16& accB, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16],
+template <typename E, int NW, int KS, int ACT, int ACT_IN, bool PEND_IN>
+__device__ __forceinline__ void layer(Pipe<E, NW>& P, f32x16& accA, f32x16& accB, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16],
                                       const float* bias, int h) {
-    row_block<E, F0 + 0 * KS, KS, ACT_IN, PEND_IN, true>(P, accA, accB, Bm, Bp, Bm[14], Bm[15], bias, h);
-    row_block<E, F0 + 1 * KS, KS, ACT, true, false>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], bias + 32, h);
-    row_block<E, F0 + 2 * KS, KS, ACT, true, false>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], bias + 64, h);
-    row_block<E, F0 + 3 * KS, KS, ACT, true, false>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], bias + 96, h);
-    row_block<E, F0 + 4 * KS, KS, ACT, true, false>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], bias + 128, h);
-    row_block<E, F0 + 5 * KS, KS, ACT, true, false>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], bias + 160, h);
-    row_block<E, F0 + 6 * KS, KS, ACT, true, false>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], bias + 192, h);
-    row_block<E, F0 + 7 * KS, KS, ACT, true, false>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], bias + 224, h);
+    row_block<E, NW, 0, KS, ACT_IN, PEND_IN, true, false>(P, accA, accB, Bm, Bp, Bm[14], Bm[15], bias, h);
+    row_block<E, NW, (1 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], bias + 32, h);
+    row_block<E, NW, (2 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], bias + 64, h);
+    row_block<E, NW, (3 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], bias + 96, h);
+    row_block<E, NW, (4 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], bias + 128, h);
+    row_block<E, NW, (5 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], bias + 160, h);
+    row_block<E, NW, (6 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], bias + 192, h);
+    row_block<E, NW, (7 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], bias + 224, h);
 }
 
 // encoding B fragments of one point (lane half h): see pe_chan_resd / pe_chan_sdf in ra_pack.cpp
@@ -249,32 +257,33 @@ __device__ __forceinline__ void pe_frags(u32x4 (&Bp)[4], const float (&x)[3], in
 }
 
 // one network: L0 (encoding) .. L7, then the <= 32-row head; returns the head accumulator (bias included)
-template <typename E, int F0, int ACT, int PEL, bool LO>
-__device__ __forceinline__ f32x16 run_net(Pipe<E>& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h) {
+template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO>
+__device__ __forceinline__ f32x16 run_net(Pipe<E, NW>& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h) {
     u32x4 B0[16], B1[16], Bp[4];
     f32x16 accA, accB;
     pe_frags<E, PEL, LO>(Bp, x, h);
-    constexpr int F1 = F0 + 32, F4 = F1 + 3 * 128, F5 = F4 + 160, FH = F5 + 3 * 128;
-    layer<E, F0, 4, ACT, ACT, false>(P, accA, accB, B0 /* unused */, Bp, B0, bias, h);
-    layer<E, F1, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 256, h);
-    layer<E, F1 + 128, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 512, h);
-    layer<E, F1 + 256, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 768, h);
-    layer<E, F4, 20, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1024, h);
-    layer<E, F5, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1280, h);
-    layer<E, F5 + 128, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1536, h);
-    layer<E, F5 + 256, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1792, h);
-    row_block<E, FH, 16, ACT, true, true>(P, accA, accB, B1, Bp, B1[14], B1[15], bias + 2048, h);
+    // every layer starts on a stage boundary (32, 128, 160 and 16 fragments are multiples of 16)
+    layer<E, NW, 4, ACT, ACT, false>(P, accA, accB, B0 /* unused */, Bp, B0, bias, h);
+    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 256, h);
+    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 512, h);
+    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 768, h);
+    layer<E, NW, 20, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1024, h);
+    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1280, h);
+    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1536, h);
+    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1792, h);
+    row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accA, accB, B1, Bp, B1[14], B1[15], bias + 2048, h);
     return accA;
 }
 
-template <typename E>
-__global__ __launch_bounds__(ST_THREADS, 2) void mlp_sdf_stream_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba,
+template <typename E, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba,
                                                                       FrameState fr, MlpIO io) {
     __shared__ __attribute__((aligned(16))) StSmem<E> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     // bias table: resd rows (L0 / L4 carry the per-frame pose condition), resd head, scaled sdf rows, sdf head
-    for (int i = tid; i < BIAS_ROWS * 256; i += ST_THREADS) {
+    constexpr int ST_TM = 32 * NW;     // points per workgroup tile
+    for (int i = tid; i < BIAS_ROWS * 256; i += 64 * NW) {
         const int row = i >> 8, r = i & 255;
         float v = 0.f;
         if (row < 8) v = row == 0 ? fr.bias_r0[r] : (row == 4 ? fr.bias_r4[r] : ba[net.r[row].bias + r]);
@@ -290,12 +299,13 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_sdf_stream_kernel(GeoNet ne
     const int ntiles = (count + ST_TM - 1) / ST_TM;
     if ((int)blockIdx.x >= ntiles) return;
 
-    Pipe<E> P;
+    Pipe<E, NW> P;
     P.g = reinterpret_cast<const char*>(stream);
-    P.voff = wave * 2048 + lane * 16;
+    P.voff = wave * (16 / NW) * 1024 + lane * 16;
     P.ring = reinterpret_cast<const char*>(sm.ring) + lane * 16;
-    P.ring_addr = (unsigned)(size_t)sm.ring + wave * 2048;
-    P.slot = 0;
+    P.ring_addr = (unsigned)(size_t)sm.ring + wave * (16 / NW) * 1024;
+    P.slot = ST_RING - 1;            // the first sync_stage() advances to slot 0 / stream stage 0
+    P.sstage = ST_STAGES - 1;
     P.rd = P.ring;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_sdf_stream_kernel(GeoNet ne
         // the first ST_PF fragments of the tile (stage 0 of the stream)
         P.template fetch<0>(); P.template fetch<1>(); P.template fetch<2>(); P.template fetch<3>();
         // ---- residual deformation net (ReLU); head: resd = tanh(z) * resd_limit, cpts = bpts + resd
-        const f32x16 hr = run_net<E, 0, ACT_RELU, 10, false>(P, x, sm.bias, h);
+        const f32x16 hr = run_net<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h);
         float cp[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_sdf_stream_kernel(GeoNet ne
             cp[k] = x[k] + __shfl(r, c);
         }
         // ---- signed distance net (softplus, scaled domain); head row 0 = sdf
-        const f32x16 hs = run_net<E, ST_FRAGS / 2, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h);
+        const f32x16 hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h);
         if (h == 0 && s < count) {
             float d = hs[0] * SP_INV;                                 // head accumulates beta*log2(e) * sdf
             if (io.smooth) {                                          // HDQ blend (base_network.py:374-382)
@@ -331,7 +341,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_sdf_stream_kernel(GeoNet ne
             }
             io.sdf[pidx] = d;
         }
-        P.slot = (P.slot + 1) & (ST_RING - 1);      // the next tile's stage 0 follows this tile's stage 121
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -340,11 +349,25 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_sdf_stream_kernel(GeoNet ne
 
 }  // namespace
 
+template <int NW>
+static void launch_nw(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io,
+                      int max_slots, bool f16w, hipStream_t stream) {
+    const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
+    const int grid = tiles < 256 ? tiles : 256;     // one workgroup per CU (the weight ring fills its LDS), persistent over tiles
+    if (f16w) hipLaunchKernelGGL((mlp_sdf_stream_kernel<f16, NW>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena, barena, fr, io);
+    else if (NW == 8) hipLaunchKernelGGL((mlp_sdf_stream_kernel<bf16, 8>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena, barena, fr, io);
+}
+
 void launch_mlp_sdf_stream(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io,
                            int max_slots, bool f16w, hipStream_t stream) {
     if (max_slots <= 0) return;
-    const int tiles = (max_slots + ST_TM - 1) / ST_TM;
-    const int grid = tiles < 256 ? tiles : 256;     // one 8-wave workgroup per CU, persistent over tiles
-    if (f16w) hipLaunchKernelGGL((mlp_sdf_stream_kernel<f16>), dim3(grid), dim3(ST_THREADS), 0, stream, net, sarena, barena, fr, io);
-    else hipLaunchKernelGGL((mlp_sdf_stream_kernel<bf16>), dim3(grid), dim3(ST_THREADS), 0, stream, net, sarena, barena, fr, io);
+    // A launch that cannot fill the 256 CUs with 256-point tiles is bound by the latency of ONE tile (1952 MFMAs per
+    // wave): narrower workgroups put one wave on a SIMD instead of two and cut that latency by ~2x.
+    static const int force = getenv("RA_STREAM_NW") ? atoi(getenv("RA_STREAM_NW")) : 0;
+    const int nw = !f16w ? 8 : (force ? force : (max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 128 ? 4 : 8)));   // bf16 (A/B only): wide variant
+#ifndef RA_STREAM_WIDE_ONLY
+    if (nw == 2) { launch_nw<2>(net, sarena, barena, fr, io, max_slots, f16w, stream); return; }
+    if (nw == 4) { launch_nw<4>(net, sarena, barena, fr, io, max_slots, f16w, stream); return; }
+#endif
+    launch_nw<8>(net, sarena, barena, fr, io, max_slots, f16w, stream);
 }
