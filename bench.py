@@ -48,6 +48,18 @@ def cpu_baseline(cfg, H, n_target=768, threads=16):
                        f'torch fp32 CPU restatement of the reference path (oracle/ra_oracle.py)')
 
 
+def hbm_traffic_per_launch(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own
+    passes, tools/collect_profiles.sh): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_relight512_pmc.csv')
+    try:
+        rows = [l.strip().split(',') for l in open(path) if l.startswith(kernel + ',')]
+        v = {r[1]: (float(r[2]), int(r[3])) for r in rows}
+        return (2.0 * v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1] + v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -126,6 +138,8 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         achieved = (cnt.n_fine_sdf * F_SDF) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        kname = {'1': 'mlp_sdf_kernel', '2': 'mlp_sdf_pipe_kernel'}.get(os.environ.get('RA_MLP_GEN', '3'), 'mlp_sdf_stream_kernel')
+        default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel'
         line = {
             'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
@@ -135,9 +149,10 @@ def main():
                        'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
                        'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'full_queries_per_frame': int(cnts[1].item() / args.steps),
                        'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
-                       'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'rays round-robin over {world} GPU(s) + all_gather'},
+                       'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'8x8 pixel tiles dealt over {world} GPU(s) + one all_gather'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
-                         'traffic': None, 'kernel': {'1': 'mlp_sdf_kernel', '2': 'mlp_sdf_pipe_kernel'}.get(os.environ.get('RA_MLP_GEN', '3'), 'mlp_sdf_stream_kernel'), 'launches': mlp_launches,
+                         'traffic': hbm_traffic_per_launch(kname) if default_cmd else None, 'traffic_unit': 'B/launch (offline PMC pass of this command, profiles/r01_relight512_pmc.csv)',
+                         'kernel': kname, 'launches': mlp_launches,
                          'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': F_SDF,
                          'units_per_launch': cnt.n_fine_sdf / max(mlp_launches, 1)},
         }
