@@ -15,6 +15,7 @@
 // Skinning: A_bw = sum_k w_k * (sum_j weights[nn_k][j] A_j); the inner sum is a per-vertex table
 // built once per frame (vert_blend_kernel), so a point gathers 3x24 floats instead of 3x52.
 #include "ra_kernels.hpp"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -190,6 +191,20 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
     }
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// lane K of every 16-lane row, as a DPP source modifier (gfx90a+ row_newbcast); folds into the consuming VALU op
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float box_dist2(const float p[3], float lx, float ly, float lz, float hx, float hy, float hz) {
     const float dx = fmaxf(fmaxf(lx - p[0], p[0] - hx), 0.f);
     const float dy = fmaxf(fmaxf(ly - p[1], p[1] - hy), 0.f);
@@ -276,19 +291,20 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
         const int lane = threadIdx.x & 63;
         // one coalesced load per leaf (lane k holds point k; the array is padded with +inf to whole
         // leaves), then 32 register broadcasts: no per-point memory latency
+        // A leaf (32 points) sits in two float4 registers per lane: lane l holds points l & 15 and 16 + (l & 15), i.e.
+        // every 16-lane row carries the whole leaf, and a candidate's coordinates reach all lanes as the DPP operand
+        // of the subtraction itself (row_newbcast k): per candidate 3 DPP subtracts + mul + 2 fma + compare + branch.
         auto scan_leaf = [&](int l) __attribute__((always_inline)) {
-            const float4 mine = fr.bvh_pts[l * BVH_LEAF + (lane & (BVH_LEAF - 1))];
-            const int mi = __float_as_int(mine.w);
-#pragma unroll
-            for (int k = 0; k < BVH_LEAF; ++k) {
-                const float vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), k));
-                const float vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), k));
-                const float vz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), k));
-                const float dx = p[0] - vx, dy = p[1] - vy, dz = p[2] - vz;
+            const float4 pa = fr.bvh_pts[l * BVH_LEAF + (lane & 15)];
+            const float4 pb = fr.bvh_pts[l * BVH_LEAF + 16 + (lane & 15)];
+            static_for<0, 32>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                const float4& q = k < 16 ? pa : pb;
+                const float dx = p[0] - row_bcast<k & 15>(q.x), dy = p[1] - row_bcast<k & 15>(q.y), dz = p[2] - row_bcast<k & 15>(q.z);
                 const float d = dx * dx + dy * dy + dz * dz;
                 if (__builtin_expect(__ballot(d <= d2) != 0ull, 0))          // the vertex id is only needed on the rare insert path
-                    knn_insert(d, __builtin_amdgcn_readlane(mi, k), d0, d1, d2, i0, i1, i2);
-            }
+                    knn_insert(d, __builtin_amdgcn_readlane(__float_as_int(q.w), k & 15), d0, d1, d2, i0, i1, i2);
+            });
         };
         auto sdist = [&](int j) __attribute__((always_inline)) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
         auto ldist = [&](int j) __attribute__((always_inline)) { const float4 lo = lbx[2 * j], hi = lbx[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
