@@ -362,9 +362,11 @@ void launch_mlp_sdf_stream(const GeoNet& net, const void* sarena, const float* b
                            int max_slots, bool f16w, hipStream_t stream) {
     if (max_slots <= 0) return;
     // A launch that cannot fill the 256 CUs with 256-point tiles is bound by the latency of ONE tile (1952 MFMAs per
-    // wave): narrower workgroups put one wave on a SIMD instead of two and cut that latency by ~2x.
+    // wave): narrower workgroups put one wave on a SIMD instead of two (86 -> 67 -> 58 us per tile for 8 / 4 / 2 waves).
+    // max_slots is only an upper bound of the device-side count: up to 65536 the 4-wave variant needs at most the two
+    // rounds that equal one 8-wave round, and one when the real count is below half.
     static const int force = getenv("RA_STREAM_NW") ? atoi(getenv("RA_STREAM_NW")) : 0;
-    const int nw = !f16w ? 8 : (force ? force : (max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 128 ? 4 : 8)));   // bf16 (A/B only): wide variant
+    const int nw = !f16w ? 8 : (force ? force : (max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8)));   // bf16 (A/B only): wide variant
 #ifndef RA_STREAM_WIDE_ONLY
     if (nw == 2) { launch_nw<2>(net, sarena, barena, fr, io, max_slots, f16w, stream); return; }
     if (nw == 4) { launch_nw<4>(net, sarena, barena, fr, io, max_slots, f16w, stream); return; }
