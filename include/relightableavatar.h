@@ -189,6 +189,17 @@ int ra_enable_timing(ra_ctx* ctx, int on);
  * Takes effect at the next ra_set_frame. Both return identical neighbours. */
 int ra_set_knn_mode(ra_ctx* ctx, int use_bvh);
 
+/* ---- N2: ray generation + bounding-box culling on the device ------------------------------------
+ * replaces lib/utils/data_utils.py:827-845 (get_rays), :860-875 (get_full_near_far), :925-938 (get_rays_within_bounds),
+ * called per frame by lib/datasets/pose_dataset.py:53-68 on the CPU.
+ * K, R: 9 doubles row-major, T: 3 doubles (host); bounds: 6 floats (host: min xyz, max xyz = batch.wbounds).
+ * Device outputs with capacity H*W rays: ray_o, ray_d (n,3) f32; near, far (n) f32 — the in-box rays in row-major
+ * pixel order, exactly the reference's boolean-mask order; mask_at_box: H*W uint8.  *n_rays receives the count
+ * (synchronises the stream).  Directions are computed in fp64 and rounded once (the reference computes them in the
+ * camera's dtype and casts to float32); near/far follow the reference's float32 arithmetic operation by operation. */
+int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
+                void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream);
+
 /* ---- test hooks: stage outputs for the parity tests (tests/test_gpu_*.py); not used by renderers ---- */
 /* resd + sdf MLPs on given big-pose points: resd n x 3, sdf n, feat n x 256 (any may be NULL) */
 int ra_debug_mlp(ra_ctx* ctx, const float* bpts_dev, int n, float* resd, float* sdf, float* feat, void* stream);

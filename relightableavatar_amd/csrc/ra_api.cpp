@@ -566,6 +566,45 @@ int ra_set_knn_mode(ra_ctx* c, int use_bvh) {
     return 0;
 }
 
+static void inv3x3(const double* m, double* o) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    o[0] = (e * i - f * h) / det; o[1] = (c * h - b * i) / det; o[2] = (b * f - c * e) / det;
+    o[3] = (f * g - d * i) / det; o[4] = (a * i - c * g) / det; o[5] = (c * d - a * f) / det;
+    o[6] = (d * h - e * g) / det; o[7] = (b * g - a * h) / det; o[8] = (a * e - b * d) / det;
+}
+
+int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
+                void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream) {
+    RA_CHECK(c, "ra_gen_rays: null ctx");
+    RA_CHECK(H > 0 && W > 0 && (long long)H * W < (1ll << 30), "ra_gen_rays: bad image size");
+    RA_CHECK(K && R && T && bounds && ray_o && ray_d && near && far && mask_at_box && n_rays, "ra_gen_rays: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    RA_HIP(hipSetDevice(c->device));
+    RayCam cam;
+    inv3x3(K, cam.Kinv);
+    for (int k = 0; k < 9; ++k) cam.R[k] = R[k];
+    for (int k = 0; k < 3; ++k) {
+        cam.T[k] = T[k];
+        cam.o[k] = -(R[k] * T[0] + R[3 + k] * T[1] + R[6 + k] * T[2]);      // -R^T T
+        cam.bmin[k] = bounds[k];
+        cam.bmax[k] = bounds[3 + k];
+    }
+    cam.H = H; cam.W = W;
+    const int n = H * W;
+    int err = 0;
+    const size_t tb = gen_rays_temp_bytes(n);
+    int* pix = c->buf<int>("ray_pix", (size_t)n + 1, &err);
+    void* temp = c->buf<char>("ray_tmp", tb ? tb : 16, &err);
+    RA_CHECK(!err, "ra_gen_rays: out of device memory");
+    int* count_dev = pix + n;
+    RA_CHECK(launch_gen_rays(cam, (unsigned char*)mask_at_box, pix, count_dev, temp, tb, (float*)ray_o, (float*)ray_d, (float*)near,
+                             (float*)far, s) == 0, "ra_gen_rays: device selection failed");
+    RA_HIP(hipMemcpyAsync(n_rays, count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    RA_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
 int ra_enable_timing(ra_ctx* c, int on) {
     RA_CHECK(c, "ra_enable_timing: null ctx");
     c->timing = on != 0;

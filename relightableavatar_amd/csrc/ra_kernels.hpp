@@ -129,3 +129,10 @@ void launch_volume_composite(const float* raw, int C, const float* near_, const 
                              const ra_render_out& out, hipStream_t s);
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
 void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s);
+
+// N2: ray generation + AABB culling (ra_trace.hip)
+struct RayCam { double Kinv[9]; double R[9]; double T[3]; double o[3]; float bmin[3]; float bmax[3]; int H, W; };
+size_t gen_rays_temp_bytes(int n_pixels);
+int launch_gen_rays(const RayCam& cam, unsigned char* mask, int* pix_idx, int* count_dev, void* temp, size_t temp_bytes,
+                    float* ray_o, float* ray_d, float* near, float* far, hipStream_t s);
+

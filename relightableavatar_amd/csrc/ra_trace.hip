@@ -610,6 +610,70 @@ void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s) {
     hipLaunchKernelGGL(shadow_gen_kernel, grid_for(groups * 64 * g.L), dim3(TPB), 0, s, g);
 }
 
+// ------------------------------------------------------------------------------------------ N2: ray generation
+// one pixel's ray and box interval (data_utils.py:827-845, 860-875): direction in fp64, rounded once; the rest fp32
+__device__ __forceinline__ bool pixel_ray(const RayCam& c, int pix, float o[3], float d[3], float& nr, float& fr) {
+    const double x = (double)(pix % c.W), y = (double)(pix / c.W);
+    double pc[3], pw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pc[k] = x * c.Kinv[3 * k] + y * c.Kinv[3 * k + 1] + c.Kinv[3 * k + 2] - c.T[k];    // xy1 @ inv(K).T - T
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pw[k] = pc[0] * c.R[k] + pc[1] * c.R[3 + k] + pc[2] * c.R[6 + k] - c.o[k];          // (.) @ R - ray_o
+    const double inv = 1.0 / sqrt(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d[k] = (float)(pw[k] * inv); o[k] = (float)c.o[k]; }
+    const float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float t_near = -3.4e38f, t_far = 3.4e38f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = d[k] / nd;
+        if (v < 1e-5f && v > -1e-10f) v = 1e-5f;
+        if (v > -1e-5f && v < 1e-10f) v = -1e-5f;
+        const float t0 = (c.bmin[k] - o[k]) / v, t1 = (c.bmax[k] - o[k]) / v;
+        t_near = fmaxf(t_near, fminf(t0, t1));
+        t_far = fminf(t_far, fmaxf(t0, t1));
+    }
+    nr = t_near / nd / nd;          // get_full_near_far and get_near_far both divide by |d| (= 1)
+    fr = t_far / nd / nd;
+    return t_near < t_far;
+}
+
+__global__ void ray_mask_kernel(RayCam c, unsigned char* __restrict__ mask) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= c.H * c.W) return;
+    float o[3], d[3], nr, fr;
+    mask[i] = pixel_ray(c, i, o, d, nr, fr) ? 1 : 0;
+}
+
+__global__ void ray_emit_kernel(RayCam c, const int* __restrict__ pix_idx, const int* __restrict__ count, float* __restrict__ ro,
+                                float* __restrict__ rd, float* __restrict__ near_, float* __restrict__ far_) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= *count) return;
+    float o[3], d[3], nr, fr;
+    pixel_ray(c, pix_idx[i], o, d, nr, fr);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ro[3 * i + k] = o[k]; rd[3 * i + k] = d[k]; }
+    near_[i] = nr;
+    far_[i] = fr;
+}
+
+size_t gen_rays_temp_bytes(int n) {
+    size_t bytes = 0;
+    hipcub::DeviceSelect::Flagged(nullptr, bytes, hipcub::CountingInputIterator<int>(0), (const unsigned char*)nullptr, (int*)nullptr, (int*)nullptr, n);
+    return bytes;
+}
+
+int launch_gen_rays(const RayCam& cam, unsigned char* mask, int* pix_idx, int* count_dev, void* temp, size_t temp_bytes,
+                    float* ray_o, float* ray_d, float* near, float* far, hipStream_t s) {
+    const int n = cam.H * cam.W;
+    if (n <= 0) { hipMemsetAsync(count_dev, 0, sizeof(int), s); return 0; }
+    hipLaunchKernelGGL(ray_mask_kernel, grid_for(n), dim3(TPB), 0, s, cam, mask);
+    // stable selection: the in-box pixels in row-major order, as the reference's boolean mask indexing gives them
+    if (hipcub::DeviceSelect::Flagged(temp, temp_bytes, hipcub::CountingInputIterator<int>(0), mask, pix_idx, count_dev, n, s) != hipSuccess) return 1;
+    hipLaunchKernelGGL(ray_emit_kernel, grid_for(n), dim3(TPB), 0, s, cam, pix_idx, count_dev, ray_o, ray_d, near, far);
+    return 0;
+}
+
 size_t sort_hits_temp_bytes(int P) {
     size_t bytes = 0;
     hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, P);

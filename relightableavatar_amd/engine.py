@@ -168,6 +168,27 @@ class Engine:
         check(self.lib.ra_set_knn_mode(self.ctx, int(use_bvh)), 'ra_set_knn_mode')
         self._frame_key = None
 
+    def gen_rays(self, H, W, K, R, T, bounds):
+        """N2: rays of an H x W pinhole view culled against the body's bounding box, on the device.
+        K, R (3,3), T (3,) or (3,1): anything numpy can read; bounds (2,3).  Returns the reference's
+        get_rays_within_bounds outputs as device tensors: ray_o, ray_d (P,3), near, far (P,), mask_at_box (H,W) bool."""
+        import numpy as np
+        Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
+        Rd = np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(9))
+        Td = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(3))
+        bd = np.ascontiguousarray(np.asarray(bounds.detach().cpu() if isinstance(bounds, torch.Tensor) else bounds, dtype=np.float32).reshape(6))
+        n = int(H) * int(W)
+        d = self.device
+        ro, rd = torch.empty(n, 3, device=d), torch.empty(n, 3, device=d)
+        near, far = torch.empty(n, device=d), torch.empty(n, device=d)
+        mask = torch.empty(n, device=d, dtype=torch.uint8)
+        cnt = C.c_int(0)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        check(self.lib.ra_gen_rays(self.ctx, int(H), int(W), dp(Kd), dp(Rd), dp(Td), bd.ctypes.data_as(C.POINTER(C.c_float)),
+                                   _ptr(ro), _ptr(rd), _ptr(near), _ptr(far), _ptr(mask), C.byref(cnt), self.stream), 'ra_gen_rays')
+        P = cnt.value
+        return dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(int(H), int(W)).bool())
+
     def enable_timing(self, on=True):
         check(self.lib.ra_enable_timing(self.ctx, int(on)), 'ra_enable_timing')
 

@@ -127,12 +127,15 @@ def npz(path, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel'])
+    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays'])
     args = ap.parse_args()
     mode = args.mode
     from relightableavatar_amd import synthetic
     from relightableavatar_amd.config import make_cfg
     cfg = install_reference()
+    if mode == 'rays':
+        gen_rays(synthetic)
+        return
     set_cfg(cfg, mode)
     torch.manual_seed(0)
     torch.set_grad_enabled(True)
@@ -190,6 +193,31 @@ def main():
                 if k in out[name]:
                     kw[f'{name}.{k}'] = out[name][k]
         npz('frame_novel.npz', **kw)
+
+
+def gen_rays(synthetic):
+    """N2: the reference's per-frame ray set-up (lib/utils/data_utils.py:925-938) on two cameras."""
+    from lib.utils.data_utils import get_rays_within_bounds
+    kw = {}
+    b = synthetic.make_body(0, True)
+    bounds = b.wbounds[0].numpy().astype(np.float32)          # get_bounds() returns float32 (base_dataset.py)
+    # (a) the synthetic frontal camera (float64, as relightableavatar_amd.synthetic builds it)
+    H = W = 96
+    K, R, T = synthetic.make_camera(H, W)
+    # (b) a rotated float32 camera, H != W (novel-view style intrinsics, pose_dataset.py:57-64)
+    H2, W2 = 64, 80
+    K2 = np.array([[H2 * 0.8, 0, W2 / 2], [0, H2 * 0.8, H2 / 2], [0, 0, 1]], dtype=np.float32)
+    ax, ay = 0.35, -0.6
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    R2 = (Rx @ Ry).astype(np.float32)
+    T2 = np.array([[0.1], [-0.05], [2.2]], dtype=np.float32)
+    for tag, (h, w, k, r, t) in {'a': (H, W, K, R, T), 'b': (H2, W2, K2, R2, T2)}.items():
+        ro, rd, near, far, mask = get_rays_within_bounds(h, w, k, r, t, bounds)
+        kw.update({f'{tag}_H': h, f'{tag}_W': w, f'{tag}_K': np.asarray(k, np.float64), f'{tag}_R': np.asarray(r, np.float64),
+                   f'{tag}_T': np.asarray(t, np.float64).reshape(3), f'{tag}_ray_o': ro, f'{tag}_ray_d': rd, f'{tag}_near': near,
+                   f'{tag}_far': far, f'{tag}_mask': mask})
+    npz('rays.npz', bounds=bounds, **kw)
 
 
 def gen_ops(net, cfg, synthetic):

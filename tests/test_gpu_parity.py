@@ -369,3 +369,31 @@ def test_rccl_path_world1_under_torchrun():
                                '--size', '128', '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=600)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['roofline']['achieved'] > 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ray_generation_on_device(golden, relight):
+    """N2: ra_gen_rays vs the reference's get_rays_within_bounds outputs (golden rays.npz): same in-box
+    pixels in the same order, directions within 1 ulp-ish (2e-7), near/far within 2e-6; then full-size properties."""
+    _, _, dev, body, eng = relight
+    g = golden('rays.npz')
+    for tag in ('a', 'b'):
+        H, W = int(g[f'{tag}_H']), int(g[f'{tag}_W'])
+        o = eng.gen_rays(H, W, g[f'{tag}_K'], g[f'{tag}_R'], g[f'{tag}_T'], g['bounds'])
+        ref_mask = T(g[f'{tag}_mask'])
+        assert int((o.mask_at_box.cpu() != ref_mask).sum()) <= 2                  # pixels grazing a box edge may flip
+        if bool((o.mask_at_box.cpu() == ref_mask).all()):
+            assert float(err(o.ray_d, g[f'{tag}_ray_d']).max()) < 2e-7 and float(err(o.ray_o, g[f'{tag}_ray_o']).max()) < 1e-7
+            assert float(err(o.near, g[f'{tag}_near']).max()) < 2e-6 and float(err(o.far, g[f'{tag}_far']).max()) < 2e-6
+    # 512 x 512: matches the host-side set-up the benchmark batches are built with, row-major order, unit directions
+    from relightableavatar_amd.data_utils import get_rays_within_bounds
+    K, R, Tc = synthetic.make_camera(512, 512)
+    ro, rd, near, far, mask = get_rays_within_bounds(512, 512, K, R, Tc, body.wbounds[0], eng)
+    b = synthetic.make_batch(512, 512, seed=0, posed=True)
+    assert int((mask.cpu().reshape(1, -1) != b.mask_at_box).sum()) <= 4
+    if ro.shape[0] == b.ray_o.shape[1]:
+        assert float(err(rd, b.ray_d[0]).max()) < 3e-7 and float(err(near, b.near[0]).max()) < 5e-6 and float(err(far, b.far[0]).max()) < 5e-6
+    assert float((rd.norm(dim=-1) - 1).abs().max()) < 1e-6 and bool((near < far).all())
+    # degenerate: a box behind the camera yields no rays
+    e = eng.gen_rays(16, 16, K, R, Tc, torch.tensor([[10., 10., -9.], [11., 11., -8.]]))
+    assert e.ray_o.shape[0] == 0 and not bool(e.mask_at_box.any())
+
