@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--probes', type=int, default=8, help='novel_light: number of 16x32 probes re-shaded per frame')
     ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ground', action='store_true', help='relight: add the ground-plane pass (cfg.vis_ground_shading, SURVEY.md 8f row N1)')
     ap.add_argument('--emulate-world', type=int, default=0, help='tuning aid: render only rank 0\'s shard of an N-rank job on one GPU (no collective); value is then NOT a whole-job rate')
     args = ap.parse_args()
 
@@ -87,7 +88,8 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     H = args.size
-    cfg = make_cfg(args.mode, mlp_dtype=args.dtype)
+    kw = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0]) if args.ground else {}
+    cfg = make_cfg(args.mode, mlp_dtype=args.dtype, **kw)
     relight = args.mode in ('relight', 'novel_light')
     net = make_network(cfg)
     net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
@@ -96,10 +98,13 @@ def main():
     base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0), dev)
     P = base.ray_o.shape[1]
     wb0 = base.wbounds.clone()
+    mask0 = base.mask_at_box.clone()
     eng = net.engine()
 
     def step():
         base.wbounds.copy_(wb0)     # a fresh batch per frame, as the reference's loader delivers
+        if args.ground:
+            base.mask_at_box.copy_(mask0)   # the ground pass sets it to all-true in place (sphere_tracing_renderer.py:1103)
         if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
             out = renderer.render(shard.shard_batch(base, rank, world))
             rgb = torch.cat([out[n].rgb_map for n in base.novel_lights], dim=-1)
@@ -145,7 +150,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'xuzhen_12v_geo_fix_mat-shaped full relight, {H}x{H}, 16x32 light probe, DFSS visibility (4 iters), '
-                                   f'16-iter surface trace, synthetic weights/body' + (f', {args.probes} novel probes re-shaded' if args.mode == 'novel_light' else '') if relight else f'{args.mode} {H}x{H}',
+                                   f'16-iter surface trace, synthetic weights/body' + (f', {args.probes} novel probes re-shaded' if args.mode == 'novel_light' else '') + (', + ground-plane pass' if args.ground else '') if relight else f'{args.mode} {H}x{H}',
                        'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
                        'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'full_queries_per_frame': int(cnts[1].item() / args.steps),
                        'coarse_queries_per_frame': int(cnts[2].item() / args.steps),

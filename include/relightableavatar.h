@@ -189,6 +189,36 @@ int ra_enable_timing(ra_ctx* ctx, int on);
  * Takes effect at the next ra_set_frame. Both return identical neighbours. */
 int ra_set_knn_mode(ra_ctx* ctx, int use_bvh);
 
+/* ---- N1: ground-plane pass --------------------------------------------------------------------
+ * replaces render_ground (lib/networks/renderer/sphere_tracing_renderer.py:463-548) for one chunk of full-frame rays:
+ * ray/plane hit (moller_trumbore on one triangle of the plane, mesh_utils.py:710-738), DFSS shadows of the avatar onto
+ * the plane (light_visibility :265-344 with cfg.env_lvis), Lambert ground lit by the probe, distance fade (:497-505). */
+typedef struct ra_ground_params {
+    float normal[3];            /* cfg.ground_normal (normalised inside) */
+    float origin[3];            /* cfg.ground_origin */
+    float albedo[3];            /* cfg.ground_albedo, used when attach_envmap == 0 */
+    int attach_envmap;          /* cfg.ground_attach_envmap: albedo = probe sampled along the view ray */
+    float env_r;                /* cfg.env_r */
+    float shading_multiplier;   /* cfg.ground_shading_multiplier */
+    ra_trace_params shadow;     /* cfg.env_lvis as a trace-parameter block */
+    float shadow_near_offset;   /* cfg.env_lvis.near_offset */
+    int no_visibility, local_visibility;
+} ra_ground_params;
+
+typedef struct ra_ground_out {  /* device buffers with P rows, any may be NULL */
+    void* rgb;      /* (P,3) */
+    void* surf;     /* (P,3) */
+    void* albedo;   /* (P,3) */
+    void* shade;    /* (P,3) shade_map (multiplier applied) */
+    void* spec;     /* (P,3) spec_map = shade / 20 */
+    void* depth;    /* (P)   t clipped to +-env_r */
+} ra_ground_out;
+
+/* ray_o, ray_d: (P,3); acc: (P) = 1 - human acc (pixels with acc <= 0 are not traced and come back as zeros);
+ * bbox: 6 host floats (the human box grown by the caller, get_ground_value :1054-1056); probe: (ph,pw,3) device. */
+int ra_render_ground_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, const float* acc, int P, const float* bbox,
+                           const float* probe, int ph, int pw, const ra_ground_params* p, const ra_ground_out* out, void* stream);
+
 /* ---- N2: ray generation + bounding-box culling on the device ------------------------------------
  * replaces lib/utils/data_utils.py:827-845 (get_rays), :860-875 (get_full_near_far), :925-938 (get_rays_within_bounds),
  * called per frame by lib/datasets/pose_dataset.py:53-68 on the CPU.

@@ -609,7 +609,49 @@ BLEND_KEYS = ['rgb_map', 'rfl_map', 'surf_map', 'albedo_map', 'roughness_map', '
               'spec_map', 'depth_map', 'lvis_map', 'ldot_map', 'brdf_map', 'shade_map']
 
 
-def render_sphere_tracing(net: OracleNet, batch, probe=None, mutate_bounds=True):
+def get_rays_torch(H, W, K, R, T):
+    """get_rays net_utils.py:403-425 (torch, the camera's dtype): full-frame rays, (H*W,3) each."""
+    ray_o = -(R.mT @ T).ravel()
+    i, j = torch.meshgrid(torch.arange(H, dtype=R.dtype), torch.arange(W, dtype=R.dtype), indexing='ij')
+    xy1 = torch.stack([j, i, torch.ones_like(i)], dim=2)
+    pixel_camera = xy1 @ torch.inverse(K).mT
+    pixel_world = (pixel_camera - T.ravel()) @ R
+    ray_d = normalize(pixel_world - ray_o[None, None])
+    return ray_o[None].expand(H * W, 3), ray_d.reshape(-1, 3)
+
+
+def render_ground(net: OracleNet, ray_o, ray_d, acc, probe, fr, bbox):
+    """render_ground sphere_tracing_renderer.py:463-548, one chunk: ray/plane hit (moller_trumbore on one triangle of the
+    plane, mesh_utils.py:710-738 — its t reduces to -((o-orig).n)/(d.n + eps/|a|^2); the triangle's random edge only scales
+    eps), DFSS shadows of the avatar onto the plane with cfg.env_lvis, Lambert ground lit by the probe, distance fade.
+    ray_o, ray_d (P,3); acc (P) = 1 - human acc; returns per-pixel maps."""
+    c = net.cfg
+    n = normalize(torch.tensor(c.ground_normal, dtype=torch.float32))
+    orig = torch.tensor(c.ground_origin, dtype=torch.float32)
+    t = -((ray_o - orig) @ n) / ((ray_d @ n) + 1e-8)
+    surf = ray_o + t[:, None] * ray_d
+    norm = n[None].expand_as(surf)
+    lvis, _ = light_visibility(net, surf, norm, acc, fr, bbox, c.env_lvis, lambda th: (lambda x: hdq_sdf(net, x, fr, th, True)))
+    albedo = sample_envmap_image(probe, ray_d) if c.ground_attach_envmap else torch.tensor(c.ground_albedo)[None].expand_as(surf)
+    dist = torch.where(t <= 0, torch.full_like(t, 1e9), (surf - orig).norm(dim=-1))
+    weight = ((dist - c.env_r) / c.env_r).clip(0, 1)                       # (P)
+    xyz = net.light_xyz.reshape(-1, 3)
+    area = net.light_area.reshape(-1)
+    ldir = normalize(xyz)
+    ldot = (ldir @ n)[:, None].expand(-1, surf.shape[0])                   # (L,P): NOT clamped (:504)
+    lvis = lvis * (1 - weight)[None] + weight[None]
+    light = sample_envmap_image(probe, ldir)                               # (L,3)
+    shade = lvis[..., None] * ldot[..., None] * area[:, None, None] * light[:, None, :]
+    rgb = ((albedo / math.pi)[None] * shade).sum(0)
+    if c.tonemapping_rendering:
+        rgb = linear2srgb(rgb)
+    shade = shade.sum(0) * c.shading_albedo / math.pi
+    return odict(rgb_map=rgb, surf_map=surf, albedo_map=albedo, roughness_map=torch.ones_like(t), spec_map=shade / 20,
+                 norm_map=norm, shade_map=shade * c.ground_shading_multiplier, cpts_map=torch.zeros_like(surf),
+                 bpts_map=torch.zeros_like(surf), depth_map=t.clip(-c.env_r, c.env_r))
+
+
+def render_sphere_tracing(net: OracleNet, batch, probe=None, mutate_bounds=True, ground_inds=None):
     """Renderer.render sphere_tracing_renderer.py:1066-1115 (no ground pass): chunk rays, grow bbox
     IN PLACE per chunk (quirk 1), render_human, premultiply by acc (alpha_output_ :454-460).
     Returns batched (1,P,...) maps like the reference."""
@@ -627,6 +669,34 @@ def render_sphere_tracing(net: OracleNet, batch, probe=None, mutate_bounds=True)
     ret = odict()
     for k in outs[0]:
         ret[k] = torch.cat([o[k] for o in outs], dim=0)
+    if c.vis_ground_shading:
+        # Renderer.render :1084-1111: full-frame rays, acc = 1 - human acc scattered to the in-box pixels, ground chunks
+        # (each growing batch.wbounds again: get_ground_value :1054-1056), then blend_output_ (:434-451)
+        H, W = int(batch['meta']['H'][0]), int(batch['meta']['W'][0])
+        # the reference takes the in-box pixel indices from batch_aware_indexing = topk(sorted=False) (net_utils.py:381-389),
+        # whose order is implementation-defined (not ascending on CPU): `ground_inds` lets a test reproduce a given order
+        inds = batch['mask_at_box'].reshape(-1).nonzero()[:, 0] if ground_inds is None else ground_inds
+        g_o, g_d = get_rays_torch(H, W, batch['cam_K'][0], batch['cam_R'][0], batch['cam_T'][0])
+        acc_g = torch.ones(H * W)
+        acc_g[inds] = 1 - ret.acc_map
+        gouts = []
+        for (a, b) in _chunks(H * W, c.render_chunk_size):
+            wb[:, 0] -= c.env_lvis.bbox_margin
+            wb[:, 1] += c.env_lvis.bbox_margin
+            gouts.append(render_ground(net, g_o[a:b].float(), g_d[a:b].float(), acc_g[a:b], probe, fr, wb[0].float()))
+        grd = odict({k: torch.cat([o[k] for o in gouts], dim=0) for k in gouts[0]})
+        for k in BLEND_KEYS:
+            if k in ret and k in grd:
+                sc = torch.zeros_like(grd[k])
+                sc[inds] = ret[k]
+                ag = acc_g if grd[k].ndim == 1 else acc_g[:, None]
+                ret[k] = grd[k] * ag + sc * (1 - ag)
+            elif k in grd:
+                ret[k] = grd[k] * (acc_g if grd[k].ndim == 1 else acc_g[:, None])
+        sc = torch.zeros(H * W)
+        sc[inds] = ret.acc_map
+        ret.acc_map = sc * (1 - acc_g)                                   # alpha_blend(acc, inds, zeros, acc_map) (:449)
+        return odict({k: v[None] for k, v in ret.items()})
     acc = ret.acc_map
     for k in BLEND_KEYS:
         if k in ret:

@@ -49,6 +49,19 @@ class ra_sphere_params(C.Structure):
                 ('no_visibility', C.c_int), ('local_visibility', C.c_int), ('premultiply', C.c_int)]
 
 
+class ra_ground_params(C.Structure):
+    _fields_ = [('normal', C.c_float * 3), ('origin', C.c_float * 3), ('albedo', C.c_float * 3), ('attach_envmap', C.c_int),
+                ('env_r', C.c_float), ('shading_multiplier', C.c_float), ('shadow', ra_trace_params), ('shadow_near_offset', C.c_float),
+                ('no_visibility', C.c_int), ('local_visibility', C.c_int)]
+
+
+GROUND_OUT_KEYS = ('rgb', 'surf', 'albedo', 'shade', 'spec', 'depth')
+
+
+class ra_ground_out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in GROUND_OUT_KEYS]
+
+
 class ra_counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ('n_coarse', 'n_fine_sdf', 'n_fine_full', 'n_shadow_rays', 'n_hit_pixels', 'n_shaded')]
 
@@ -70,6 +83,8 @@ SYMBOLS = {
     'ra_render_sphere_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(ra_sphere_params), C.POINTER(ra_render_out), C.c_void_p]),
     'ra_render_volume_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.POINTER(ra_render_out), C.c_void_p]),
+    'ra_render_ground_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(ra_ground_params), C.POINTER(ra_ground_out), C.c_void_p]),
     'ra_reshade': (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
     'ra_get_counters': (C.c_int, [C.c_void_p, C.POINTER(ra_counters), C.c_void_p]),
     'ra_reset_counters': (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -91,6 +91,12 @@ def default_cfg() -> dotdict:
     c.vis_specular_map = False
     c.vis_novel_light = False
     c.vis_ground_shading = False
+    # ground-plane pass (config.py:104-107, 45, 353; render_ground sphere_tracing_renderer.py:463-548)
+    c.ground_normal = [0.0, 0.0, 1.0]
+    c.ground_origin = [0.0, 0.0, 0.0]
+    c.ground_albedo = [0.05, 0.05, 0.05]
+    c.ground_attach_envmap = True
+    c.ground_shading_multiplier = 1.0
     c.vis_lvis_map = False
     c.vis_ldot_map = False
     c.replace_light = ''

@@ -2,6 +2,7 @@
 // Every entry point only enqueues work on the caller's stream; counts that steer later passes
 // (fine points, hit pixels, shadow rays) stay on the device and kernels size themselves from them.
 #include "ra_ctx.hpp"
+#include <cmath>
 
 #include <cstring>
 #include <cstdlib>
@@ -322,6 +323,56 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
     return 0;
 }
 
+// light_visibility (sphere_tracing_renderer.py:265-344) for the hit slots of one chunk: per (slot, light) cosine and
+// visibility; rays that face the light and cross the box are sphere traced with the DFSS state machine (HOT LOOP B).
+static int light_visibility_stage(ra_ctx* c, const float* surf, const float* norm_slots, const float* acc, const int* hit_idx,
+                                  const int* hit_count, int P, const float* bbox, float near_offset, const ra_trace_params& shadow,
+                                  int no_visibility, int local_visibility, float** lvis_out, float** ldot_out, hipStream_t s) {
+    int err = 0;
+    const int L = c->n_lights;
+    const size_t NR = (size_t)P * L;
+    float* lvis = c->buf<float>("lv_lvis", NR, &err);
+    float* ldot = c->buf<float>("lv_ldot", NR, &err);
+    ShadowGen g{};
+    g.surf = surf; g.norm = norm_slots; g.acc = acc; g.hit_idx = hit_idx; g.hit_count = hit_count; g.ldir = c->light_dir.as<float>();
+    for (int k = 0; k < 6; ++k) g.bbox[k] = bbox[k];
+    g.near_offset = near_offset; g.L = L; g.no_visibility = no_visibility; g.local_visibility = local_visibility;
+    g.lvis = lvis; g.ldot = ldot;
+    const bool traced = !(no_visibility || local_visibility);
+    if (traced) {
+        g.ray_pix = c->buf<int>("lv_pix", NR, &err);
+        g.ray_light = c->buf<int>("lv_light", NR, &err);
+        g.ray_slot = c->buf<int>("lv_slot", NR, &err);
+        g.near_ = c->buf<float>("lv_near", NR, &err);
+        g.far_ = c->buf<float>("lv_far", NR, &err);
+    }
+    g.ray_count = icnt(c, CNT_RAYS);
+    TraceState sh{};
+    float* ssdf = nullptr;
+    if (traced) {
+        sh = alloc_trace(c, "sh_", (int)NR, true, &err);
+        ssdf = c->buf<float>("sh_sdf", NR, &err);
+    }
+    if (err) return 1;
+    launch_shadow_gen(g, P, s);
+    if (traced) {
+        sh.near_ = g.near_; sh.far_ = g.far_; sh.tan_i = c->light_sharp.as<float>(); sh.light = g.ray_light;
+        launch_trace_init(sh, (int)NR, g.ray_count, shadow, s);
+        RaySet r2{};
+        r2.mode = 2; r2.o = surf; r2.t = sh.t; r2.pix = g.ray_pix; r2.light = g.ray_light; r2.ldir = c->light_dir.as<float>();
+        r2.n_dev = g.ray_count;
+        for (int it = 0; it < shadow.iters; ++it) {
+            if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
+            launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
+        }
+        launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
+        launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);
+    }
+    *lvis_out = lvis;
+    *ldot_out = ldot;
+    return 0;
+}
+
 int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P,
                            const float* bbox, const float* probe, int ph, int pw, const ra_sphere_params* p,
                            const ra_render_out* out, void* stream) {
@@ -401,44 +452,8 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     // ---- light visibility + shading (HOT LOOP B)
     float *lvis = nullptr, *ldot = nullptr, *shade = nullptr, *spec = nullptr;
     if (relit) {
-        const size_t NR = (size_t)P * L;
-        lvis = c->buf<float>("lv_lvis", NR, &err);
-        ldot = c->buf<float>("lv_ldot", NR, &err);
-        ShadowGen g{};
-        g.surf = surf; g.norm = m.norm; g.acc = acc; g.hit_idx = hit_idx; g.hit_count = hit_count; g.ldir = c->light_dir.as<float>();
-        for (int k = 0; k < 6; ++k) g.bbox[k] = bbox[k];
-        g.near_offset = p->shadow_near_offset; g.L = L; g.no_visibility = p->no_visibility; g.local_visibility = p->local_visibility;
-        g.lvis = lvis; g.ldot = ldot;
-        const bool traced = !(p->no_visibility || p->local_visibility);
-        if (traced) {
-            g.ray_pix = c->buf<int>("lv_pix", NR, &err);
-            g.ray_light = c->buf<int>("lv_light", NR, &err);
-            g.ray_slot = c->buf<int>("lv_slot", NR, &err);
-            g.near_ = c->buf<float>("lv_near", NR, &err);
-            g.far_ = c->buf<float>("lv_far", NR, &err);
-        }
-        g.ray_count = icnt(c, CNT_RAYS);
-        TraceState sh{};
-        float* ssdf = nullptr;
-        if (traced) {
-            sh = alloc_trace(c, "sh_", (int)NR, true, &err);
-            ssdf = c->buf<float>("sh_sdf", NR, &err);
-        }
-        if (err) return 1;
-        launch_shadow_gen(g, P, s);
-        if (traced) {
-            sh.near_ = g.near_; sh.far_ = g.far_; sh.tan_i = c->light_sharp.as<float>(); sh.light = g.ray_light;
-            launch_trace_init(sh, (int)NR, g.ray_count, p->shadow, s);
-            RaySet r2{};
-            r2.mode = 2; r2.o = surf; r2.t = sh.t; r2.pix = g.ray_pix; r2.light = g.ray_light; r2.ldir = c->light_dir.as<float>();
-            r2.n_dev = g.ray_count;
-            for (int it = 0; it < p->shadow.iters; ++it) {
-                if (hdq_pass(c, r2, (int)NR, p->shadow.dist_th, 1, ssdf, s)) return 1;
-                launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, p->shadow, s);
-            }
-            launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
-            launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);
-        }
+        if (light_visibility_stage(c, surf, m.norm, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow,
+                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s)) return 1;
         m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
         shade = c->buf<float>("mp_shade", (size_t)P * 3, &err);
         spec = c->buf<float>("mp_spec", (size_t)P * 3, &err);
@@ -478,6 +493,56 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
         scat(out->lvis, lvis, L, pm, false);
         scat(out->ldot, ldot, L, pm, false);
     }
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, const float* acc, int P, const float* bbox,
+                           const float* probe, int ph, int pw, const ra_ground_params* p, const ra_ground_out* out, void* stream) {
+    if (check_ready(c, "ra_render_ground_chunk")) return 1;
+    RA_CHECK(p && out && P >= 0, "ra_render_ground_chunk: bad arguments");
+    if (P == 0) return 0;
+    RA_CHECK(ray_o && ray_d && acc && bbox && probe, "ra_render_ground_chunk: null argument");
+    RA_CHECK(c->cfg.relight && c->n_lights > 0, "ra_render_ground_chunk: needs the relight network's light set");
+    RA_CHECK((long long)P * c->n_lights < (1ll << 31), "ra_render_ground_chunk: chunk too large (P x lights must fit an int)");
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    GroundIn g{};
+    g.ray_o = ray_o; g.ray_d = ray_d; g.acc = acc; g.P = P;
+    const float nn = std::sqrt(p->normal[0] * p->normal[0] + p->normal[1] * p->normal[1] + p->normal[2] * p->normal[2]) + 1e-8f;   // normalize(): x / (|x| + eps)
+    for (int k = 0; k < 3; ++k) { g.n[k] = p->normal[k] / nn; g.orig[k] = p->origin[k]; g.albedo[k] = p->albedo[k]; }
+    g.attach_envmap = p->attach_envmap; g.env_r = p->env_r; g.shading_multiplier = p->shading_multiplier;
+    float* t = c->buf<float>("gd_t", P, &err);
+    float* surf = c->buf<float>("gd_surf", (size_t)P * 3, &err);
+    float* depth = c->buf<float>("gd_depth", P, &err);
+    float* nslots = c->buf<float>("gd_norm", (size_t)P * 3, &err);
+    int* hit_idx = c->buf<int>("gd_hit", P, &err);
+    if (err) return 1;
+    int* hit_count = icnt(c, CNT_HIT);
+    launch_ground_hit(g, t, surf, depth, nslots, hit_idx, hit_count, s);
+    {   // spatially coherent order of the traced pixels (results are written back per pixel, so order-free)
+        const size_t tb = sort_hits_temp_bytes(P);
+        unsigned* k0 = c->buf<unsigned>("hs_k0", P, &err);
+        unsigned* k1 = c->buf<unsigned>("hs_k1", P, &err);
+        int* v0 = c->buf<int>("hs_v0", P, &err);
+        char* tmp = c->buf<char>("hs_tmp", tb + 16, &err);
+        if (err) return 1;
+        const float bmin[3] = {bbox[0], bbox[1], bbox[2]};
+        if (launch_sort_hits(surf, acc, P, bmin, k0, k1, v0, hit_idx, tmp, tb, s)) { ra_set_error("ra_render_ground_chunk: radix sort failed"); return 1; }
+    }
+    float *lvis = nullptr, *ldot = nullptr;
+    if (light_visibility_stage(c, surf, nslots, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow, p->no_visibility,
+                               p->local_visibility, &lvis, &ldot, s)) return 1;
+    auto zero = [&](void* dst, int C) { if (dst) hipMemsetAsync(dst, 0, (size_t)P * C * sizeof(float), s); };
+    zero(out->rgb, 3); zero(out->albedo, 3); zero(out->shade, 3); zero(out->spec, 3);
+    GroundShade in{};
+    in.g = g; in.t = t; in.surf = surf; in.hit_idx = hit_idx; in.hit_count = hit_count; in.lvis = lvis;
+    in.ldir = c->light_dir.as<float>(); in.light_area = c->light_area.as<float>(); in.L = c->n_lights;
+    in.probe = probe; in.ph = ph; in.pw = pw;
+    in.rgb = (float*)out->rgb; in.albedo = (float*)out->albedo; in.shade = (float*)out->shade; in.spec = (float*)out->spec;
+    launch_ground_shade(in, c->cfg, s);
+    if (out->surf) RA_HIP(hipMemcpyAsync(out->surf, surf, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->depth) RA_HIP(hipMemcpyAsync(out->depth, depth, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, s));
     RA_HIP(hipGetLastError());
     return 0;
 }

@@ -136,3 +136,24 @@ size_t gen_rays_temp_bytes(int n_pixels);
 int launch_gen_rays(const RayCam& cam, unsigned char* mask, int* pix_idx, int* count_dev, void* temp, size_t temp_bytes,
                     float* ray_o, float* ray_d, float* near, float* far, hipStream_t s);
 
+// N1: ground-plane pass (ra_trace.hip)
+struct GroundIn {
+    const float *ray_o, *ray_d, *acc;     // P
+    int P;
+    float n[3], orig[3], albedo[3];
+    int attach_envmap;
+    float env_r, shading_multiplier;
+};
+// t, surf, clipped depth for every pixel; hit list = pixels with acc > 0; per-slot normal array filled with n
+void launch_ground_hit(const GroundIn& g, float* t, float* surf, float* depth, float* norm_slots, int* hit_idx, int* hit_count, hipStream_t s);
+struct GroundShade {
+    GroundIn g;
+    const float* t; const float* surf;
+    const int* hit_idx; const int* hit_count;
+    const float* lvis;                    // slot x L
+    const float *ldir, *light_area; int L;
+    const float* probe; int ph, pw;
+    float *rgb, *albedo, *shade, *spec;   // P x 3 (full indexing), nullable
+};
+void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_t s);
+

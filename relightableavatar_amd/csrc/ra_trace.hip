@@ -610,6 +610,88 @@ void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s) {
     hipLaunchKernelGGL(shadow_gen_kernel, grid_for(groups * 64 * g.L), dim3(TPB), 0, s, g);
 }
 
+// ------------------------------------------------------------------------------------------ N1: ground plane
+// ray / plane hit: moller_trumbore (mesh_utils.py:710-738) on a triangle of the plane reduces to
+// t = -((o - orig).N) / (d.N + eps) with N = |a|^2 n (a: the triangle's random in-plane edge, which only rescales eps)
+__global__ void ground_hit_kernel(GroundIn g, float* __restrict__ t_out, float* __restrict__ surf, float* __restrict__ depth,
+                                  float* __restrict__ norm_slots, int* __restrict__ hit_idx, int* __restrict__ hit_count) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    bool hit = false;
+    if (i < g.P) {
+        const float o[3] = {g.ray_o[3 * i], g.ray_o[3 * i + 1], g.ray_o[3 * i + 2]};
+        const float d[3] = {g.ray_d[3 * i], g.ray_d[3 * i + 1], g.ray_d[3 * i + 2]};
+        const float num = (o[0] - g.orig[0]) * g.n[0] + (o[1] - g.orig[1]) * g.n[1] + (o[2] - g.orig[2]) * g.n[2];
+        const float den = d[0] * g.n[0] + d[1] * g.n[1] + d[2] * g.n[2] + 1e-8f;
+        const float t = -num / den;
+        t_out[i] = t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { surf[3 * i + c] = o[c] + t * d[c]; norm_slots[3 * i + c] = g.n[c]; }
+        depth[i] = fminf(fmaxf(t, -g.env_r), g.env_r);
+        hit = g.acc[i] > 0.f;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(hit_count, __popcll(m));
+    base = __shfl(base, 0);
+    if (hit) hit_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// one wave per traced pixel, lanes stride the lights (render_ground :488-523)
+__global__ __launch_bounds__(TPB) void ground_shade_kernel(GroundShade in, ra_config cfg) {
+    const int n = min(*in.hit_count, in.g.P);
+    const int h = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (h >= n) return;
+    const int r = in.hit_idx[h];
+    const float t = in.t[r];
+    const float sx = in.surf[3 * r] - in.g.orig[0], sy = in.surf[3 * r + 1] - in.g.orig[1], sz = in.surf[3 * r + 2] - in.g.orig[2];
+    const float dist = t <= 0.f ? 1e9f : sqrtf(sx * sx + sy * sy + sz * sz);          // looking up: no ground (:497)
+    const float w = fminf(fmaxf((dist - in.g.env_r) / in.g.env_r, 0.f), 1.f);
+    float alb[3] = {in.g.albedo[0], in.g.albedo[1], in.g.albedo[2]};
+    if (in.g.attach_envmap) {
+        const float d[3] = {in.g.ray_d[3 * r], in.g.ray_d[3 * r + 1], in.g.ray_d[3 * r + 2]};
+        sample_probe(in.probe, in.ph, in.pw, d, alb);
+    }
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (int l = lane; l < in.L; l += 64) {
+        const float ld[3] = {in.ldir[3 * l], in.ldir[3 * l + 1], in.ldir[3 * l + 2]};
+        const float ldot = ld[0] * in.g.n[0] + ld[1] * in.g.n[1] + ld[2] * in.g.n[2];     // not clamped (:504)
+        const float lv = in.lvis[(size_t)h * in.L + l] * (1.f - w) + w;                  // :505
+        float Lr[3];
+        sample_probe(in.probe, in.ph, in.pw, ld, Lr);
+        const float k = lv * ldot * in.light_area[l];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sum[c] += k * Lr[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = sum[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) {
+            const float rgb = alb[c] / PI_F * a;
+            const float sh = a * cfg.shading_albedo / PI_F;
+            if (in.rgb) in.rgb[3 * r + c] = cfg.tonemapping ? srgb(rgb) : rgb;
+            if (in.albedo) in.albedo[3 * r + c] = alb[c];
+            if (in.shade) in.shade[3 * r + c] = sh * in.g.shading_multiplier;
+            if (in.spec) in.spec[3 * r + c] = sh / 20.f;
+        }
+    }
+}
+
+void launch_ground_hit(const GroundIn& g, float* t, float* surf, float* depth, float* norm_slots, int* hit_idx, int* hit_count, hipStream_t s) {
+    hipMemsetAsync(hit_count, 0, sizeof(int), s);
+    if (g.P <= 0) return;
+    hipLaunchKernelGGL(ground_hit_kernel, grid_for(g.P), dim3(TPB), 0, s, g, t, surf, depth, norm_slots, hit_idx, hit_count);
+}
+
+void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_t s) {
+    if (in.g.P <= 0) return;
+    hipLaunchKernelGGL(ground_shade_kernel, grid_for((long long)in.g.P * 64), dim3(TPB), 0, s, in, cfg);
+}
+
 // ------------------------------------------------------------------------------------------ N2: ray generation
 // one pixel's ray and box interval (data_utils.py:827-845, 860-875): direction in fp64, rounded once; the rest fp32
 __device__ __forceinline__ bool pixel_ray(const RayCam& c, int pix, float o[3], float d[3], float& nr, float& fr) {

@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import check, ra_config, ra_counters, ra_frame, ra_render_out, ra_sphere_params, ra_trace_params
+from ._lib import (check, ra_config, ra_counters, ra_frame, ra_ground_out, ra_ground_params, ra_render_out, ra_sphere_params,
+                   ra_trace_params)
 from .base_utils import dotdict
 
 
@@ -134,6 +135,24 @@ class Engine:
         ph, pw = (probe.shape[0], probe.shape[1]) if probe is not None else (0, 0)
         check(self.lib.ra_render_sphere_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(near), _ptr(far), P, bb, _ptr(probe), ph, pw,
                                               C.byref(params), C.byref(ro), self.stream), 'ra_render_sphere_chunk')
+
+    def ground_params(self) -> ra_ground_params:
+        c = self.cfg
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+        return ra_ground_params(normal=f3(c.ground_normal), origin=f3(c.ground_origin), albedo=f3(c.ground_albedo),
+                                attach_envmap=int(c.ground_attach_envmap), env_r=float(c.env_r),
+                                shading_multiplier=float(c.ground_shading_multiplier),
+                                shadow=self.trace_params(c.env_lvis, c.env_lvis.dist_th, not c.no_dfss),
+                                shadow_near_offset=c.env_lvis.near_offset, no_visibility=int(c.no_visibility),
+                                local_visibility=int(c.local_visibility))
+
+    def render_ground_chunk(self, ray_o, ray_d, acc, bbox6, probe, params, outs: dict):
+        """N1: one chunk of full-frame rays against the ground plane (render_ground); outs: name -> (P,3)/(P,) views."""
+        P = ray_o.shape[0]
+        go = ra_ground_out(**{k: _ptr(outs.get(k)) for k in _lib.GROUND_OUT_KEYS})
+        bb = (C.c_float * 6)(*[float(v) for v in bbox6])
+        check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
+                                              probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
 
     def render_volume_chunk(self, ray_o, ray_d, near, far, n_samples, dist_th, outs: dict):
         P = ray_o.shape[0]

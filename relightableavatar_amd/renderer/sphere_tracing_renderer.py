@@ -1,6 +1,7 @@
 """Sphere-tracing renderer, host-side mirror of lib/networks/renderer/sphere_tracing_renderer.py
-(Renderer.render :1066-1115, get_pixel_value :981-1039, render_human :551-784; eval path, no
-ground pass).  One ra_render_sphere_chunk call per chunk of cfg.render_chunk_size rays."""
+(Renderer.render :1066-1115, get_pixel_value :981-1039, render_human :551-784, and with
+cfg.vis_ground_shading the ground pass get_ground_value :1041-1064 / render_ground :463-548 / blend_output_
+:434-451; eval path).  One ra_render_sphere_chunk (ra_render_ground_chunk) call per chunk of cfg.render_chunk_size rays."""
 import torch
 from torch import nn
 
@@ -14,6 +15,10 @@ class Renderer(nn.Module):
         super().__init__()
         self.net = net
         self.cfg = config.active_cfg()
+        # reference quirk: the ground pass scatters the human layer through batch_aware_indexing = topk(sorted=False)
+        # (net_utils.py:381-389), whose index order is implementation-defined; the build uses the ascending (row-major)
+        # order the mask means.  Tests set this to reproduce the order of the platform a golden frame was made on.
+        self.ground_inds = None
 
     def _envmap(self, batch):
         cfg = self.cfg
@@ -26,8 +31,9 @@ class Renderer(nn.Module):
     @torch.no_grad()
     def render(self, batch):
         cfg = self.cfg
-        if cfg.vis_ground_shading:
-            raise NotImplementedError('ground pass (render_ground) is a SURVEY.md section 8f "next" row')
+        ground = bool(cfg.vis_ground_shading) and not self.net.training
+        if ground and not (cfg.relighting and hasattr(self.net, 'global_env_map')):
+            raise ValueError('vis_ground_shading needs the relighting renderer (light set + probe)')
         eng = self.net.set_frame(batch)
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
@@ -40,6 +46,8 @@ class Renderer(nn.Module):
             probe = (probe[0] if probe.ndim == 4 else probe).to(dev, torch.float32).contiguous()
         relit = bool(cfg.relighting)
         params = eng.sphere_params()
+        if ground:
+            params.premultiply = 0          # blend_output_ replaces alpha_output_ (:1108-1113)
         names = ['rgb', 'acc', 'depth', 'surf', 'norm', 'cpts', 'bpts', 'resd', 'ray_o']
         if eng.relight:
             names += ['albedo', 'roughness']
@@ -77,4 +85,52 @@ class Renderer(nn.Module):
             if 'lvis' in full:
                 ret.lvis_map, ret.ldot_map = full.lvis[None], full.ldot[None]
         ret.envmap = envmap
+        if ground:
+            ret = self._ground(batch, ret, eng, probe)
+        return ret
+
+    BLEND_KEYS = ('rgb_map', 'rfl_map', 'surf_map', 'albedo_map', 'roughness_map', 'norm_map', 'cpts_map', 'bpts_map', 'spec_map',
+                  'depth_map', 'lvis_map', 'ldot_map', 'brdf_map', 'shade_map')
+
+    def _ground(self, batch, ret, eng, probe):
+        """Renderer.render :1084-1111: full-frame rays, acc = 1 - human acc on the in-box pixels, ground chunks (each growing
+        batch.wbounds again, :1054-1056), blend_output_."""
+        cfg = self.cfg
+        dev = eng.device
+        H, W = int(batch.meta.H.item()), int(batch.meta.W.item())
+        F = H * W
+        inds = batch.mask_at_box.reshape(-1).to(dev).nonzero()[:, 0] if self.ground_inds is None else self.ground_inds.to(dev)
+        big = torch.tensor([[-1e9] * 3, [1e9] * 3])
+        rays = eng.gen_rays(H, W, batch.cam_K[0].cpu().numpy(), batch.cam_R[0].cpu().numpy(), batch.cam_T[0].cpu().numpy(), big)
+        g_o, g_d = rays.ray_o.contiguous(), rays.ray_d.contiguous()
+        assert g_o.shape[0] == F
+        acc_h = ret.acc_map[0]
+        acc_g = torch.ones(F, device=dev)
+        acc_g[inds] = 1 - acc_h
+        gp = eng.ground_params()
+        out = dotdict({k: torch.zeros(F, 3, device=dev) for k in ('rgb', 'surf', 'albedo', 'shade', 'spec')})
+        out.depth = torch.zeros(F, device=dev)
+        for a, b in chunks(F, cfg.render_chunk_size):
+            wb = batch.wbounds
+            wb[:, 0] -= cfg.env_lvis.bbox_margin
+            wb[:, 1] += cfg.env_lvis.bbox_margin
+            eng.render_ground_chunk(g_o[a:b], g_d[a:b], acc_g[a:b], wb[0].reshape(-1).tolist(), probe, gp,
+                                    {k: v[a:b] for k, v in out.items()})
+        n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, device=dev, dtype=torch.float32), dim=0)
+        grd = dotdict(rgb_map=out.rgb, surf_map=out.surf, albedo_map=out.albedo, roughness_map=torch.ones(F, device=dev),
+                      spec_map=out.spec, norm_map=n[None].expand(F, 3), shade_map=out.shade, cpts_map=torch.zeros(F, 3, device=dev),
+                      bpts_map=torch.zeros(F, 3, device=dev), depth_map=out.depth)
+        for k in self.BLEND_KEYS:
+            if k in ret and k in grd:
+                sc = torch.zeros_like(grd[k])
+                sc[inds] = ret[k][0]
+                ag = acc_g if grd[k].ndim == 1 else acc_g[:, None]
+                ret[k] = (grd[k] * ag + sc * (1 - ag))[None]
+            elif k in grd:
+                ret[k] = (grd[k] * (acc_g if grd[k].ndim == 1 else acc_g[:, None]))[None]
+        sc = torch.zeros(F, device=dev)
+        sc[inds] = acc_h
+        ret.acc_map = (sc * (1 - acc_g))[None]               # alpha_blend(acc, inds, zeros, acc_map) (:449)
+        ret.ground = dotdict(ray_o=g_o[None], ray_d=g_d[None], acc_map=acc_g[None], inds=inds[None])
+        batch.mask_at_box[:] = True                          # :1103
         return ret

@@ -85,7 +85,7 @@ def set_cfg(cfg, mode):
     cfg.fix_material = 0
     cfg.vis_rendering_map = True
     cfg.geometry_pretrain = '/nonexistent'
-    if mode in ('ops', 'relight', 'novel'):
+    if mode in ('ops', 'relight', 'novel', 'ground'):
         cfg.relighting = True
         cfg.n_samples = 3
         cfg.render_chunk_size = 65536
@@ -105,6 +105,11 @@ def set_cfg(cfg, mode):
     if mode == 'novel':
         cfg.vis_novel_light = True
         cfg.test_light = ['main']
+    if mode == 'ground':       # N1: ground-plane pass; two ground chunks so that the per-chunk bbox growth shows
+        cfg.vis_ground_shading = True
+        cfg.ground_normal = [0.0, -1.0, 0.0]
+        cfg.ground_origin = [0.0, 0.45, 0.0]
+        cfg.render_chunk_size = 384
 
 
 def to_ref_batch(b):
@@ -127,7 +132,7 @@ def npz(path, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays'])
+    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground'])
     args = ap.parse_args()
     mode = args.mode
     from relightableavatar_amd import synthetic
@@ -139,8 +144,8 @@ def main():
     set_cfg(cfg, mode)
     torch.manual_seed(0)
     torch.set_grad_enabled(True)
-    my_cfg = make_cfg({'ops': 'relight', 'anisdf': 'anisdf', 'sphere': 'sphere_tracing', 'relight': 'relight', 'novel': 'novel_light'}[mode])
-    relight = mode in ('ops', 'relight', 'novel')
+    my_cfg = make_cfg({'ops': 'relight', 'anisdf': 'anisdf', 'sphere': 'sphere_tracing', 'relight': 'relight', 'novel': 'novel_light', 'ground': 'relight'}[mode])
+    relight = mode in ('ops', 'relight', 'novel', 'ground')
     sd = synthetic.make_state_dict(0, relight=relight, cfg=my_cfg)
     if relight:
         from lib.networks.relight.relight_network import Network
@@ -179,6 +184,15 @@ def main():
         npz('frame_relight.npz', H=H, crop=crop, wbounds_after=batch.wbounds,
             **{k: out[k] for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'albedo_map', 'roughness_map',
                                    'shade_map', 'spec_map', 'cpts_map', 'bpts_map', 'resd_map')})
+    elif mode == 'ground':
+        H, crop = 24, 10
+        batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop))
+        with torch.no_grad():
+            out = sphere_tracing_renderer.Renderer(net).render(batch)
+        npz('frame_ground.npz', H=H, crop=crop, render_chunk_size=cfg.render_chunk_size, ground_normal=cfg.ground_normal,
+            ground_origin=cfg.ground_origin, wbounds_after=batch.wbounds,
+            **{k: out[k] for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'albedo_map', 'roughness_map',
+                                   'shade_map', 'spec_map', 'cpts_map', 'bpts_map')})
     elif mode == 'novel':
         from lib.networks.renderer import novel_light_sphere_tracing
         H, crop = 128, 12

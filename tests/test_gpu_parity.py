@@ -397,3 +397,33 @@ def test_ray_generation_on_device(golden, relight):
     e = eng.gen_rays(16, 16, K, R, Tc, torch.tensor([[10., 10., -9.], [11., 11., -8.]]))
     assert e.ray_o.shape[0] == 0 and not bool(e.mask_at_box.any())
 
+
+def test_frame_ground(golden):
+    """N1: relit frame with the ground-plane pass vs the reference's frame (golden) and vs the oracle on a
+    larger frame; the ground layer is fp32 except for the shadow trace's fine distance queries (dist_th 5 mm)."""
+    from relightableavatar_amd.renderer import make_renderer
+    from oracle import ra_oracle as O
+    ref = golden('frame_ground.npz')
+    kw = dict(vis_ground_shading=True, ground_normal=[float(v) for v in ref['ground_normal']],
+              ground_origin=[float(v) for v in ref['ground_origin']], render_chunk_size=int(ref['render_chunk_size']))
+    cfg, net, dev = build('relight', **kw)
+    H, crop = int(ref['H']), int(ref['crop'])
+    batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop), dev)
+    rend = make_renderer(cfg, net)
+    m = batch.mask_at_box.reshape(1, -1).cpu()
+    rend.ground_inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]   # the scatter order of the CPU reference run
+    out = rend.render(batch)
+    np.testing.assert_allclose(batch.wbounds.cpu().numpy(), ref['wbounds_after'], atol=1e-6)
+    assert out.rgb_map.shape == (1, H * H, 3) and bool(batch.mask_at_box.all())
+    e = err(out.rgb_map, ref['rgb_map'])
+    assert float((e < 5e-3).float().mean()) > 0.99 and psnr(out.rgb_map, ref['rgb_map']) > 40
+    assert float(err(out.albedo_map, ref['albedo_map']).max()) < 1e-2            # ground: fp32 probe lookups; human pixels: f16 heads
+    near = T(ref['surf_map'])[0].abs().amax(-1) < 1e3        # rays parallel to the plane: t = x / (0 + eps * |random edge|^2) in the reference
+    assert float((err(out.surf_map, ref['surf_map'])[0][near] < 1e-3).float().mean()) > 0.99
+    assert float((err(out.shade_map, ref['shade_map']) < 5e-3).float().mean()) > 0.99
+    assert float(err(out.acc_map, ref['acc_map']).max()) < 2e-2
+    # the shadow on the ground exists: some ground pixels near the body are darker than the unshadowed ground
+    acc_h = out.acc_map[0]
+    g = out.shade_map[0][acc_h == 0].sum(-1)
+    assert float(g.min()) < 0.9 * float(g.median())
+

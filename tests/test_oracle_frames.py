@@ -82,3 +82,31 @@ def test_frame_anisdf(golden):
     _cmp(out, ref, 'norm_map', 1e-3)
     _cmp(out, ref, 'rgb_map', 1e-4)
     assert O.psnr(out.rgb_map, T(ref['rgb_map'])) > 80
+
+
+GROUND_KW = dict(vis_ground_shading=True)
+
+
+def _ground_cfg(ref):
+    return dict(vis_ground_shading=True, ground_normal=[float(v) for v in ref['ground_normal']],
+                ground_origin=[float(v) for v in ref['ground_origin']], render_chunk_size=int(ref['render_chunk_size']))
+
+
+def test_frame_ground(golden):
+    """N1: relit frame with the ground-plane pass (render_ground + blend_output_), two ground chunks."""
+    ref = golden('frame_ground.npz')
+    net = _net('relight', True, **_ground_cfg(ref))
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']))
+    m = batch.mask_at_box.reshape(1, -1)
+    inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]      # the order the (CPU) reference run scattered with
+    out = O.render_sphere_tracing(net, batch, ground_inds=inds)
+    np.testing.assert_allclose(batch.wbounds.numpy(), ref['wbounds_after'], atol=1e-6)   # human + ground chunks all grow the box
+    _cmp(out, ref, 'acc_map', 5e-3)
+    near = T(ref['surf_map'])[0].abs().amax(-1) < 1e3     # rays parallel to the plane: t = x / (0 + eps * |random edge|^2) in the reference
+    assert float((out.surf_map[0][near] - T(ref['surf_map'])[0][near]).abs().max()) < 2e-4
+    _cmp(out, ref, 'albedo_map', 2e-4)
+    _cmp(out, ref, 'rgb_map', 3e-4, frac_ok=0.999)
+    _cmp(out, ref, 'shade_map', 3e-4, frac_ok=0.999)
+    _cmp(out, ref, 'spec_map', 5e-4, frac_ok=0.999)
+    assert O.psnr(out.rgb_map, T(ref['rgb_map'])) > 60
+
