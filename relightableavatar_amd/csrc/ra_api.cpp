@@ -256,6 +256,7 @@ TraceState alloc_trace(ra_ctx* c, const char* pfx, int n, bool soft, int* err) {
     ts.d0 = c->buf<float>(p + "d0", n, err);
     ts.occ = c->buf<float>(p + "occ", n, err);
     ts.ot = c->buf<float>(p + "ot", n, err);
+    ts.stuck = c->buf<unsigned char>(p + "stuck", n, err);
     if (!soft) {
         ts.dt = c->buf<float>(p + "dt", n, err);
         ts.st = c->buf<float>(p + "st", n, err);
@@ -323,6 +324,12 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
     return 0;
 }
 
+// RA_NO_SKIP=1 re-queries rays that did not move / are already fully shadowed (A/B: the images must be bit-identical)
+static bool skip_enabled() {
+    static const bool on = !(getenv("RA_NO_SKIP") && atoi(getenv("RA_NO_SKIP")));
+    return on;
+}
+
 // light_visibility (sphere_tracing_renderer.py:265-344) for the hit slots of one chunk: per (slot, light) cosine and
 // visibility; rays that face the light and cross the box are sphere traced with the DFSS state machine (HOT LOOP B).
 static int light_visibility_stage(ra_ctx* c, const float* surf, const float* norm_slots, const float* acc, const int* hit_idx,
@@ -361,6 +368,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         RaySet r2{};
         r2.mode = 2; r2.o = surf; r2.t = sh.t; r2.pix = g.ray_pix; r2.light = g.ray_light; r2.ldir = c->light_dir.as<float>();
         r2.n_dev = g.ray_count;
+        r2.skip = skip_enabled() ? sh.stuck : nullptr;
         for (int it = 0; it < shadow.iters; ++it) {
             if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
             launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
@@ -415,7 +423,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     ts.near_ = near_; ts.far_ = far_;
     launch_trace_init(ts, P, nullptr, p->surface, s);
     RaySet rs{};
-    rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t;
+    rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t; rs.skip = skip_enabled() ? ts.stuck : nullptr;
     for (int it = 0; it < p->surface.iters; ++it) {
         if (hdq_pass(c, rs, P, p->surface.dist_th, 1, sdf, s)) return 1;
         launch_trace_update(ts, sdf, P, nullptr, it, p->surface, s);

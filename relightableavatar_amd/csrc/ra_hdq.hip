@@ -260,8 +260,9 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
     if (base >= n) return;               // whole block idle (uniform)
     if (blockIdx.x == 0 && threadIdx.x == 0 && out.counters) atomicAdd(&out.counters->n_coarse, (unsigned long long)n);
     const int i = base + (SPLIT == 1 ? threadIdx.x : (threadIdx.x & 63));
-    const bool live_q = i < n;
+    const bool live_q = i < n && !(rs.skip && rs.skip[i < n ? i : 0]);
     bool live = live_q;
+    if (__syncthreads_count(live_q) == 0) return;       // nothing to query in this workgroup (uniform)
     float x[3] = {0.f, 0.f, 0.f};
     if (live) ray_point(rs, i, x);
     // world -> pose: (x - Th) R   (blend_utils.py:252-261)

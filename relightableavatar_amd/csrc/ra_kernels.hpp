@@ -13,6 +13,7 @@ struct RaySet {
     const int* light;     // mode 2
     const float* ldir;    // mode 2: n_lights x 3 (unit)
     const int* n_dev;     // optional device-side count (<= n launched); nullptr -> n
+    const unsigned char* skip;   // optional: ray i did not move since its last query -> its sdf[i] is still valid, do not re-query
 };
 
 struct HdqOut {
@@ -49,6 +50,7 @@ struct TraceState {       // SoA per ray
     const float *near_, *far_;
     const float* tan_i;   // per ray (mode 1) or per light (mode 2) or nullptr -> scalar
     const int* light;     // mode 2
+    unsigned char* stuck; // ray did not move in the last update (t clamped at far / near): the next query would repeat the last one
 };
 void launch_trace_init(const TraceState& ts, int n, const int* n_dev, const ra_trace_params& p, hipStream_t s);
 void launch_trace_update(const TraceState& ts, const float* sdf, int n, const int* n_dev, int iter,

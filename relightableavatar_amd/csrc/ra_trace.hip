@@ -33,6 +33,7 @@ __global__ void trace_init_kernel(TraceState ts, int n_launch, const int* n_dev,
     ts.t[i] = nr;
     ts.d0[i] = 1e9f;
     ts.occ[i] = 1.f;
+    if (ts.stuck) ts.stuck[i] = 0;
     if (ts.dt) ts.dt[i] = 1e9f;
     if (ts.st) ts.st[i] = fr;
     if (ts.ot) ts.ot[i] = fr;
@@ -49,6 +50,7 @@ __global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf
     const float d1 = sdf[i];
     const float d0 = ts.d0[i];
     float t = ts.t[i];
+    const float t_prev = t;
     float occ = ts.occ[i];
     const float nr = ts.near_[i], fr = ts.far_[i];
     float tan_i = p.tan_i;                                   // hard shadow (sphere_tracing_renderer.py:107-110)
@@ -97,6 +99,10 @@ __global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf
     t = fmaxf(t, nr);
     if (ts.dt) ts.dt[i] = dtn;
     ts.t[i] = t;
+    // a ray clamped at far (or near) queries the same point again: the distance is already known, the state machine
+    // still runs on it (exact), only the query is skipped
+    // A shadow ray whose visibility reached 0 is decided (occ = min(occ, cls >= 0) and only occ is read back): no more queries.
+    if (ts.stuck) ts.stuck[i] = (t == t_prev || (SOFT && occ == 0.f)) ? 1 : 0;
     ts.d0[i] = d1;
     ts.occ[i] = occ;
     if (ts.ot) ts.ot[i] = ot;

@@ -427,3 +427,20 @@ def test_frame_ground(golden):
     g = out.shade_map[0][acc_h == 0].sum(-1)
     assert float(g.min()) < 0.9 * float(g.median())
 
+
+def test_query_skip_is_exact(tmp_path):
+    """rays that did not move since their last query (clamped at far/near) and shadow rays whose visibility already reached 0
+    are not re-queried: the frame (relight + ground pass) must be BIT-identical to the one rendered with RA_NO_SKIP=1"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ('1', '0'):
+        f = str(tmp_path / f'skip{flag}.pt')
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ab_skip.py'), f, 'ground'], env=dict(os.environ, RA_NO_SKIP=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
