@@ -258,62 +258,104 @@ __global__ void light_dirs_kernel(const float* __restrict__ xyz, int L, float* _
     ldir[3 * l] = x / n; ldir[3 * l + 1] = y / n; ldir[3 * l + 2] = z / n;
 }
 
-__global__ void shadow_gen_kernel(ShadowGen g) {
+// workgroup = 64 neighbouring hit slots x 32 lights; a wave handles ONE light for the 64 slots at a time (so that the
+// traced rays it emits stay neighbours in the coarse level), 8 rounds cover the 32 lights.  lvis / ldot are [slot][light]:
+// they are staged in LDS and written as whole 128-byte rows (a direct store would touch 64 cache lines per instruction).
+constexpr int SG_LIGHTS = 32;
+__global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
+    __shared__ float t_ldot[64][SG_LIGHTS + 1], t_lvis[64][SG_LIGHTS + 1];
     const int nh = *g.hit_count;
-    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
-    bool trace = false;
-    int h = 0, l = 0, r = 0;
-    float nr = 0.f, fr = 0.f;
-    // thread -> (group of 64 hit slots, light, slot in group): a wave = ONE light x 64 neighbouring pixels
-    const long long grp = k / (64LL * g.L);
-    const int rem = (int)(k - grp * 64LL * g.L);
-    l = rem >> 6;
-    h = (int)(grp * 64 + (rem & 63));
-    if (h < nh && l < g.L) {
+    const int lchunks = (g.L + SG_LIGHTS - 1) / SG_LIGHTS;
+    const int grp = blockIdx.x / lchunks, lc = blockIdx.x - grp * lchunks;
+    if (grp * 64 >= nh) return;                 // uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = grp * 64 + lane;
+    const bool hv = h < nh;
+    int r = 0;
+    float nrm[3] = {0.f, 0.f, 0.f}, o[3] = {0.f, 0.f, 0.f}, acc = 0.f;
+    if (hv) {
         r = g.hit_idx[h];
-        const float dx = g.ldir[3 * l], dy = g.ldir[3 * l + 1], dz = g.ldir[3 * l + 2];
-        const float ldot = dx * g.norm[3 * h] + dy * g.norm[3 * h + 1] + dz * g.norm[3 * h + 2];     // :292
-        const long long kk = (long long)h * g.L + l;          // output slot: [hit slot][light]
-        g.ldot[kk] = ldot;
-        float lv;
-        if (g.no_visibility) lv = 1.f;
-        else if (g.local_visibility) lv = ldot > 0.f ? 1.f : 0.f;
-        else {
-            const bool front = (ldot > 0.f) && (g.acc[r] > 0.f);                                        // :303
-            lv = 0.f;
-            if (front) {
-                // get_near_far_aabb (net_utils.py:1683-1712), tiny components -> +1e-8
-                float d[3] = {dx, dy, dz};
-                const float o[3] = {g.surf[3 * r], g.surf[3 * r + 1], g.surf[3 * r + 2]};
-                nr = -3.0e38f; fr = 3.0e38f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (d[c] < 1e-8f && d[c] > -1e-16f) d[c] = 1e-8f;
-                    const float t0 = (g.bbox[c] - o[c]) / d[c], t1 = (g.bbox[3 + c] - o[c]) / d[c];
-                    nr = fmaxf(nr, fminf(t0, t1));
-                    fr = fminf(fr, fmaxf(t0, t1));
-                }
-                nr = fmaxf(nr, g.near_offset);                                                          // :311
-                fr = fmaxf(fr, g.near_offset);
-                trace = nr < fr;
-                lv = 1.f;           // outside the box: visible (:341); traced rays are overwritten later
-            }
-        }
-        g.lvis[kk] = lv;
+        nrm[0] = g.norm[3 * h]; nrm[1] = g.norm[3 * h + 1]; nrm[2] = g.norm[3 * h + 2];
+        o[0] = g.surf[3 * r]; o[1] = g.surf[3 * r + 1]; o[2] = g.surf[3 * r + 2];
+        acc = g.acc[r];
     }
-    const unsigned long long m = __ballot(trace);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(g.ray_count, __popcll(m));
-    base = __shfl(base, 0);
-    if (trace) {
-        const int s = base + __popcll(m & ((1ull << lane) - 1ull));
-        g.ray_pix[s] = r;
-        g.ray_light[s] = l;
-        g.ray_slot[s] = h * g.L + l;
-        g.near_[s] = nr;
-        g.far_[s] = fr;
+    constexpr int ROUNDS = SG_LIGHTS / (TPB / 64);
+    __shared__ int cnt[ROUNDS * (TPB / 64) + 1];
+    float nrv[ROUNDS], frv[ROUNDS];
+    unsigned tmask = 0;
+#pragma unroll
+    for (int round = 0; round < ROUNDS; ++round) {
+        const int ll = round * (TPB / 64) + wv;            // light within the chunk (wave-uniform)
+        const int l = lc * SG_LIGHTS + ll;
+        bool trace = false;
+        float nr = 0.f, fr = 0.f;
+        if (hv && l < g.L) {
+            const float dx = g.ldir[3 * l], dy = g.ldir[3 * l + 1], dz = g.ldir[3 * l + 2];
+            const float ldot = dx * nrm[0] + dy * nrm[1] + dz * nrm[2];                                   // :292
+            float lv;
+            if (g.no_visibility) lv = 1.f;
+            else if (g.local_visibility) lv = ldot > 0.f ? 1.f : 0.f;
+            else {
+                const bool front = (ldot > 0.f) && (acc > 0.f);                                           // :303
+                lv = 0.f;
+                if (front) {
+                    // get_near_far_aabb (net_utils.py:1683-1712), tiny components -> +1e-8
+                    float d[3] = {dx, dy, dz};
+                    nr = -3.0e38f; fr = 3.0e38f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (d[c] < 1e-8f && d[c] > -1e-16f) d[c] = 1e-8f;
+                        const float t0 = (g.bbox[c] - o[c]) / d[c], t1 = (g.bbox[3 + c] - o[c]) / d[c];
+                        nr = fmaxf(nr, fminf(t0, t1));
+                        fr = fminf(fr, fmaxf(t0, t1));
+                    }
+                    nr = fmaxf(nr, g.near_offset);                                                        // :311
+                    fr = fmaxf(fr, g.near_offset);
+                    trace = nr < fr;
+                    lv = 1.f;           // outside the box: visible (:341); traced rays are overwritten later
+                }
+            }
+            t_ldot[lane][ll] = ldot;
+            t_lvis[lane][ll] = lv;
+        }
+        nrv[round] = nr; frv[round] = fr;
+        if (trace) tmask |= 1u << round;
+        const unsigned long long m = __ballot(trace);
+        if (lane == 0) cnt[ll] = __popcll(m);
+    }
+    __syncthreads();
+    // ONE atomic per workgroup for the traced-ray list (same-address atomics serialise: per wave they were the whole kernel
+    // time); a wave's rays (one light x 64 neighbouring slots) stay contiguous
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < ROUNDS * (TPB / 64); ++k) { const int c = cnt[k]; cnt[k] = tot; tot += c; }
+        cnt[ROUNDS * (TPB / 64)] = tot ? atomicAdd(g.ray_count, tot) : 0;
+    }
+    __syncthreads();
+    const int gbase = cnt[ROUNDS * (TPB / 64)];
+#pragma unroll
+    for (int round = 0; round < ROUNDS; ++round) {
+        const int ll = round * (TPB / 64) + wv;
+        const bool trace = (tmask >> round) & 1u;
+        const unsigned long long m = __ballot(trace);
+        if (trace) {
+            const int s = gbase + cnt[ll] + __popcll(m & ((1ull << lane) - 1ull));
+            const int l = lc * SG_LIGHTS + ll;
+            g.ray_pix[s] = r;
+            g.ray_light[s] = l;
+            g.ray_slot[s] = h * g.L + l;
+            g.near_[s] = nrv[round];
+            g.far_[s] = frv[round];
+        }
+    }
+    // rows of 32 lights: thread t -> (row = t / 32 + 8 k, light = t % 32)
+    const int col = threadIdx.x & (SG_LIGHTS - 1), l = lc * SG_LIGHTS + col;
+    for (int row = threadIdx.x / SG_LIGHTS; row < 64; row += TPB / SG_LIGHTS) {
+        const int hh = grp * 64 + row;
+        if (hh < nh && l < g.L) {
+            g.ldot[(size_t)hh * g.L + l] = t_ldot[row][col];
+            g.lvis[(size_t)hh * g.L + l] = t_lvis[row][col];
+        }
     }
 }
 
@@ -613,7 +655,8 @@ void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s) {
     hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
     if (P <= 0) return;
     const long long groups = ((long long)P + 63) / 64;
-    hipLaunchKernelGGL(shadow_gen_kernel, grid_for(groups * 64 * g.L), dim3(TPB), 0, s, g);
+    const int lchunks = (g.L + SG_LIGHTS - 1) / SG_LIGHTS;
+    hipLaunchKernelGGL(shadow_gen_kernel, dim3((unsigned)(groups * lchunks)), dim3(TPB), 0, s, g);
 }
 
 // ------------------------------------------------------------------------------------------ N1: ground plane
