@@ -250,9 +250,10 @@ __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
 // workgroup serve the SAME 64 queries and share out the opened super boxes; their three-bests are merged through LDS.
 // Each wave prunes against its own (weaker) bound, which is still conservative, so the merged result is exact.
 template <bool BVH, int SPLIT>
-__global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
+__global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
                                                                   HdqOut out, int dbg) {
-    static_assert(SPLIT == 1 || (BVH && SPLIT == KNN_THREADS / 64), "SPLIT is all waves of the workgroup or none");
+    static_assert(SPLIT == 1 || (BVH && SPLIT >= 2 && SPLIT <= 16), "SPLIT > 1: the workgroup is SPLIT waves on the same 64 queries");
+    constexpr int NT = SPLIT == 1 ? KNN_THREADS : 64 * SPLIT;      // threads per workgroup
     // BVH: super + leaf boxes (2 float4 each); brute force: a vertex tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? (BVH_MAXS + BVH_MAXL) * 32 : VT * 16];
     const int n = rs.n_dev ? min(*rs.n_dev, n_launch) : n_launch;
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
         float4* sb = reinterpret_cast<float4*>(smem);                 // [ns][2] then [nl][2]
         const int nl = fr.bvh_leaves, ns = fr.bvh_supers;
         float4* lbx = sb + 2 * ns;
-        for (int j = threadIdx.x; j < 2 * ns; j += KNN_THREADS) sb[j] = fr.bvh_sbox[j];
-        for (int j = threadIdx.x; j < 2 * nl; j += KNN_THREADS) lbx[j] = fr.bvh_lbox[j];
+        for (int j = threadIdx.x; j < 2 * ns; j += NT) sb[j] = fr.bvh_sbox[j];
+        for (int j = threadIdx.x; j < 2 * nl; j += NT) lbx[j] = fr.bvh_lbox[j];
         __syncthreads();
         if (!live) { d0 = d1 = d2 = -1.f; }            // idle lanes: every test fails, nothing is inserted
         const unsigned long long lm = __ballot(live);
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
             }
         }
         if (SPLIT > 1) {
-            __shared__ float md[KNN_THREADS / 64 - 1][3][64];
-            __shared__ int mi[KNN_THREADS / 64 - 1][3][64];
+            __shared__ float md[SPLIT > 1 ? SPLIT - 1 : 1][3][64];
+            __shared__ int mi[SPLIT > 1 ? SPLIT - 1 : 1][3][64];
             const int wv = threadIdx.x >> 6;
             if (wv > 0) {
                 md[wv - 1][0][lane] = d0; md[wv - 1][1][lane] = d1; md[wv - 1][2][lane] = d2;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
             __syncthreads();
             if (wv == 0) {
 #pragma unroll
-                for (int w = 0; w < KNN_THREADS / 64 - 1; ++w)
+                for (int w = 0; w < SPLIT - 1; ++w)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         // every wave scanned the seed leaf (for its bound): a vertex may come back more than once
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
     }
     // compaction: one atomic per workgroup (same-address atomics serialise in L2: per wave they cost as much as the
     // whole post-processing), wave offsets through LDS
-    __shared__ int wcount[KNN_THREADS / 64 + 1];
+    __shared__ int wcount[NT / 64 + 1];
     const unsigned long long m = __ballot(fine);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) wcount[wv] = __popcll(m);
@@ -428,12 +429,12 @@ __global__ __launch_bounds__(KNN_THREADS) void hdq_coarse_kernel(FrameState fr, 
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
-        for (int w = 0; w < KNN_THREADS / 64; ++w) { const int cnt = wcount[w]; wcount[w] = tot; tot += cnt; }
-        wcount[KNN_THREADS / 64] = (dbg & 8) ? base : (tot ? atomicAdd(out.fine_count, tot) : 0);
+        for (int w = 0; w < NT / 64; ++w) { const int cnt = wcount[w]; wcount[w] = tot; tot += cnt; }
+        wcount[NT / 64] = (dbg & 8) ? base : (tot ? atomicAdd(out.fine_count, tot) : 0);
     }
     __syncthreads();
     if (!fine || (dbg & 16)) return;
-    const int slot = wcount[KNN_THREADS / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
+    const int slot = wcount[NT / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
     // gaussian-weighted blend of the per-vertex transforms (base_network.py:287-296)
     float w[3], ws = 0.f;
 #pragma unroll
@@ -518,7 +519,13 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
         const int d = pass == 0 ? probe : dbg;
         if (fr.bvh_leaves > 0 && n <= split_max)
-            hipLaunchKernelGGL((hdq_coarse_kernel<true, KNN_THREADS / 64>), dim3((n + 63) / 64), dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
+        {
+            // more waves per 64 queries the smaller the launch (about 4-8 k waves in flight on the 1024 SIMDs)
+            const int groups = (n + 63) / 64;
+            if (n <= split_max / 8) hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
+            else if (n <= split_max / 2) hipLaunchKernelGGL((hdq_coarse_kernel<true, 8>), dim3(groups), dim3(512), 0, s, fr, rs, n, th, inv2r2, out, d);
+            else hipLaunchKernelGGL((hdq_coarse_kernel<true, 4>), dim3(groups), dim3(256), 0, s, fr, rs, n, th, inv2r2, out, d);
+        }
         else if (fr.bvh_leaves > 0) hipLaunchKernelGGL((hdq_coarse_kernel<true, 1>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
         else hipLaunchKernelGGL((hdq_coarse_kernel<false, 1>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
         if (pass == 0) hipMemsetAsync(out.fine_count, 0, sizeof(int), s);
