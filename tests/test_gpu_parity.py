@@ -350,6 +350,39 @@ def test_errors_are_python_exceptions():
         eng.hdq_sdf(torch.zeros(4, 3, device=dev), 0.1, True)
     with pytest.raises(_lib.RaError, match='missing'):
         eng.load_state_dict({'residual_deformation_network.mlp.linears.0.weight': torch.zeros(256, 219)})
+    K, R, Tc = synthetic.make_camera(16, 16)
+    with pytest.raises(_lib.RaError, match='bad image size'):
+        eng.gen_rays(0, 16, K, R, Tc, torch.tensor([[-1., -1., -1.], [1., 1., 1.]]))
+    # the ground pass needs a finalised relight network, and refuses chunks whose (pixel x light) count overflows an int
+    with pytest.raises(_lib.RaError, match='weights not finalized'):
+        z3 = torch.zeros(4, 3, device=dev)
+        eng.render_ground_chunk(z3, z3, torch.ones(4, device=dev), [-1, -1, -1, 1, 1, 1], torch.ones(16, 32, 3, device=dev),
+                                eng.ground_params(), {})
+
+
+def test_ground_pass_edge_cases(relight):
+    """ground chunks: nothing to trace (acc = 0 everywhere) gives zeros; rays looking away from the plane get no ground"""
+    cfg, net, dev, body, eng = relight
+    P = 300
+    g = torch.Generator().manual_seed(3)
+    ro = torch.tensor([0., 0., -2.], device=dev).expand(P, 3).contiguous()
+    rd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    probe = net.global_env_map.to(dev, torch.float32).contiguous()
+    gp = eng.ground_params()
+    gp.normal[0], gp.normal[1], gp.normal[2] = 0.0, -1.0, 0.0
+    gp.origin[0], gp.origin[1], gp.origin[2] = 0.0, 0.45, 0.0
+    bbox = [-0.7, -0.7, -0.7, 0.7, 0.7, 0.7]
+    outs = {k: torch.full((P, 3), 7.0, device=dev) for k in ('rgb', 'surf', 'albedo', 'shade', 'spec')}
+    outs['depth'] = torch.full((P,), 7.0, device=dev)
+    eng.render_ground_chunk(ro, rd, torch.zeros(P, device=dev), bbox, probe, gp, outs)
+    assert float(outs['rgb'].abs().max()) == 0.0 and float(outs['shade'].abs().max()) == 0.0        # no pixel to trace
+    eng.render_ground_chunk(ro, rd, torch.ones(P, device=dev), bbox, probe, gp, outs)
+    assert torch.isfinite(outs['rgb']).all() and float(outs['rgb'].min()) >= 0.0
+    up = rd[:, 1] < 0                                    # looking away from the plane (y = 0.45, normal -y): t <= 0
+    assert bool((outs['depth'][up] <= 0).all())
+    # beyond env_r the ground fades into the unshadowed light sum: identical shade for all far / upward pixels
+    far = outs['shade'][up]
+    assert float((far - far[0]).abs().max()) < 1e-5
 
 
 @pytest.mark.gpu
