@@ -230,6 +230,15 @@ int ra_render_ground_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, 
 int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
                 void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream);
 
+/* ---- N4: environment-map rotation and the light-probe inset -------------------------------------
+ * ra_shift_envmap: rotate_envmap's shift_image (lib/utils/relight_utils.py:69-85): out[y][x] = bilinear sample of img at
+ * x + 0.5 + shift (wrapped modulo W; grid_sample align_corners=False, border padding), img/out: (H,W,C) device fp32.
+ * ra_add_light_probe: add_light_probe (relight_utils.py:38-54 with gen_light_dir :9-35): overwrites the top-left uH x uW
+ * pixels of rgb (H,W,3) with the probe seen along the camera's horizontal heading; cam_R: 9 host floats (world-to-camera). */
+int ra_shift_envmap(ra_ctx* ctx, const float* img, int H, int W, int C, float shift, float* out, void* stream);
+int ra_add_light_probe(ra_ctx* ctx, float* rgb, int H, int W, const float* probe, int ph, int pw, const float* cam_R, int uH, int uW,
+                       void* stream);
+
 /* ---- test hooks: stage outputs for the parity tests (tests/test_gpu_*.py); not used by renderers ---- */
 /* resd + sdf MLPs on given big-pose points: resd n x 3, sdf n, feat n x 256 (any may be NULL) */
 int ra_debug_mlp(ra_ctx* ctx, const float* bpts_dev, int n, float* resd, float* sdf, float* feat, void* stream);

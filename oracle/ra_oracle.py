@@ -138,6 +138,53 @@ def sample_envmap_image(image: torch.Tensor, ray_d: torch.Tensor):
     return rgb[0, :, 0].permute(1, 0).reshape(sh)
 
 
+def shift_envmap(image: torch.Tensor, shift: float):
+    """rotate_envmap's shift_image (relight_utils.py:69-85): horizontal float shift with wrap-around, bilinear
+    (grid_sample align_corners=False, border padding).  image (H,W,C) -> (H,W,C)."""
+    H, W = image.shape[:2]
+    i, j = torch.meshgrid(torch.arange(0, H), torch.arange(0, W), indexing='ij')
+    gx = (j.float() + 0.5 + shift) % W
+    grid = torch.stack([gx / W * 2 - 1, (i.float() + 0.5) / H * 2 - 1], dim=-1)[None]
+    return F.grid_sample(image.permute(2, 0, 1)[None], grid, align_corners=False, mode='bilinear', padding_mode='border')[0].permute(1, 2, 0)
+
+
+def rotate_envmap(novel_lights, index, repeat, probe_width):
+    """rotate_envmap relight_utils.py:57-103 (probe only): (name, rotated probe (eH,eW,3))."""
+    keys = list(novel_lights.keys())
+    pr = lambda e: e['probe'][0] if e['probe'].ndim == 4 else e['probe']
+    if repeat <= 0:
+        return keys[index], pr(novel_lights[keys[index]])
+    n_rotation = probe_width * repeat
+    i, j = index // n_rotation, index % n_rotation
+    probe = pr(novel_lights[keys[i]])
+    eW = probe.shape[1]
+    return f'{keys[i]}-{j:04d}', shift_envmap(probe, eW / (eW * repeat) * j)
+
+
+def probe_axes(cam_R):
+    """gen_light_dir relight_utils.py:9-30: camera axes with only the horizontal rotation kept (world z is up/down), then
+    the probe's axis convention (y <- -front, z <- -down).  cam_R: (3,3) world-to-camera.  Returns the 3x3 whose columns
+    are the axes the probe directions are expressed in."""
+    R = cam_R.clone().mT.clone()
+    front = R[:, 2].clone()
+    down = torch.zeros(3, dtype=R.dtype)
+    down[2] = torch.sign(R[2, 1])
+    right = normalize(torch.cross(down, front, dim=0))
+    front = normalize(torch.cross(right, down, dim=0))
+    return torch.stack([right, -front, -down], dim=1)
+
+
+def add_light_probe(rgb, probe, H, W, cam_R, env_h, env_w, probe_size_ratio):
+    """add_light_probe relight_utils.py:38-54 (+ gen_light_dir :26-35): the probe, seen along the camera axes, is pasted
+    into the top-left corner.  rgb (H*W,3) -> (H*W,3)."""
+    uW = int(W * probe_size_ratio)
+    uH = int(uW * env_h / env_w)
+    ray_d = normalize(gen_light_xyz(uH, uW, 10.0)[0]) @ probe_axes(cam_R).mT
+    out = rgb.reshape(H, W, 3).clone()
+    out[:uH, :uW] = sample_envmap_image(probe, ray_d)
+    return out.reshape(H * W, 3)
+
+
 def safe_divide(a, b, eps=1e-8):
     """relight_utils.py:618-633 — mutates its arguments IN PLACE exactly like the reference."""
     a[(a < eps) & (a >= 0)] = eps

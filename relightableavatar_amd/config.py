@@ -102,6 +102,9 @@ def default_cfg() -> dotdict:
     c.replace_light = ''
     c.test_light = ['main']
     c.vis_rotate_light = False
+    c.rotate_ratio = 4            # config.py:350
+    c.probe_size_ratio = 0.2      # config.py:354
+    c.env_image_w = 2048
     # build-side knobs (not in the reference)
     c.mlp_dtype = 'f16'          # element type of the fused MLP kernels: 'f16' or 'bf16' (fp32 accumulate either way)
     return c

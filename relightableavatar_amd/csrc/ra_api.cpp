@@ -639,6 +639,38 @@ int ra_set_knn_mode(ra_ctx* c, int use_bvh) {
     return 0;
 }
 
+int ra_shift_envmap(ra_ctx* c, const float* img, int H, int W, int C, float shift, float* out, void* stream) {
+    RA_CHECK(c, "ra_shift_envmap: null ctx");
+    RA_CHECK(img && out && H > 0 && W > 0 && C > 0 && img != out, "ra_shift_envmap: bad arguments");
+    RA_HIP(hipSetDevice(c->device));
+    launch_shift_envmap(img, H, W, C, shift, out, (hipStream_t)stream);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_add_light_probe(ra_ctx* c, float* rgb, int H, int W, const float* probe, int ph, int pw, const float* cam_R, int uH, int uW,
+                       void* stream) {
+    RA_CHECK(c, "ra_add_light_probe: null ctx");
+    RA_CHECK(rgb && probe && cam_R && H > 0 && W > 0 && ph > 0 && pw > 0, "ra_add_light_probe: bad arguments");
+    RA_CHECK(uH >= 0 && uW >= 0 && uH <= H && uW <= W, "ra_add_light_probe: the inset does not fit the image");
+    RA_HIP(hipSetDevice(c->device));
+    // gen_light_dir (relight_utils.py:9-30): camera axes (columns of R^T) with only the horizontal heading kept
+    const double front0[3] = {cam_R[6], cam_R[7], cam_R[8]};             // third row of the w2c rotation = camera z in the world
+    const double downz = cam_R[5] > 0 ? 1.0 : (cam_R[5] < 0 ? -1.0 : 0.0);   // sign of (camera y).z
+    const double down[3] = {0.0, 0.0, downz};
+    auto cross = [](const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    auto norml = [](double* v) { const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-8; v[0] /= n; v[1] /= n; v[2] /= n; };
+    double right[3], front[3];
+    cross(down, front0, right); norml(right);
+    cross(right, down, front); norml(front);
+    ProbeInset p{};
+    for (int r = 0; r < 3; ++r) { p.axes[3 * r] = (float)right[r]; p.axes[3 * r + 1] = (float)-front[r]; p.axes[3 * r + 2] = (float)-down[r]; }
+    p.H = H; p.W = W; p.uH = uH; p.uW = uW; p.ph = ph; p.pw = pw;
+    launch_light_probe(p, probe, rgb, (hipStream_t)stream);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
 static void inv3x3(const double* m, double* o) {
     const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);

@@ -159,3 +159,8 @@ struct GroundShade {
 };
 void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_t s);
 
+// N4: envmap rotation + light-probe inset (ra_trace.hip)
+void launch_shift_envmap(const float* img, int H, int W, int C, float shift, float* out, hipStream_t s);
+struct ProbeInset { float axes[9]; int H, W, uH, uW, ph, pw; };     // axes: columns = right, -front, -down (gen_light_dir)
+void launch_light_probe(const ProbeInset& p, const float* probe, float* rgb, hipStream_t s);
+

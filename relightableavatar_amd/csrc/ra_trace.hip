@@ -741,6 +741,59 @@ void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_
     hipLaunchKernelGGL(ground_shade_kernel, grid_for((long long)in.g.P * 64), dim3(TPB), 0, s, in, cfg);
 }
 
+// ------------------------------------------------------------------------------------------ N4: envmap utilities
+// shift_image (relight_utils.py:69-85): grid x = ((j + 0.5 + shift) mod W) / W * 2 - 1, grid_sample(align_corners=False, border)
+__global__ void shift_envmap_kernel(const float* __restrict__ img, int H, int W, int C, float shift, float* __restrict__ out) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= H * W) return;
+    const int y = k / W, x = k - y * W;
+    float gx = fmodf((float)x + 0.5f + shift, (float)W);
+    if (gx < 0.f) gx += (float)W;                        // python's % is non-negative
+    gx = gx / (float)W * 2.f - 1.f;
+    float ix = ((gx + 1.f) * W - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    const float fx = floorf(ix);
+    const int x0 = (int)fx, x1 = x0 + 1;
+    const float w1 = ix - fx, w0 = 1.f - w1;
+    for (int c = 0; c < C; ++c) {
+        float v = w0 * img[((size_t)y * W + x0) * C + c];
+        if (x1 < W) v += w1 * img[((size_t)y * W + x1) * C + c];
+        out[(size_t)k * C + c] = v;
+    }
+}
+
+// add_light_probe (relight_utils.py:38-54): pixel (y, x) of the inset looks along gen_light_xyz(uH, uW)[y][x] (relight_utils.py:423-465)
+// rotated into the world by the probe axes of gen_light_dir
+__global__ void light_probe_kernel(ProbeInset p, const float* __restrict__ probe, float* __restrict__ rgb) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= p.uH * p.uW) return;
+    const int y = k / p.uW, x = k - y * p.uW;
+    const float lat_half = PI_F / p.uH / 2.f, lng_half = 2.f * PI_F / p.uW / 2.f;
+    // torch.linspace(a, b, n)[i]: a + i * step for the first half, b - (n - 1 - i) * step for the second
+    auto lin = [](float a, float b, int n, int i) { const float st = (b - a) / (float)(n - 1); return i < n / 2 ? a + i * st : b - (n - 1 - i) * st; };
+    const float lat = p.uH > 1 ? lin(PI_F / 2.f - lat_half, -PI_F / 2.f + lat_half, p.uH, y) : PI_F / 2.f - lat_half;
+    const float lng = p.uW > 1 ? lin(PI_F - lng_half, -PI_F + lng_half, p.uW, x) : PI_F - lng_half;
+    float v[3] = {cosf(lat) * cosf(lng), cosf(lat) * sinf(lng), sinf(lat)};
+    const float nn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-8f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = (v[0] * p.axes[3 * r] + v[1] * p.axes[3 * r + 1] + v[2] * p.axes[3 * r + 2]) / nn;   // v @ axes^T
+    float c[3];
+    sample_probe(probe, p.ph, p.pw, d, c);
+    float* o = rgb + ((size_t)y * p.W + x) * 3;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+}
+
+void launch_shift_envmap(const float* img, int H, int W, int C, float shift, float* out, hipStream_t s) {
+    if (H * W <= 0) return;
+    hipLaunchKernelGGL(shift_envmap_kernel, grid_for(H * W), dim3(TPB), 0, s, img, H, W, C, shift, out);
+}
+
+void launch_light_probe(const ProbeInset& p, const float* probe, float* rgb, hipStream_t s) {
+    if (p.uH * p.uW <= 0) return;
+    hipLaunchKernelGGL(light_probe_kernel, grid_for(p.uH * p.uW), dim3(TPB), 0, s, p, probe, rgb);
+}
+
 // ------------------------------------------------------------------------------------------ N2: ray generation
 // one pixel's ray and box interval (data_utils.py:827-845, 860-875): direction in fp64, rounded once; the rest fp32
 __device__ __forceinline__ bool pixel_ray(const RayCam& c, int pix, float o[3], float d[3], float& nr, float& fr) {

@@ -208,6 +208,26 @@ class Engine:
         P = cnt.value
         return dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(int(H), int(W)).bool())
 
+    def shift_envmap(self, image, shift):
+        """N4: rotate_envmap's shift_image: (H,W,C) or (1,H,W,C) -> same shape, shifted `shift` pixels with wrap-around."""
+        x = _f32(image, self.device)
+        lead = x.shape[:-3]
+        x3 = x.reshape(x.shape[-3:])
+        out = torch.empty_like(x3)
+        check(self.lib.ra_shift_envmap(self.ctx, _ptr(x3), x3.shape[0], x3.shape[1], x3.shape[2], float(shift), _ptr(out), self.stream),
+              'ra_shift_envmap')
+        return out.reshape(*lead, *x3.shape)
+
+    def add_light_probe(self, rgb, probe, H, W, cam_R, uH, uW):
+        """N4: add_light_probe: rgb (..., H*W, 3) gets the probe inset in its top-left uH x uW pixels (in place on a device copy)."""
+        import numpy as np
+        out = _f32(rgb, self.device).clone()
+        pr = _f32(probe[0] if probe.ndim == 4 else probe, self.device)
+        R = np.ascontiguousarray(np.asarray(cam_R.detach().cpu() if isinstance(cam_R, torch.Tensor) else cam_R, dtype=np.float32).reshape(9))
+        check(self.lib.ra_add_light_probe(self.ctx, _ptr(out), int(H), int(W), _ptr(pr), pr.shape[0], pr.shape[1],
+                                          R.ctypes.data_as(C.POINTER(C.c_float)), int(uH), int(uW), self.stream), 'ra_add_light_probe')
+        return out
+
     def enable_timing(self, on=True):
         check(self.lib.ra_enable_timing(self.ctx, int(on)), 'ra_enable_timing')
 

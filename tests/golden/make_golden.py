@@ -132,7 +132,7 @@ def npz(path, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground'])
+    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground', 'envmap'])
     args = ap.parse_args()
     mode = args.mode
     from relightableavatar_amd import synthetic
@@ -140,6 +140,9 @@ def main():
     cfg = install_reference()
     if mode == 'rays':
         gen_rays(synthetic)
+        return
+    if mode == 'envmap':
+        gen_envmap(cfg, synthetic)
         return
     set_cfg(cfg, mode)
     torch.manual_seed(0)
@@ -232,6 +235,38 @@ def gen_rays(synthetic):
                    f'{tag}_T': np.asarray(t, np.float64).reshape(3), f'{tag}_ray_o': ro, f'{tag}_ray_d': rd, f'{tag}_near': near,
                    f'{tag}_far': far, f'{tag}_mask': mask})
     npz('rays.npz', bounds=bounds, **kw)
+
+
+def gen_envmap(cfg, synthetic):
+    """N4: rotate_envmap (probe + image) and add_light_probe of the reference (lib/utils/relight_utils.py:38-103)."""
+    from lib.utils.base_utils import dotdict
+    from lib.utils import relight_utils
+    lights = synthetic.make_novel_lights(3, 0)
+    g = torch.Generator().manual_seed(3)
+    nl = dotdict()
+    for k, v in lights.items():
+        nl[k] = dotdict(probe=v.probe, image=torch.rand(1, 24, 48, 3, generator=g))
+    kw = {}
+    repeat = 4
+    for index in (0, 5, 37, 128 + 77, 2 * 128 + 127):
+        name, env = relight_utils.rotate_envmap(nl, index, repeat, 32, 48)
+        kw[f'rot{index}_probe'] = env.probe[0]
+        kw[f'rot{index}_image'] = env.image[0]
+        kw[f'rot{index}_name'] = np.array(name)
+    K, R, T = synthetic.make_camera(96, 96)
+    ax, ay = 0.35, -0.6
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    cam_R = torch.from_numpy((Rx @ Ry).astype(np.float32))[None]
+    H, W = 40, 64
+    rgb = torch.rand(1, H * W, 3, generator=g)
+    batch = dotdict(meta=dotdict(H=torch.tensor([H]), W=torch.tensor([W])), cam_R=cam_R)
+    cfg.env_h, cfg.env_w, cfg.probe_size_ratio = 16, 32, 0.2
+    _glx = relight_utils.gen_light_xyz           # its device argument defaults to 'cuda'
+    relight_utils.gen_light_xyz = lambda h, w, r=1e2, device='cpu': _glx(h, w, r, device='cpu')
+    out = relight_utils.add_light_probe(rgb.clone(), nl['probe00'].probe, batch, cfg)
+    npz('envmap.npz', repeat=repeat, images=torch.stack([nl[k].image[0] for k in nl]), cam_R=cam_R[0], H=H, W=W, rgb_in=rgb[0],
+        rgb_out=out[0], **kw)
 
 
 def gen_ops(net, cfg, synthetic):

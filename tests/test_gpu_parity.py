@@ -477,3 +477,46 @@ def test_query_skip_is_exact(tmp_path):
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
 
+
+def test_envmap_rotation_and_probe_inset(golden, relight):
+    """N4: ra_shift_envmap / ra_add_light_probe vs the reference's rotate_envmap / add_light_probe outputs"""
+    from relightableavatar_amd import relight_utils
+    from relightableavatar_amd.base_utils import dotdict
+    cfg, net, dev, body, eng = relight
+    g = golden('envmap.npz')
+    lights = synthetic.make_novel_lights(3, 0)
+    nl = dotdict({k: dotdict(probe=v.probe, image=T(g['images'][i])[None]) for i, (k, v) in enumerate(lights.items())})
+    repeat = int(g['repeat'])
+    for index in (0, 5, 37, 128 + 77, 2 * 128 + 127):
+        name, env = relight_utils.rotate_envmap(nl, index, repeat, 32, 48, eng)
+        assert name == str(g[f'rot{index}_name'])
+        assert float(err(env.probe[0], g[f'rot{index}_probe']).max()) < 2e-5          # HDR values up to 100
+        assert float(err(env.image[0], g[f'rot{index}_image']).max()) < 1e-6
+    H, W = int(g['H']), int(g['W'])
+    batch = dotdict(meta=dotdict(H=torch.tensor([H]), W=torch.tensor([W])), cam_R=T(g['cam_R'])[None])
+    c2 = dotdict(env_h=16, env_w=32, probe_size_ratio=0.2)
+    out = relight_utils.add_light_probe(T(g['rgb_in'])[None], lights['probe00'].probe, batch, c2, eng)
+    assert out.shape == (1, H * W, 3)
+    assert float(err(out[0], g['rgb_out']).max()) < 5e-5
+    # a full turn brings the probe back
+    full = eng.shift_envmap(lights['probe00'].probe, 32.0)
+    assert float(err(full, lights['probe00'].probe).max()) < 1e-5
+
+
+def test_rotating_light_sequence():
+    """cfg.vis_rotate_light: every probe is re-shaded at rotate_ratio * env_w headings from ONE traced frame; heading 0 is the
+    unrotated probe, and a constant probe is rotation invariant"""
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('novel_light', vis_rotate_light=True, rotate_ratio=1, test_light=[])
+    batch = synthetic.make_batch(96, 96, seed=0, posed=True, crop=16, n_novel_lights=1)
+    from relightableavatar_amd.base_utils import dotdict
+    batch.novel_lights['flat'] = dotdict(probe=torch.full((1, 16, 32, 3), 0.7))
+    out = make_renderer(cfg, net).render(synthetic.to_device(batch, dev))
+    names = [k for k in out if k != 'diff']
+    assert len(names) == 2 * 32 and 'probe00-0000' in names and 'flat-0031' in names
+    cfg2, net2, _ = build('novel_light', test_light=[])
+    ref = make_renderer(cfg2, net2).render(synthetic.to_device(synthetic.make_batch(96, 96, seed=0, posed=True, crop=16, n_novel_lights=1), dev))
+    assert float((out['probe00-0000'].rgb_map - ref['probe00'].rgb_map).abs().max()) < 1e-6
+    assert float((out['flat-0000'].rgb_map - out['flat-0017'].rgb_map).abs().max()) < 1e-5
+    assert float((out['probe00-0000'].rgb_map - out['probe00-0016'].rgb_map).abs().max()) > 1e-3      # half a turn changes the picture
+
