@@ -219,6 +219,13 @@ typedef struct ra_ground_out {  /* device buffers with P rows, any may be NULL *
 int ra_render_ground_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, const float* acc, int P, const float* bbox,
                            const float* probe, int ph, int pw, const ra_ground_params* p, const ra_ground_out* out, void* stream);
 
+/* blend_output_ / alpha_blend (sphere_tracing_renderer.py:396-451) for one map of C channels:
+ *   dst[f] = ground[f] * acc[f]                      for all F full-frame pixels (ground == NULL: zeros, the acc_map case)
+ *   dst[inds[j]] += human[j] * (1 - acc[inds[j]])    for the P in-box rays (human == NULL: skipped, the ground-only keys)
+ * acc: (F) = 1 - human acc scattered to the frame; inds: (P) int64 frame index of every in-box ray. */
+int ra_blend_ground(ra_ctx* ctx, const float* ground, const float* human, const long long* inds, const float* acc, int F, int P, int C,
+                    float* dst, void* stream);
+
 /* ---- N2: ray generation + bounding-box culling on the device ------------------------------------
  * replaces lib/utils/data_utils.py:827-845 (get_rays), :860-875 (get_full_near_far), :925-938 (get_rays_within_bounds),
  * called per frame by lib/datasets/pose_dataset.py:53-68 on the CPU.

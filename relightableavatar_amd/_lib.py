@@ -85,6 +85,7 @@ SYMBOLS = {
     'ra_render_volume_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.POINTER(ra_render_out), C.c_void_p]),
     'ra_render_ground_chunk': (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(ra_ground_params), C.POINTER(ra_ground_out), C.c_void_p]),
+    'ra_blend_ground': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'ra_reshade': (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
     'ra_get_counters': (C.c_int, [C.c_void_p, C.POINTER(ra_counters), C.c_void_p]),
     'ra_reset_counters': (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -555,6 +555,16 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     return 0;
 }
 
+int ra_blend_ground(ra_ctx* c, const float* ground, const float* human, const long long* inds, const float* acc, int F, int P, int C,
+                    float* dst, void* stream) {
+    RA_CHECK(c, "ra_blend_ground: null ctx");
+    RA_CHECK(acc && dst && F >= 0 && P >= 0 && C > 0 && (!human || inds), "ra_blend_ground: bad arguments");
+    RA_HIP(hipSetDevice(c->device));
+    launch_blend_ground(ground, human, inds, acc, F, P, C, dst, (hipStream_t)stream);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
 int ra_render_volume_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P,
                            int n_samples, float dist_th, const ra_render_out* out, void* stream) {
     if (check_ready(c, "ra_render_volume_chunk")) return 1;

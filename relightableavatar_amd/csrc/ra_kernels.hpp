@@ -163,4 +163,6 @@ void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_
 void launch_shift_envmap(const float* img, int H, int W, int C, float shift, float* out, hipStream_t s);
 struct ProbeInset { float axes[9]; int H, W, uH, uW, ph, pw; };     // axes: columns = right, -front, -down (gen_light_dir)
 void launch_light_probe(const ProbeInset& p, const float* probe, float* rgb, hipStream_t s);
+void launch_blend_ground(const float* ground, const float* human, const long long* inds, const float* acc, int F, int P, int C, float* dst,
+                         hipStream_t s);
 

@@ -730,6 +730,28 @@ __global__ __launch_bounds__(TPB) void ground_shade_kernel(GroundShade in, ra_co
     }
 }
 
+__global__ void blend_ground_base_kernel(const float* __restrict__ ground, const float* __restrict__ acc, int F, int C, float* __restrict__ dst) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (k >= (long long)F * C) return;
+    dst[k] = ground ? ground[k] * acc[k / C] : 0.f;
+}
+
+__global__ void blend_ground_human_kernel(const float* __restrict__ human, const long long* __restrict__ inds, const float* __restrict__ acc,
+                                          int P, int C, float* __restrict__ dst) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (k >= (long long)P * C) return;
+    const int j = (int)(k / C), c = (int)(k - (long long)j * C);
+    const long long f = inds[j];
+    dst[f * C + c] += human[k] * (1.f - acc[f]);
+}
+
+void launch_blend_ground(const float* ground, const float* human, const long long* inds, const float* acc, int F, int P, int C, float* dst,
+                         hipStream_t s) {
+    if (F <= 0) return;
+    hipLaunchKernelGGL(blend_ground_base_kernel, grid_for((long long)F * C), dim3(TPB), 0, s, ground, acc, F, C, dst);
+    if (human && P > 0) hipLaunchKernelGGL(blend_ground_human_kernel, grid_for((long long)P * C), dim3(TPB), 0, s, human, inds, acc, P, C, dst);
+}
+
 void launch_ground_hit(const GroundIn& g, float* t, float* surf, float* depth, float* norm_slots, int* hit_idx, int* hit_count, hipStream_t s) {
     hipMemsetAsync(hit_count, 0, sizeof(int), s);
     if (g.P <= 0) return;

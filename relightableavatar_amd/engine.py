@@ -154,6 +154,19 @@ class Engine:
         check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
                                               probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
 
+    def blend_ground(self, ground, human, inds, acc):
+        """blend_output_'s alpha_blend for one map: ground (F,C)/(F,) or None, human (P,C)/(P,) or None, inds (P) int64, acc (F)."""
+        ref = ground if ground is not None else human
+        flat = ref.ndim == 1
+        C_ = 1 if flat else ref.shape[-1]
+        F_ = acc.shape[0]
+        g = None if ground is None else _f32(ground, self.device).reshape(F_, C_)
+        h = None if human is None else _f32(human, self.device).reshape(-1, C_)
+        P = 0 if h is None else h.shape[0]
+        dst = torch.empty(F_, C_, device=self.device)
+        check(self.lib.ra_blend_ground(self.ctx, _ptr(g), _ptr(h), _ptr(inds), _ptr(acc), F_, P, C_, _ptr(dst), self.stream), 'ra_blend_ground')
+        return dst[:, 0] if flat else dst
+
     def render_volume_chunk(self, ray_o, ray_d, near, far, n_samples, dist_th, outs: dict):
         P = ray_o.shape[0]
         ro = ra_render_out(**{k: _ptr(outs.get(k)) for k in _lib.RENDER_OUT_KEYS})

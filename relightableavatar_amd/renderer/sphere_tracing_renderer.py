@@ -120,17 +120,13 @@ class Renderer(nn.Module):
         grd = dotdict(rgb_map=out.rgb, surf_map=out.surf, albedo_map=out.albedo, roughness_map=torch.ones(F, device=dev),
                       spec_map=out.spec, norm_map=n[None].expand(F, 3), shade_map=out.shade, cpts_map=torch.zeros(F, 3, device=dev),
                       bpts_map=torch.zeros(F, 3, device=dev), depth_map=out.depth)
+        inds = inds.to(torch.int64).contiguous()
         for k in self.BLEND_KEYS:
             if k in ret and k in grd:
-                sc = torch.zeros_like(grd[k])
-                sc[inds] = ret[k][0]
-                ag = acc_g if grd[k].ndim == 1 else acc_g[:, None]
-                ret[k] = (grd[k] * ag + sc * (1 - ag))[None]
+                ret[k] = eng.blend_ground(grd[k].contiguous(), ret[k][0], inds, acc_g)[None]
             elif k in grd:
-                ret[k] = (grd[k] * (acc_g if grd[k].ndim == 1 else acc_g[:, None]))[None]
-        sc = torch.zeros(F, device=dev)
-        sc[inds] = acc_h
-        ret.acc_map = (sc * (1 - acc_g))[None]               # alpha_blend(acc, inds, zeros, acc_map) (:449)
+                ret[k] = eng.blend_ground(grd[k].contiguous(), None, inds, acc_g)[None]
+        ret.acc_map = eng.blend_ground(None, acc_h, inds, acc_g)[None]      # alpha_blend(acc, inds, zeros, acc_map) (:449)
         ret.ground = dotdict(ray_o=g_o[None], ray_d=g_d[None], acc_map=acc_g[None], inds=inds[None])
         batch.mask_at_box[:] = True                          # :1103
         return ret
