@@ -445,7 +445,7 @@ __device__ __forceinline__ float sdf_to_occ_dev(float sdf, float beta) {   // ne
 }
 
 template <typename E>
-__global__ __launch_bounds__(MLP_THREADS, 1) void mlp_full_kernel(GeoNet net, MatNet mat, ColNet col,
+__global__ __launch_bounds__(MLP_THREADS, 2) void mlp_full_kernel(GeoNet net, MatNet mat, ColNet col,
                                                                  const void* __restrict__ wa_, const float* __restrict__ ba,
                                                                  FrameState fr, FullIO io) {
     typedef typename Tr<E>::x8 x8;
