@@ -391,6 +391,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     const bool relit = p->relighting != 0;
     RA_CHECK(!relit || (c->cfg.relight && probe && bbox && c->n_lights > 0), "ra_render_sphere_chunk: relighting needs the relight network, a probe and a bbox");
     RA_CHECK(p->n_samples >= 1 && p->n_samples <= 16, "ra_render_sphere_chunk: n_samples out of range");
+    RA_CHECK(!relit || (long long)P * c->n_lights < (1ll << 31), "ra_render_sphere_chunk: chunk too large (rays x lights must fit an int): lower cfg.render_chunk_size");
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     const int S = p->n_samples, C = c->cfg.relight ? 17 : 16, L = c->n_lights;
