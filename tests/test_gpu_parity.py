@@ -520,3 +520,22 @@ def test_rotating_light_sequence():
     assert float((out['flat-0000'].rgb_map - out['flat-0017'].rgb_map).abs().max()) < 1e-5
     assert float((out['probe00-0000'].rgb_map - out['probe00-0016'].rgb_map).abs().max()) > 1e-3      # half a turn changes the picture
 
+
+def test_streamed_k3_tile_boundaries(relight):
+    """the production K3 (weights streamed, 32 points per wave, 64/128/256-point tiles) against the first-generation kernel
+    behind the stage hook, for fine counts around every tile boundary (ragged last tiles, a single point, an empty set)"""
+    _, _, dev, body, eng = relight
+    g = torch.Generator().manual_seed(21)
+    vid = torch.randint(0, 6890, (70000,), generator=g)
+    wv = (body.pverts[0] @ body.R[0].T + body.Th[0])[vid.to(dev)]
+    x_all = wv + 0.01 * torch.nn.functional.normalize(torch.randn(70000, 3, generator=g), dim=-1).to(dev)     # all within dist_th
+    for n in (1, 31, 32, 33, 63, 64, 65, 127, 129, 255, 256, 257, 511, 513, 16383, 16385, 32769, 65537):
+        x = x_all[:n].contiguous()
+        o = eng.debug_hdq(x, 0.125)
+        assert o.fine_count == n
+        sdf3 = eng.hdq_sdf(x, 0.125, False)                      # production path: coarse level + streamed K3, no blend
+        _, sdf1, _ = eng.debug_mlp(o.bpts)                       # first-generation kernel on the same big-pose points
+        e = (sdf3 - sdf1).abs()
+        assert torch.isfinite(sdf3).all() and float(e.max()) < 6e-4 and float(e.mean()) < 6e-5, (n, float(e.max()), float(e.mean()))
+    assert eng.hdq_sdf(x_all[:0], 0.125, True).numel() == 0
+
