@@ -237,6 +237,26 @@ int ra_blend_ground(ra_ctx* ctx, const float* ground, const float* human, const 
 int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
                 void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream);
 
+/* ---- N3: per-frame body state on the device -----------------------------------------------------
+ * replaces lib/datasets/base_dataset.py:308-397 (get_lbs_params with cfg.use_geometry, get_blend), which runs on the CPU
+ * per frame: bone transforms from the axis-angle poses (net_utils.py:1164-1183 / data_utils.py:1004-1069), template ->
+ * T pose -> posed -> world vertices (blend_utils.py:212-218,264-313), vertex normals (pytorch3d Meshes.verts_normals),
+ * bounds (data_utils.py:616-622).
+ * Host inputs: poses, tjoints (J,3) f32, parents (J) int32 (topological order, parents[0] unused), big_A (J,16) f32,
+ * Rh, Th (3) f32, faces (F,3) int32 (cached by pointer + count: keep the array alive and unchanged).
+ * Device inputs: tverts (N,3), weights (N,J).  Device outputs (any may be NULL): A (J,16), joints (J,3), tpose (N,3),
+ * pverts (N,3), wverts (N,3), pnorm (N,3), R (9), pbounds (6), wbounds (6). */
+typedef struct ra_pose_in {
+    const float *poses, *tjoints, *big_A, *Rh, *Th;
+    const int* parents;
+    const int* faces;
+    int n_bones, n_faces, n_verts;
+    const void *tverts, *weights;
+    float bounds_padding;           /* get_bounds(padding=0.05) */
+} ra_pose_in;
+typedef struct ra_pose_out { void *A, *joints, *tpose, *pverts, *wverts, *pnorm, *R, *pbounds, *wbounds; } ra_pose_out;
+int ra_pose_frame(ra_ctx* ctx, const ra_pose_in* in, const ra_pose_out* out, void* stream);
+
 /* ---- N4: environment-map rotation and the light-probe inset -------------------------------------
  * ra_shift_envmap: rotate_envmap's shift_image (lib/utils/relight_utils.py:69-85): out[y][x] = bilinear sample of img at
  * x + 0.5 + shift (wrapped modulo W; grid_sample align_corners=False, border padding), img/out: (H,W,C) device fp32.

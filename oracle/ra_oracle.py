@@ -656,6 +656,66 @@ BLEND_KEYS = ['rgb_map', 'rfl_map', 'surf_map', 'albedo_map', 'roughness_map', '
               'spec_map', 'depth_map', 'lvis_map', 'ldot_map', 'brdf_map', 'shade_map']
 
 
+def rodrigues(rot_vecs: torch.Tensor):
+    """batch_rodrigues, data_utils.py:1004-1023 (the numpy twin of smplx.lbs.batch_rodrigues): float64 inside, float32 out."""
+    r = rot_vecs.double()
+    angle = torch.linalg.norm(r + 1e-8, dim=1, keepdim=True)
+    d = r / angle
+    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    z = torch.zeros_like(rx)
+    K = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(-1, 3, 3)
+    return (torch.eye(3, dtype=torch.float64)[None] + sin * K + (1 - cos) * (K @ K)).float()
+
+
+def rigid_transforms(poses, joints, parents):
+    """get_rigid_transformation_and_joints, data_utils.py:1026-1069 (== smplx.lbs.batch_rigid_transform, which
+    net_utils.py:1164-1183 calls): per-bone rest-to-posed 4x4 `A` and the posed joints.  poses, joints (J,3), parents (J)."""
+    J = joints.shape[0]
+    R = rodrigues(poses).double()
+    jt = joints.double()
+    rel = jt.clone()
+    rel[1:] -= jt[parents[1:]]
+    T = torch.zeros(J, 4, 4, dtype=torch.float64)
+    T[:, :3, :3], T[:, :3, 3], T[:, 3, 3] = R, rel, 1.0
+    chain = [T[0]]
+    for i in range(1, J):
+        chain.append(chain[int(parents[i])] @ T[i])
+    tr = torch.stack(chain)
+    posed = tr[:, :3, 3].clone()
+    jh = torch.cat([jt, torch.zeros(J, 1, dtype=torch.float64)], dim=1)
+    tr[:, :, 3] = tr[:, :, 3] - (tr * jh[:, None]).sum(-1)
+    return tr.float(), posed.float()
+
+
+def verts_normals(verts, faces):
+    """pytorch3d.structures.Meshes.verts_normals_packed (un-vendored dependency, version unpinned: PARITY UNPINNED — restated
+    from its published algorithm): area-weighted face normals accumulated per corner with that corner's edge pair, then
+    F.normalize(eps=1e-6)."""
+    v0, v1, v2 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    n = torch.zeros_like(verts)
+    n = n.index_add(0, faces[:, 1], torch.cross(v2 - v1, v0 - v1, dim=1))
+    n = n.index_add(0, faces[:, 2], torch.cross(v0 - v2, v1 - v2, dim=1))
+    n = n.index_add(0, faces[:, 0], torch.cross(v1 - v0, v2 - v0, dim=1))
+    return F.normalize(n, eps=1e-6, dim=1)
+
+
+def pose_frame(poses, tjoints, parents, tverts, weights, big_A, faces, Rh, Th, padding=0.05):
+    """N3: base_dataset.py:308-397 (get_lbs_params with cfg.use_geometry, get_blend): bone transforms, template -> T pose ->
+    posed -> world vertices (blend_utils.py:212-218,264-313), vertex normals, bounds (data_utils.py:616-622)."""
+    A, Jp = rigid_transforms(poses, tjoints, parents)
+    Abig = torch.einsum('nj,jab->nab', weights, big_A)
+    t = tverts - Abig[:, :3, 3]
+    txyz = (inverse_3x3(Abig[:, :3, :3]) * t[:, None]).sum(-1)
+    Abw = torch.einsum('nj,jab->nab', weights, A)
+    pxyz = (Abw[:, :3, :3] * txyz[:, None]).sum(-1) + Abw[:, :3, 3]
+    R = rodrigues(Rh[None])[0]
+    wxyz = pxyz @ R.mT + Th
+    bnd = lambda x: torch.stack([x.min(0)[0] - padding, x.max(0)[0] + padding])
+    return odict(A=A, joints=Jp, tverts=txyz, pverts=pxyz, wverts=wxyz, R=R, pnorm=verts_normals(pxyz, faces),
+                 pbounds=bnd(pxyz), wbounds=bnd(wxyz))
+
+
 def get_rays_torch(H, W, K, R, T):
     """get_rays net_utils.py:403-425 (torch, the camera's dtype): full-frame rays, (H*W,3) each."""
     ray_o = -(R.mT @ T).ravel()

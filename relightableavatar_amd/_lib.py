@@ -62,6 +62,19 @@ class ra_ground_out(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in GROUND_OUT_KEYS]
 
 
+class ra_pose_in(C.Structure):
+    _fields_ = [(k, C.POINTER(C.c_float)) for k in ('poses', 'tjoints', 'big_A', 'Rh', 'Th')] + \
+               [('parents', C.POINTER(C.c_int)), ('faces', C.POINTER(C.c_int)), ('n_bones', C.c_int), ('n_faces', C.c_int), ('n_verts', C.c_int),
+                ('tverts', C.c_void_p), ('weights', C.c_void_p), ('bounds_padding', C.c_float)]
+
+
+POSE_OUT_KEYS = ('A', 'joints', 'tpose', 'pverts', 'wverts', 'pnorm', 'R', 'pbounds', 'wbounds')
+
+
+class ra_pose_out(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in POSE_OUT_KEYS]
+
+
 class ra_counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ('n_coarse', 'n_fine_sdf', 'n_fine_full', 'n_shadow_rays', 'n_hit_pixels', 'n_shaded')]
 
@@ -92,6 +105,7 @@ SYMBOLS = {
     'ra_get_mlp_time': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
     'ra_enable_timing': (C.c_int, [C.c_void_p, C.c_int]),
     'ra_set_knn_mode': (C.c_int, [C.c_void_p, C.c_int]),
+    'ra_pose_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_pose_in), C.POINTER(ra_pose_out), C.c_void_p]),
     'ra_shift_envmap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'ra_add_light_probe': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     'ra_gen_rays': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.c_void_p]),

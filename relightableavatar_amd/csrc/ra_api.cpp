@@ -3,6 +3,7 @@
 // (fine points, hit pixels, shadow rays) stay on the device and kernels size themselves from them.
 #include "ra_ctx.hpp"
 #include <cmath>
+#include <vector>
 
 #include <cstring>
 #include <cstdlib>
@@ -58,7 +59,8 @@ int ra_ctx_destroy(ra_ctx* c) {
     hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->warena, &c->sarena, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
-                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs};
+                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs,
+                      &c->adj_start, &c->adj_list, &c->adj_dfaces};
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : c->scratch) kv.second.release();
     for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -647,6 +649,130 @@ int ra_set_knn_mode(ra_ctx* c, int use_bvh) {
     RA_CHECK(c, "ra_set_knn_mode: null ctx");
     c->use_bvh = use_bvh != 0;
     c->have_frame = false;      // takes effect at the next ra_set_frame
+    return 0;
+}
+
+// Rodrigues as data_utils.py:1004-1023 (smplx.lbs.batch_rodrigues): angle = |r + 1e-8|, R = I + sin K + (1 - cos) K^2, float32 out
+static void rodrigues_smplx(const float* r, double R[9]) {
+    const double x = (double)r[0] + 1e-8, y = (double)r[1] + 1e-8, z = (double)r[2] + 1e-8;
+    const double angle = std::sqrt(x * x + y * y + z * z);
+    const double d[3] = {r[0] / angle, r[1] / angle, r[2] / angle};
+    const double K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+    const double sn = std::sin(angle), cs = std::cos(angle);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double kk = 0;
+            for (int k = 0; k < 3; ++k) kk += K[3 * i + k] * K[3 * k + j];
+            R[3 * i + j] = (double)(float)((i == j ? 1.0 : 0.0) + sn * K[3 * i + j] + (1.0 - cs) * kk);
+        }
+}
+
+int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void* stream) {
+    RA_CHECK(c && in && out, "ra_pose_frame: null argument");
+    const int J = in->n_bones, N = in->n_verts, F = in->n_faces;
+    RA_CHECK(J > 0 && J <= 256 && N > 0 && F >= 0, "ra_pose_frame: bad sizes");
+    RA_CHECK(in->poses && in->tjoints && in->parents && in->big_A && in->Rh && in->Th && in->tverts && in->weights, "ra_pose_frame: null input");
+    RA_CHECK(!out->pnorm || (in->faces && F > 0), "ra_pose_frame: vertex normals need faces");
+    hipStream_t s = (hipStream_t)stream;
+    RA_HIP(hipSetDevice(c->device));
+    // ---- bone transforms on the host in fp64 (get_rigid_transformation_and_joints, data_utils.py:1026-1069): 52 4x4 products
+    std::vector<double> T((size_t)J * 16), chain((size_t)J * 16);
+    for (int j = 0; j < J; ++j) {
+        double R[9];
+        rodrigues_smplx(in->poses + 3 * j, R);
+        RA_CHECK(j == 0 || (in->parents[j] >= 0 && in->parents[j] < j), "ra_pose_frame: parents must be in topological order");
+        double* t = &T[(size_t)j * 16];
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) t[4 * r + k] = R[3 * r + k];
+            t[4 * r + 3] = (double)in->tjoints[3 * j + r] - (j ? (double)in->tjoints[3 * in->parents[j] + r] : 0.0);
+        }
+        t[12] = t[13] = t[14] = 0.0; t[15] = 1.0;
+        double* o = &chain[(size_t)j * 16];
+        if (j == 0) { for (int e = 0; e < 16; ++e) o[e] = t[e]; continue; }
+        const double* p = &chain[(size_t)in->parents[j] * 16];
+        for (int r = 0; r < 4; ++r)
+            for (int k = 0; k < 4; ++k) { double a = 0; for (int m = 0; m < 4; ++m) a += p[4 * r + m] * t[4 * m + k]; o[4 * r + k] = a; }
+    }
+    std::vector<float> A((size_t)J * 16), joints((size_t)J * 3);
+    for (int j = 0; j < J; ++j) {
+        double* o = &chain[(size_t)j * 16];
+        for (int r = 0; r < 3; ++r) joints[3 * j + r] = (float)o[4 * r + 3];
+        for (int r = 0; r < 4; ++r) {
+            double rot = 0;
+            for (int k = 0; k < 3; ++k) rot += o[4 * r + k] * (double)in->tjoints[3 * j + k];
+            o[4 * r + 3] -= rot;          // transforms[..., 3] -= transforms @ [joint, 0]
+        }
+        for (int e = 0; e < 16; ++e) A[(size_t)j * 16 + e] = (float)o[e];
+    }
+    // global rotation: cv2.Rodrigues(Rh)
+    float Rg[9];
+    {
+        const double r[3] = {in->Rh[0], in->Rh[1], in->Rh[2]};
+        const double th = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (th >= 1e-12) {
+            const double k[3] = {r[0] / th, r[1] / th, r[2] / th};
+            const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double kk = 0;
+                    for (int m = 0; m < 3; ++m) kk += K[3 * i + m] * K[3 * m + j];
+                    Rd[3 * i + j] = (i == j ? 1.0 : 0.0) + std::sin(th) * K[3 * i + j] + (1.0 - std::cos(th)) * kk;
+                }
+        }
+        for (int e = 0; e < 9; ++e) Rg[e] = (float)Rd[e];
+    }
+    int err = 0;
+    float* dA = c->buf<float>("pf_A", (size_t)J * 16, &err);
+    float* dB = c->buf<float>("pf_bigA", (size_t)J * 16, &err);
+    float* dR = c->buf<float>("pf_R", 12, &err);
+    float* dP = c->buf<float>("pf_p", (size_t)N * 3, &err);
+    float* dW = c->buf<float>("pf_w", (size_t)N * 3, &err);
+    RA_CHECK(!err, "ra_pose_frame: out of device memory");
+    float RT[12];
+    for (int e = 0; e < 9; ++e) RT[e] = Rg[e];
+    for (int e = 0; e < 3; ++e) RT[9 + e] = in->Th[e];
+    RA_HIP(hipMemcpyAsync(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice, s));
+    RA_HIP(hipMemcpyAsync(dB, in->big_A, (size_t)J * 64, hipMemcpyHostToDevice, s));
+    RA_HIP(hipMemcpyAsync(dR, RT, sizeof(RT), hipMemcpyHostToDevice, s));
+    RA_HIP(hipStreamSynchronize(s));        // the host vectors go out of scope
+    float* pv = out->pverts ? (float*)out->pverts : dP;
+    float* wv = out->wverts ? (float*)out->wverts : dW;
+    launch_lbs_verts((const float*)in->tverts, (const float*)in->weights, dA, dB, dR, dR + 9, N, J, (float*)out->tpose, pv, wv, s);
+    if (out->pnorm) {
+        // incident corners per vertex in index_add order, cached per (faces pointer, count)
+        if (c->adj_faces != in->faces || c->adj_n_faces != F || c->adj_n_verts != N) {
+            std::vector<int> start(N + 1, 0), adj((size_t)F * 3);
+            const int order[3] = {1, 2, 0};
+            for (int f = 0; f < F; ++f)
+                for (int k = 0; k < 3; ++k) {
+                    const int v = in->faces[3 * f + k];
+                    RA_CHECK(v >= 0 && v < N, "ra_pose_frame: face index out of range");
+                    ++start[v + 1];
+                }
+            for (int v = 0; v < N; ++v) start[v + 1] += start[v];
+            std::vector<int> fill(start.begin(), start.end() - 1);
+            for (int pass = 0; pass < 3; ++pass)
+                for (int f = 0; f < F; ++f) { const int corner = order[pass]; adj[fill[in->faces[3 * f + corner]]++] = (f << 2) | corner; }
+            if (c->adj_start.ensure((size_t)(N + 1) * 4) || c->adj_list.ensure((size_t)F * 12 + 4) || c->adj_dfaces.ensure((size_t)F * 12 + 4)) return 1;
+            RA_HIP(hipMemcpy(c->adj_start.p, start.data(), (size_t)(N + 1) * 4, hipMemcpyHostToDevice));
+            RA_HIP(hipMemcpy(c->adj_list.p, adj.data(), (size_t)F * 12, hipMemcpyHostToDevice));
+            RA_HIP(hipMemcpy(c->adj_dfaces.p, in->faces, (size_t)F * 12, hipMemcpyHostToDevice));
+            c->adj_faces = in->faces; c->adj_n_faces = F; c->adj_n_verts = N;
+        }
+        launch_vert_normals(pv, c->adj_dfaces.as<int>(), c->adj_start.as<int>(), c->adj_list.as<int>(), N, (float*)out->pnorm, s);
+    }
+    if (out->pbounds) launch_bounds(pv, N, in->bounds_padding, (float*)out->pbounds, s);
+    if (out->wbounds) launch_bounds(wv, N, in->bounds_padding, (float*)out->wbounds, s);
+    if (out->A) RA_HIP(hipMemcpyAsync(out->A, dA, (size_t)J * 64, hipMemcpyDeviceToDevice, s));
+    if (out->R) RA_HIP(hipMemcpyAsync(out->R, dR, 36, hipMemcpyDeviceToDevice, s));
+    if (out->joints) {
+        float* dJ = c->buf<float>("pf_J", (size_t)J * 3, &err);
+        RA_CHECK(!err, "ra_pose_frame: out of device memory");
+        RA_HIP(hipMemcpy(dJ, joints.data(), joints.size() * 4, hipMemcpyHostToDevice));
+        RA_HIP(hipMemcpyAsync(out->joints, dJ, (size_t)J * 12, hipMemcpyDeviceToDevice, s));
+    }
+    RA_HIP(hipGetLastError());
     return 0;
 }
 

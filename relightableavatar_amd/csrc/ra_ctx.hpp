@@ -36,6 +36,10 @@ struct ra_ctx {
     FrameState fr{};
     DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond, fbvh_pts, fbvh_pairs;
     bool use_bvh = true;
+    // N3: vertex -> incident corners of the template mesh (built once per faces array)
+    DevBuf adj_start, adj_list, adj_dfaces;
+    const int* adj_faces = nullptr;
+    int adj_n_faces = 0, adj_n_verts = 0;
     // scratch (grow-only)
     std::map<std::string, DevBuf> scratch;
     DevBuf dcounters;       // DevCounters + small int counters

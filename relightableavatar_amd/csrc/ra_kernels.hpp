@@ -166,3 +166,9 @@ void launch_light_probe(const ProbeInset& p, const float* probe, float* rgb, hip
 void launch_blend_ground(const float* ground, const float* human, const long long* inds, const float* acc, int F, int P, int C, float* dst,
                          hipStream_t s);
 
+// N3: per-frame body state (ra_trace.hip)
+void launch_lbs_verts(const float* tverts, const float* weights, const float* A, const float* big_A, const float* R, const float* Th,
+                      int n_verts, int n_bones, float* tpose, float* pverts, float* wverts, hipStream_t s);
+void launch_vert_normals(const float* verts, const int* faces, const int* adj_start, const int* adj, int n_verts, float* normals, hipStream_t s);
+void launch_bounds(const float* pts, int n, float padding, float* bounds6, hipStream_t s);
+

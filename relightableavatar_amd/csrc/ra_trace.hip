@@ -763,6 +763,116 @@ void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_
     hipLaunchKernelGGL(ground_shade_kernel, grid_for((long long)in.g.P * 64), dim3(TPB), 0, s, in, cfg);
 }
 
+// ------------------------------------------------------------------------------------------ N3: body state
+// per vertex: template -> T pose (pose_points_to_tpose_points with the big-pose blend, blend_utils.py:290-300) -> posed
+// (tpose_points_to_pose_points :303-313) -> world (pose_points_to_world_points :264-273); bone matrices staged in LDS
+__global__ void lbs_verts_kernel(const float* __restrict__ tverts, const float* __restrict__ weights, const float* __restrict__ A,
+                                 const float* __restrict__ big_A, const float* __restrict__ R, const float* __restrict__ Th, int n_verts,
+                                 int n_bones, float* __restrict__ tpose, float* __restrict__ pverts, float* __restrict__ wverts) {
+    extern __shared__ float sA[];                      // [n_bones][12] posed, then [n_bones][12] big pose
+    float* sB = sA + n_bones * 12;
+    for (int k = threadIdx.x; k < n_bones * 12; k += blockDim.x) {
+        const int j = k / 12, e = k - j * 12;
+        sA[k] = A[j * 16 + e];
+        sB[k] = big_A[j * 16 + e];
+    }
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_verts) return;
+    float Ma[12], Mb[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Ma[e] = Mb[e] = 0.f;
+    for (int j = 0; j < n_bones; ++j) {
+        const float w = weights[(size_t)v * n_bones + j];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) { Ma[e] += w * sA[j * 12 + e]; Mb[e] += w * sB[j * 12 + e]; }
+    }
+    const float t[3] = {tverts[3 * v] - Mb[3], tverts[3 * v + 1] - Mb[7], tverts[3 * v + 2] - Mb[11]};
+    const float Rb[9] = {Mb[0], Mb[1], Mb[2], Mb[4], Mb[5], Mb[6], Mb[8], Mb[9], Mb[10]};
+    float Ri[9];
+    {   // adjugate / (det + 1e-8)  (torch_inverse_3x3, blend_utils.py:125-165)
+        Ri[0] = Rb[4] * Rb[8] - Rb[7] * Rb[5]; Ri[3] = -Rb[3] * Rb[8] + Rb[6] * Rb[5]; Ri[6] = Rb[3] * Rb[7] - Rb[6] * Rb[4];
+        Ri[1] = -Rb[1] * Rb[8] + Rb[7] * Rb[2]; Ri[4] = Rb[0] * Rb[8] - Rb[6] * Rb[2]; Ri[7] = -Rb[0] * Rb[7] + Rb[6] * Rb[1];
+        Ri[2] = Rb[1] * Rb[5] - Rb[4] * Rb[2]; Ri[5] = -Rb[0] * Rb[5] + Rb[3] * Rb[2]; Ri[8] = Rb[0] * Rb[4] - Rb[3] * Rb[1];
+        const float inv = 1.f / (Rb[0] * Ri[0] + Rb[1] * Ri[3] + Rb[2] * Ri[6] + 1e-8f);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Ri[i] *= inv;
+    }
+    float tp[3], pp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tp[r] = Ri[3 * r] * t[0] + Ri[3 * r + 1] * t[1] + Ri[3 * r + 2] * t[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pp[r] = Ma[4 * r] * tp[0] + Ma[4 * r + 1] * tp[1] + Ma[4 * r + 2] * tp[2] + Ma[4 * r + 3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (tpose) tpose[3 * v + r] = tp[r];
+        if (pverts) pverts[3 * v + r] = pp[r];
+        if (wverts) wverts[3 * v + r] = pp[0] * R[3 * r] + pp[1] * R[3 * r + 1] + pp[2] * R[3 * r + 2] + Th[r];       // p @ R^T + Th
+    }
+}
+
+// pytorch3d Meshes.verts_normals: every corner adds the cross product of ITS two edges; the incident corners of a vertex
+// are listed (host-built, cached) in the order index_add visits them (corner 1 pass, corner 2 pass, corner 0 pass, faces
+// ascending), so the fp32 sum is deterministic
+__global__ void vert_normals_kernel(const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ adj_start,
+                                    const int* __restrict__ adj, int n_verts, float* __restrict__ normals) {
+    const int v = blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_verts) return;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int k = adj_start[v]; k < adj_start[v + 1]; ++k) {
+        const int code = adj[k], f = code >> 2, corner = code & 3;
+        const int ia = faces[3 * f + corner], ib = faces[3 * f + (corner + 1) % 3], ic = faces[3 * f + (corner + 2) % 3];
+        // corner c: cross(v[c+1] - v[c], v[c+2] - v[c])
+        const float e1[3] = {verts[3 * ib] - verts[3 * ia], verts[3 * ib + 1] - verts[3 * ia + 1], verts[3 * ib + 2] - verts[3 * ia + 2]};
+        const float e2[3] = {verts[3 * ic] - verts[3 * ia], verts[3 * ic + 1] - verts[3 * ia + 1], verts[3 * ic + 2] - verts[3 * ia + 2]};
+        n[0] += e1[1] * e2[2] - e1[2] * e2[1];
+        n[1] += e1[2] * e2[0] - e1[0] * e2[2];
+        n[2] += e1[0] * e2[1] - e1[1] * e2[0];
+    }
+    const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-6f);      // F.normalize(eps=1e-6)
+    normals[3 * v] = n[0] / len; normals[3 * v + 1] = n[1] / len; normals[3 * v + 2] = n[2] / len;
+}
+
+// get_bounds (data_utils.py:616-622): one workgroup, min / max over the points, then the padding
+__global__ __launch_bounds__(1024) void bounds_kernel(const float* __restrict__ pts, int n, float padding, float* __restrict__ out) {
+    __shared__ float smin[16][3], smax[16][3];
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = threadIdx.x; i < n; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], pts[3 * i + c]); hi[c] = fmaxf(hi[c], pts[3 * i + c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { smin[wv][c] = lo[c]; smax[wv][c] = hi[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float a = smin[0][threadIdx.x], b = smax[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w) { a = fminf(a, smin[w][threadIdx.x]); b = fmaxf(b, smax[w][threadIdx.x]); }
+        out[threadIdx.x] = a - padding;
+        out[3 + threadIdx.x] = b + padding;
+    }
+}
+
+void launch_lbs_verts(const float* tverts, const float* weights, const float* A, const float* big_A, const float* R, const float* Th,
+                      int n_verts, int n_bones, float* tpose, float* pverts, float* wverts, hipStream_t s) {
+    if (n_verts <= 0) return;
+    hipLaunchKernelGGL(lbs_verts_kernel, dim3((n_verts + 255) / 256), dim3(256), (size_t)n_bones * 24 * sizeof(float), s, tverts, weights, A,
+                       big_A, R, Th, n_verts, n_bones, tpose, pverts, wverts);
+}
+
+void launch_vert_normals(const float* verts, const int* faces, const int* adj_start, const int* adj, int n_verts, float* normals, hipStream_t s) {
+    if (n_verts <= 0) return;
+    hipLaunchKernelGGL(vert_normals_kernel, grid_for(n_verts), dim3(TPB), 0, s, verts, faces, adj_start, adj, n_verts, normals);
+}
+
+void launch_bounds(const float* pts, int n, float padding, float* bounds6, hipStream_t s) {
+    hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(1024), 0, s, pts, n, padding, bounds6);
+}
+
 // ------------------------------------------------------------------------------------------ N4: envmap utilities
 // shift_image (relight_utils.py:69-85): grid x = ((j + 0.5 + shift) mod W) / W * 2 - 1, grid_sample(align_corners=False, border)
 __global__ void shift_envmap_kernel(const float* __restrict__ img, int H, int W, int C, float shift, float* __restrict__ out) {

@@ -8,8 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (check, ra_config, ra_counters, ra_frame, ra_ground_out, ra_ground_params, ra_render_out, ra_sphere_params,
-                   ra_trace_params)
+from ._lib import (check, ra_config, ra_counters, ra_frame, ra_ground_out, ra_ground_params, ra_pose_in, ra_pose_out, ra_render_out,
+                   ra_sphere_params, ra_trace_params)
 from .base_utils import dotdict
 
 
@@ -220,6 +220,36 @@ class Engine:
                                    _ptr(ro), _ptr(rd), _ptr(near), _ptr(far), _ptr(mask), C.byref(cnt), self.stream), 'ra_gen_rays')
         P = cnt.value
         return dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(int(H), int(W)).bool())
+
+    def pose_frame(self, poses, tjoints, parents, tverts, weights, big_A, faces, Rh, Th, padding=0.05):
+        """N3: per-frame body state on the device (base_dataset.py:308-397).  Small inputs (poses, tjoints (J,3), parents (J),
+        big_A (J,4,4), Rh, Th, faces (F,3)) are read from host memory; tverts (N,3) and weights (N,J) are device tensors
+        (moved if needed).  Returns device tensors A (J,4,4), joints, tverts (T pose), pverts, wverts, pnorm, R, pbounds, wbounds."""
+        import numpy as np
+        h32 = lambda a: np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+        hp, hj, hb, hr, ht = h32(poses).reshape(-1, 3), h32(tjoints).reshape(-1, 3), h32(big_A).reshape(-1, 16), h32(Rh).reshape(3), h32(Th).reshape(3)
+        par = np.ascontiguousarray(parents.cpu().numpy() if isinstance(parents, torch.Tensor) else parents, dtype=np.int32)
+        key = id(faces)
+        if getattr(self, '_faces_key', None) != key:            # the C side caches the adjacency by pointer: keep one int32 copy alive
+            self._faces_host = np.ascontiguousarray(faces.cpu().numpy() if isinstance(faces, torch.Tensor) else faces, dtype=np.int32).reshape(-1, 3)
+            self._faces_key = key
+        fc = self._faces_host
+        d = self.device
+        tv, w = _f32(tverts.reshape(-1, 3) if isinstance(tverts, torch.Tensor) else torch.as_tensor(tverts).reshape(-1, 3), d), \
+            _f32(weights if isinstance(weights, torch.Tensor) else torch.as_tensor(weights), d)
+        w = w.reshape(tv.shape[0], -1)
+        J, N = hp.shape[0], tv.shape[0]
+        o = dotdict(A=torch.empty(J, 4, 4, device=d), joints=torch.empty(J, 3, device=d), tverts=torch.empty(N, 3, device=d),
+                    pverts=torch.empty(N, 3, device=d), wverts=torch.empty(N, 3, device=d), pnorm=torch.empty(N, 3, device=d),
+                    R=torch.empty(3, 3, device=d), pbounds=torch.empty(2, 3, device=d), wbounds=torch.empty(2, 3, device=d))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        pin = ra_pose_in(poses=fp(hp), tjoints=fp(hj), big_A=fp(hb), Rh=fp(hr), Th=fp(ht), parents=par.ctypes.data_as(C.POINTER(C.c_int)),
+                         faces=fc.ctypes.data_as(C.POINTER(C.c_int)), n_bones=J, n_faces=fc.shape[0], n_verts=N, tverts=_ptr(tv), weights=_ptr(w),
+                         bounds_padding=float(padding))
+        pout = ra_pose_out(A=_ptr(o.A), joints=_ptr(o.joints), tpose=_ptr(o.tverts), pverts=_ptr(o.pverts), wverts=_ptr(o.wverts),
+                           pnorm=_ptr(o.pnorm), R=_ptr(o.R), pbounds=_ptr(o.pbounds), wbounds=_ptr(o.wbounds))
+        check(self.lib.ra_pose_frame(self.ctx, C.byref(pin), C.byref(pout), self.stream), 'ra_pose_frame')
+        return o
 
     def shift_envmap(self, image, shift):
         """N4: rotate_envmap's shift_image: (H,W,C) or (1,H,W,C) -> same shape, shifted `shift` pixels with wrap-around."""

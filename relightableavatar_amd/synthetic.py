@@ -253,6 +253,33 @@ def rays_within_bounds(H, W, K, R, T, bounds: np.ndarray):
     return ray_o[mask], ray_d[mask], near.astype(np.float32), far.astype(np.float32), mask.reshape(H, W)
 
 
+def make_skeleton(seed: int = 0):
+    """N3 inputs (base_dataset.py:308-397): a 52-joint tree (parents in topological order, SMPL-H style), rest joints
+    inside the body, per-frame axis-angle poses / Rh / Th, the big-pose transforms, and a triangulation of the template
+    (convex hull of the Fibonacci sphere: a closed, consistently oriented mesh)."""
+    from scipy.spatial import ConvexHull
+    r = _rng(seed, 'skeleton')
+    parents = np.zeros(N_BONES, dtype=np.int64)
+    parents[0] = -1
+    for j in range(1, N_BONES):
+        parents[j] = r.integers(max(0, j - 6), j)
+    tjoints = r.uniform(-0.25, 0.25, (N_BONES, 3)).astype(np.float32)
+    poses = (r.standard_normal((N_BONES, 3)) * 0.25).astype(np.float32)
+    big_poses = (r.standard_normal((N_BONES, 3)) * 0.15).astype(np.float32)
+    Rh = np.array([0.1, -0.2, 0.15], dtype=np.float32)
+    Th = np.array([0.03, -0.02, 0.05], dtype=np.float32)
+    b = make_body(seed, posed=False)
+    tv = b.tverts[0].numpy().astype(np.float64)
+    hull = ConvexHull(tv / np.array([0.8, 0.7, 1.1]))          # on the sphere itself: every vertex is on the hull
+    faces = hull.simplices.astype(np.int64)
+    # outward orientation (pytorch3d normals follow the winding)
+    c = np.cross(tv[faces[:, 1]] - tv[faces[:, 0]], tv[faces[:, 2]] - tv[faces[:, 0]])
+    flip = (c * tv[faces].mean(1)).sum(-1) < 0
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    return dotdict(parents=parents, tjoints=tjoints, poses=poses, big_poses=big_poses, Rh=Rh, Th=Th, faces=faces,
+                   tverts=b.tverts[0].numpy(), weights=b.weights[0].numpy())
+
+
 def make_batch(H: int, W: int, seed: int = 0, posed: bool = True, n_novel_lights: int = 0,
                crop: int = 0) -> dotdict:
     """Full §8b batch on CPU. ``crop``>0 keeps only a centred crop x crop window of pixels."""

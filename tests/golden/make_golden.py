@@ -132,7 +132,7 @@ def npz(path, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground', 'envmap'])
+    ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground', 'envmap', 'lbs'])
     args = ap.parse_args()
     mode = args.mode
     from relightableavatar_amd import synthetic
@@ -143,6 +143,9 @@ def main():
         return
     if mode == 'envmap':
         gen_envmap(cfg, synthetic)
+        return
+    if mode == 'lbs':
+        gen_lbs(synthetic)
         return
     set_cfg(cfg, mode)
     torch.manual_seed(0)
@@ -235,6 +238,24 @@ def gen_rays(synthetic):
                    f'{tag}_T': np.asarray(t, np.float64).reshape(3), f'{tag}_ray_o': ro, f'{tag}_ray_d': rd, f'{tag}_near': near,
                    f'{tag}_far': far, f'{tag}_mask': mask})
     npz('rays.npz', bounds=bounds, **kw)
+
+
+def gen_lbs(synthetic):
+    """N3: the reference's own per-frame SMPL-state functions on the synthetic skeleton (every 5th vertex kept to stay small):
+    get_rigid_transformation_and_joints (data_utils.py:1026-1069), pose_points_to_tpose_points / tpose_points_to_pose_points /
+    pose_points_to_world_points (blend_utils.py:264-313), get_bounds (data_utils.py:616-622)."""
+    from lib.utils import data_utils, blend_utils
+    sk = synthetic.make_skeleton(0)
+    A, J = data_utils.get_rigid_transformation_and_joints(sk.poses, sk.tjoints, sk.parents)
+    big_A, _ = data_utils.get_rigid_transformation_and_joints(sk.big_poses, sk.tjoints, sk.parents)
+    sel = np.arange(0, sk.tverts.shape[0], 5)
+    tv, w = torch.from_numpy(sk.tverts[sel])[None], torch.from_numpy(sk.weights[sel])[None]
+    txyz = blend_utils.pose_points_to_tpose_points(tv, w, torch.from_numpy(big_A)[None])
+    pxyz = blend_utils.tpose_points_to_pose_points(txyz, w, torch.from_numpy(A)[None])
+    R = synthetic._rodrigues(sk.Rh.astype(np.float64)).astype(np.float32)
+    wxyz = blend_utils.pose_points_to_world_points(pxyz, torch.from_numpy(R)[None], torch.from_numpy(sk.Th)[None])
+    npz('lbs.npz', sel=sel, A=A, joints=J, big_A=big_A, txyz=txyz[0], pxyz=pxyz[0], wxyz=wxyz[0], R=R,
+        pbounds=data_utils.get_bounds(pxyz[0].numpy().copy()), wbounds=data_utils.get_bounds(wxyz[0].numpy().copy()))
 
 
 def gen_envmap(cfg, synthetic):

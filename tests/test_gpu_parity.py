@@ -539,3 +539,26 @@ def test_streamed_k3_tile_boundaries(relight):
         assert torch.isfinite(sdf3).all() and float(e.max()) < 6e-4 and float(e.mean()) < 6e-5, (n, float(e.max()), float(e.mean()))
     assert eng.hdq_sdf(x_all[:0], 0.125, True).numel() == 0
 
+
+def test_pose_frame_on_device(golden, relight):
+    """N3: ra_pose_frame vs the reference's own functions (golden lbs.npz: bone transforms, T-pose / posed /
+    world vertices, bounds) and vs the oracle (vertex normals, full vertex set)."""
+    from oracle import ra_oracle as O
+    _, _, dev, _, eng = relight
+    g = golden('lbs.npz')
+    sk = synthetic.make_skeleton(0)
+    big_A = T(g['big_A'])
+    o = eng.pose_frame(sk.poses, sk.tjoints, sk.parents, T(sk.tverts).to(dev), T(sk.weights).to(dev), big_A, sk.faces, sk.Rh, sk.Th)
+    sel = T(g['sel'])
+    assert float(err(o.A, g['A']).max()) < 1e-6 and float(err(o.joints, g['joints']).max()) < 1e-6 and float(err(o.R, g['R']).max()) < 1e-6
+    assert float(err(o.tverts.cpu()[sel], g['txyz']).max()) < 3e-6
+    assert float(err(o.pverts.cpu()[sel], g['pxyz']).max()) < 3e-6
+    assert float(err(o.wverts.cpu()[sel], g['wxyz']).max()) < 3e-6
+    ref = O.pose_frame(T(sk.poses), T(sk.tjoints), T(sk.parents), T(sk.tverts), T(sk.weights), big_A, T(sk.faces), T(sk.Rh), T(sk.Th))
+    assert float(err(o.pverts, ref.pverts).max()) < 3e-6 and float(err(o.wverts, ref.wverts).max()) < 3e-6
+    assert float(err(o.pnorm, ref.pnorm).max()) < 1e-4
+    assert float(err(o.pbounds, ref.pbounds).max()) < 3e-6 and float(err(o.wbounds, ref.wbounds).max()) < 3e-6
+    # determinism (fixed summation order) and reuse of the cached adjacency
+    o2 = eng.pose_frame(sk.poses, sk.tjoints, sk.parents, T(sk.tverts).to(dev), T(sk.weights).to(dev), big_A, sk.faces, sk.Rh, sk.Th)
+    assert torch.equal(o.pnorm, o2.pnorm) and torch.equal(o.pverts, o2.pverts)
+
