@@ -11,7 +11,9 @@ tests/golden/make_golden.py (imports /root/reference with third-party stubs) and
 tests/golden/*.npz.  tests/test_oracle_golden.py checks every stage against those fixtures.
 The one third-party op on the path, pytorch3d.ops.knn_points (un-vendored, version unpinned), is
 restated as exact brute-force squared-L2 3-NN, ascending (its documented contract); tie order is
-unpinned.
+unpinned.  Row N3's vertex normals (pytorch3d Meshes.verts_normals, also un-vendored) are restated from the
+published algorithm: PARITY UNPINNED for that function; smplx.lbs' bone transforms are pinned through the
+reference's own numpy twin (lib/utils/data_utils.py:1004-1069).
 
 Compaction (batch_aware_indexing + multi_gather/multi_scatter, net_utils.py:381-461) is restated
 with boolean masks: at B=1 topk(S) of the metric selects exactly the mask-true elements and results
