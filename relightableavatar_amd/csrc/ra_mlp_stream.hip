@@ -25,6 +25,9 @@
 #include "ra_common.hpp"
 #include <type_traits>
 
+#ifndef RA_SCHED
+#define RA_SCHED 0     // 1: pin the per-MFMA-slot instruction order with sched_barrier(0) (A/B: 1 % slower)
+#endif
 #ifndef RA_ABL
 #define RA_ABL 0      // compile-time ablations for timing experiments (tools/): results are garbage when != 0
 #endif
@@ -75,11 +78,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-__device__ __forceinline__ float max0(float z) {       // v_max_f32 without the canonicalising self-max fmaxf() emits
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(z));
-    return r;
-}
+// max(z, 0) as ONE compiler-visible instruction (v_med3_f32 z, 0, +inf): fmaxf() adds a canonicalising self-max, and an
+// inline-asm v_max hides the read of a just-written MFMA accumulator from the hazard recogniser (no wait states inserted:
+// wrong values as soon as the scheduler places it right behind the producing MFMA)
+__device__ __forceinline__ float max0(float z) { return __builtin_amdgcn_fmed3f(z, 0.f, __builtin_inff()); }
 
 template <int ACT>
 __device__ __forceinline__ float act(float z) {
@@ -203,7 +205,7 @@ __device__ __forceinline__ void row_block(Pipe<E, NW>& P, f32x16& acc, const f32
                 }
             });
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (RA_SCHED) __builtin_amdgcn_sched_barrier(0);
     });
 }
 
