@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // max(z, 0) as ONE compiler-visible instruction (v_med3_f32 z, 0, +inf): fmaxf() adds a canonicalising self-max, and an
 // inline-asm v_max hides the read of a just-written MFMA accumulator from the hazard recogniser (no wait states inserted:
 // wrong values as soon as the scheduler places it right behind the producing MFMA)
-__device__ __forceinline__ float max0(float z) { return __builtin_amdgcn_fmed3f(z, 0.f, __builtin_inff()); }
+__device__ __forceinline__ float max0(float z) { return __builtin_amdgcn_fmed3f(z, 0.f, 3.0e38f); }     // finite bound: with +inf LLVM folds it back to two v_max
 
 template <int ACT>
 __device__ __forceinline__ float act(float z) {
