@@ -243,7 +243,7 @@ int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, con
  * T pose -> posed -> world vertices (blend_utils.py:212-218,264-313), vertex normals (pytorch3d Meshes.verts_normals),
  * bounds (data_utils.py:616-622).
  * Host inputs: poses, tjoints (J,3) f32, parents (J) int32 (topological order, parents[0] unused), big_A (J,16) f32,
- * Rh, Th (3) f32, faces (F,3) int32 (cached by pointer + count: keep the array alive and unchanged).
+ * Rh, Th (3) f32, faces (F,3) int32 (its vertex -> corner list is cached by content hash).
  * Device inputs: tverts (N,3), weights (N,J).  Device outputs (any may be NULL): A (J,16), joints (J,3), tpose (N,3),
  * pverts (N,3), wverts (N,3), pnorm (N,3), R (9), pbounds (6), wbounds (6). */
 typedef struct ra_pose_in {

@@ -741,7 +741,9 @@ int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void*
     launch_lbs_verts((const float*)in->tverts, (const float*)in->weights, dA, dB, dR, dR + 9, N, J, (float*)out->tpose, pv, wv, s);
     if (out->pnorm) {
         // incident corners per vertex in index_add order, cached per (faces pointer, count)
-        if (c->adj_faces != in->faces || c->adj_n_faces != F || c->adj_n_verts != N) {
+        unsigned long long fh = 1469598103934665603ull;          // FNV-1a over the face indices: the cache key is the CONTENT
+        for (int k = 0; k < 3 * F; ++k) { fh ^= (unsigned)in->faces[k]; fh *= 1099511628211ull; }
+        if (c->adj_hash != fh || c->adj_n_faces != F || c->adj_n_verts != N) {
             std::vector<int> start(N + 1, 0), adj((size_t)F * 3);
             const int order[3] = {1, 2, 0};
             for (int f = 0; f < F; ++f)
@@ -758,7 +760,7 @@ int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void*
             RA_HIP(hipMemcpy(c->adj_start.p, start.data(), (size_t)(N + 1) * 4, hipMemcpyHostToDevice));
             RA_HIP(hipMemcpy(c->adj_list.p, adj.data(), (size_t)F * 12, hipMemcpyHostToDevice));
             RA_HIP(hipMemcpy(c->adj_dfaces.p, in->faces, (size_t)F * 12, hipMemcpyHostToDevice));
-            c->adj_faces = in->faces; c->adj_n_faces = F; c->adj_n_verts = N;
+            c->adj_hash = fh; c->adj_n_faces = F; c->adj_n_verts = N;
         }
         launch_vert_normals(pv, c->adj_dfaces.as<int>(), c->adj_start.as<int>(), c->adj_list.as<int>(), N, (float*)out->pnorm, s);
     }

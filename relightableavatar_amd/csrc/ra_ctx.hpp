@@ -38,7 +38,7 @@ struct ra_ctx {
     bool use_bvh = true;
     // N3: vertex -> incident corners of the template mesh (built once per faces array)
     DevBuf adj_start, adj_list, adj_dfaces;
-    const int* adj_faces = nullptr;
+    unsigned long long adj_hash = 0;
     int adj_n_faces = 0, adj_n_verts = 0;
     // scratch (grow-only)
     std::map<std::string, DevBuf> scratch;

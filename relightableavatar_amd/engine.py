@@ -229,11 +229,7 @@ class Engine:
         h32 = lambda a: np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
         hp, hj, hb, hr, ht = h32(poses).reshape(-1, 3), h32(tjoints).reshape(-1, 3), h32(big_A).reshape(-1, 16), h32(Rh).reshape(3), h32(Th).reshape(3)
         par = np.ascontiguousarray(parents.cpu().numpy() if isinstance(parents, torch.Tensor) else parents, dtype=np.int32)
-        key = id(faces)
-        if getattr(self, '_faces_key', None) != key:            # the C side caches the adjacency by pointer: keep one int32 copy alive
-            self._faces_host = np.ascontiguousarray(faces.cpu().numpy() if isinstance(faces, torch.Tensor) else faces, dtype=np.int32).reshape(-1, 3)
-            self._faces_key = key
-        fc = self._faces_host
+        fc = np.ascontiguousarray(faces.cpu().numpy() if isinstance(faces, torch.Tensor) else faces, dtype=np.int32).reshape(-1, 3)
         d = self.device
         tv, w = _f32(tverts.reshape(-1, 3) if isinstance(tverts, torch.Tensor) else torch.as_tensor(tverts).reshape(-1, 3), d), \
             _f32(weights if isinstance(weights, torch.Tensor) else torch.as_tensor(weights), d)
