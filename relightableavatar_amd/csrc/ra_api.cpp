@@ -578,15 +578,27 @@ int ra_render_volume_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     const int S = n_samples, C = 16;
-    const size_t N = (size_t)P * S;
+    const size_t N = (size_t)((P + 63) & ~63) * S;          // samples are laid out per group of 64 rays (padded)
     RA_CHECK(N < (1u << 30), "ra_render_volume_chunk: chunk too large");
+    // spatially coherent ray order (Morton code of the entry point); outputs go back through the permutation
+    const size_t tb = sort_hits_temp_bytes(P);
+    unsigned* k0 = c->buf<unsigned>("hs_k0", P, &err);
+    unsigned* k1 = c->buf<unsigned>("hs_k1", P, &err);
+    int* v0 = c->buf<int>("hs_v0", P, &err);
+    int* perm = c->buf<int>("rs_perm", P, &err);
+    char* tmp = c->buf<char>("hs_tmp", tb + 16, &err);
+    float* so = c->buf<float>("rs_o", (size_t)P * 3, &err);
+    float* sd = c->buf<float>("rs_d", (size_t)P * 3, &err);
+    float* sn = c->buf<float>("rs_n", P, &err);
+    float* sf = c->buf<float>("rs_f", P, &err);
     float* xs = c->buf<float>("vl_x", N * 3, &err);
     float* vs = c->buf<float>("vl_v", N * 3, &err);
     float* raw = c->buf<float>("vl_raw", N * C, &err);
     if (err) return 1;
-    launch_volume_samples(ray_o, ray_d, near_, far_, P, S, xs, vs, s);
+    if (launch_sort_rays(ray_o, ray_d, near_, far_, P, nullptr, k0, k1, v0, perm, tmp, tb, so, sd, sn, sf, s)) { ra_set_error("ra_render_volume_chunk: radix sort failed"); return 1; }
+    launch_volume_samples(so, sd, sn, sf, P, S, xs, vs, s);
     if (forward_pass(c, xs, vs, (int)N, nullptr, dist_th, raw, s)) return 1;
-    launch_volume_composite(raw, C, near_, far_, P, S, c->cfg.bg_brightness, *out, s);
+    launch_volume_composite(raw, C, sn, sf, P, S, c->cfg.bg_brightness, *out, perm, s);
     RA_HIP(hipGetLastError());
     return 0;
 }

@@ -128,7 +128,7 @@ void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s)
 void launch_volume_samples(const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P, int S,
                            float* x, float* v, hipStream_t s);
 void launch_volume_composite(const float* raw, int C, const float* near_, const float* far_, int P, int S, float bg,
-                             const ra_render_out& out, hipStream_t s);
+                             const ra_render_out& out, const int* perm, hipStream_t s);
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
 void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s);
 

@@ -161,15 +161,40 @@ __global__ void hit_keys_kernel(const float* __restrict__ surf, const float* __r
 // sort key of a primary ray: Morton code of its entry point (o + near d) on a 1/256 m grid inside the box, so that
 // the 64 rays of a wave start (and stay) close together -> compact box sweeps in the coarse level
 __global__ void ray_keys_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr, int P,
-                                float bx, float by, float bz, unsigned* __restrict__ keys, int* __restrict__ vals) {
+                                float bx, float by, float bz, const float* __restrict__ origin_dev, unsigned* __restrict__ keys,
+                                int* __restrict__ vals) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= P) return;
+    if (origin_dev) { bx = origin_dev[0]; by = origin_dev[1]; bz = origin_dev[2]; }
     const float t = nr[i];
     const unsigned qx = (unsigned)fminf(fmaxf((ro[3 * i] + t * rd[3 * i] - bx) * 256.f, 0.f), 1023.f);
     const unsigned qy = (unsigned)fminf(fmaxf((ro[3 * i + 1] + t * rd[3 * i + 1] - by) * 256.f, 0.f), 1023.f);
     const unsigned qz = (unsigned)fminf(fmaxf((ro[3 * i + 2] + t * rd[3 * i + 2] - bz) * 256.f, 0.f), 1023.f);
     keys[i] = (expand10t(qx) << 2) | (expand10t(qy) << 1) | expand10t(qz);
     vals[i] = i;
+}
+
+// lower corner of the rays' entry points (one workgroup): origin of the Morton grid when the caller gives no box
+__global__ __launch_bounds__(1024) void entry_min_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr,
+                                                         int P, float* __restrict__ out) {
+    __shared__ float sm_[16][3];
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f};
+    for (int i = threadIdx.x; i < P; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lo[c] = fminf(lo[c], ro[3 * i + c] + nr[i] * rd[3 * i + c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sm_[threadIdx.x >> 6][c] = lo[c];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float a = sm_[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w) a = fminf(a, sm_[w][threadIdx.x]);
+        out[threadIdx.x] = a;
+    }
 }
 
 __global__ void gather_rays_kernel(const int* __restrict__ perm, int P, const float* __restrict__ ro, const float* __restrict__ rd,
@@ -564,11 +589,19 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
 }
 
 // ------------------------------------------------------------------------------------------ volume path
+// sample (ray r, depth s) lives at ((r / 64) * S + s) * 64 + r % 64: a wave = 64 neighbouring rays (the chunk's rays are
+// Morton-sorted) at ONE depth, so the coarse level sweeps a centimetre-sized patch instead of half a ray
+__device__ __forceinline__ size_t vol_slot(int r, int s, int S) { return ((size_t)(r >> 6) * S + s) * 64 + (r & 63); }
+
 __global__ void volume_samples_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ nr,
                                       const float* __restrict__ fr, int P, int S, float* __restrict__ x, float* __restrict__ v) {
     const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (k >= (long long)P * S) return;
-    const int r = (int)(k / S), s = (int)(k - (long long)r * S);
+    const int Pp = (P + 63) & ~63;
+    if (k >= (long long)Pp * S) return;
+    const int j = (int)(k & 63);
+    const long long gs = k >> 6;
+    const int s = (int)(gs % S), rg = (int)(gs / S);
+    const int r = min(rg * 64 + j, P - 1);                      // padding slots repeat the last ray (never composited)
     const float tv = linspace01(s, S);
     const float z = nr[r] * (1.f - tv) + fr[r] * tv;            // base_renderer.py:17-18
 #pragma unroll
@@ -579,7 +612,7 @@ __global__ void volume_samples_kernel(const float* __restrict__ ro, const float*
 }
 
 __global__ void volume_composite_kernel(const float* __restrict__ raw, int C, const float* __restrict__ nr, const float* __restrict__ fr,
-                                        int P, int S, float bg, ra_render_out out) {
+                                        int P, int S, float bg, ra_render_out out, const int* __restrict__ perm) {
     const int r = blockIdx.x * TPB + threadIdx.x;
     if (r >= P) return;
     float o[16];
@@ -589,7 +622,7 @@ __global__ void volume_composite_kernel(const float* __restrict__ raw, int C, co
     float T = 1.f, acc = 0.f, depth = 0.f;
     const float n_ = nr[r], f_ = fr[r];
     for (int s = 0; s < S; ++s) {
-        const float* p = raw + ((size_t)r * S + s) * C;
+        const float* p = raw + vol_slot(r, s, S) * C;
         const float a = p[CC];
         const float w = a * T;
         T *= (1.f - a + 1e-8f);
@@ -600,15 +633,16 @@ __global__ void volume_composite_kernel(const float* __restrict__ raw, int C, co
             for (int c = 0; c < CC; ++c) o[c] += w * p[c];
     }
     for (int c = 0; c < CC; ++c) o[c] += (1.f - acc) * bg;
-    if (out.acc) out.acc[r] = acc;
-    if (out.depth) out.depth[r] = depth;
+    const int w_ = perm ? perm[r] : r;                          // internal (sorted) ray -> caller's ray index
+    if (out.acc) out.acc[w_] = acc;
+    if (out.depth) out.depth[w_] = depth;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        if (out.cpts) out.cpts[3 * r + c] = o[c];
-        if (out.bpts) out.bpts[3 * r + c] = o[3 + c];
-        if (out.resd) out.resd[3 * r + c] = o[6 + c];
-        if (out.norm) out.norm[3 * r + c] = o[9 + c];
-        if (out.rgb) out.rgb[3 * r + c] = o[12 + c];
+        if (out.cpts) out.cpts[3 * w_ + c] = o[c];
+        if (out.bpts) out.bpts[3 * w_ + c] = o[3 + c];
+        if (out.resd) out.resd[3 * w_ + c] = o[6 + c];
+        if (out.norm) out.norm[3 * w_ + c] = o[9 + c];
+        if (out.rgb) out.rgb[3 * w_ + c] = o[12 + c];
     }
 }
 
@@ -1023,7 +1057,13 @@ int launch_sort_rays(const float* ro, const float* rd, const float* nr, const fl
                      unsigned* keys_out, int* vals_in, int* perm, void* temp, size_t temp_bytes, float* so, float* sd, float* sn, float* sf,
                      hipStream_t s) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(ray_keys_kernel, grid_for(P), dim3(TPB), 0, s, ro, rd, nr, P, bbox_min[0], bbox_min[1], bbox_min[2], keys_in, vals_in);
+    float* origin_dev = nullptr;
+    if (!bbox_min) {            // no box from the caller: the grid starts at the lower corner of the entry points (device side)
+        origin_dev = reinterpret_cast<float*>(keys_out);        // 12 bytes of the sort's output buffer, consumed before the sort runs
+        hipLaunchKernelGGL(entry_min_kernel, dim3(1), dim3(1024), 0, s, ro, rd, nr, P, origin_dev);
+    }
+    hipLaunchKernelGGL(ray_keys_kernel, grid_for(P), dim3(TPB), 0, s, ro, rd, nr, P, bbox_min ? bbox_min[0] : 0.f, bbox_min ? bbox_min[1] : 0.f,
+                       bbox_min ? bbox_min[2] : 0.f, origin_dev, keys_in, vals_in);
     if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, perm, P, 0, 32, s) != hipSuccess) return 1;
     hipLaunchKernelGGL(gather_rays_kernel, grid_for(P), dim3(TPB), 0, s, perm, P, ro, rd, nr, fr, so, sd, sn, sf);
     return 0;
@@ -1047,11 +1087,11 @@ void launch_fill(float* p, size_t n, float v, hipStream_t s) {
 void launch_volume_samples(const float* ray_o, const float* ray_d, const float* near_, const float* far_, int P, int S, float* x,
                            float* v, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(volume_samples_kernel, grid_for((long long)P * S), dim3(TPB), 0, s, ray_o, ray_d, near_, far_, P, S, x, v);
+    hipLaunchKernelGGL(volume_samples_kernel, grid_for((long long)((P + 63) & ~63) * S), dim3(TPB), 0, s, ray_o, ray_d, near_, far_, P, S, x, v);
 }
 
 void launch_volume_composite(const float* raw, int C, const float* near_, const float* far_, int P, int S, float bg,
-                             const ra_render_out& out, hipStream_t s) {
+                             const ra_render_out& out, const int* perm, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(volume_composite_kernel, grid_for(P), dim3(TPB), 0, s, raw, C, near_, far_, P, S, bg, out);
+    hipLaunchKernelGGL(volume_composite_kernel, grid_for(P), dim3(TPB), 0, s, raw, C, near_, far_, P, S, bg, out, perm);
 }
