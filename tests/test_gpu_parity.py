@@ -402,6 +402,9 @@ def test_rccl_path_world1_under_torchrun():
                                '--size', '128', '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=600)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['roofline']['achieved'] > 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in line, k
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline']) and 'workload' in line['config']
 
 
 def test_ray_generation_on_device(golden, relight):
