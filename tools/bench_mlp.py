@@ -1,4 +1,4 @@
-"""micro-benchmark of the fused HDQ MLP kernel (K3) on 5.1 M fine points; prints HIP-event time and TFLOP/s."""
+"""micro-benchmark of the fused HDQ MLP kernel (K3) on 64 * RA_NV (default 5.1 M) fine points; prints HIP-event time and TFLOP/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ net = net.to(dev).eval()
 body = synthetic.to_device(synthetic.make_body(0, posed=True), dev)
 eng = net.set_frame(body)
 g = torch.Generator().manual_seed(0)
-vid = torch.randint(0, 6890, (80000,), generator=g)
+vid = torch.randint(0, 6890, (int(os.environ.get('RA_NV', '80000')),), generator=g)
 wv = (body.pverts[0] @ body.R[0].T + body.Th[0])[vid.to(dev)]
 dirs = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1).to(dev)
 x = (wv[:, None, :] + 0.02 * dirs[None]).reshape(-1, 3).contiguous()
