@@ -22,6 +22,7 @@ from relightableavatar_amd.renderer import make_renderer    # noqa: E402
 
 F_SDF = 1_901_568          # algorithmic FLOP per fine distance query
 F_FULL = 3_934_208 + 197_632
+F_FULL_ANISDF = 3_934_208 + 541_184       # volume path: geometry point with normal + colour net
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
@@ -136,14 +137,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     cnt = eng.counters()
-    mlp_ms, mlp_launches = eng.mlp_time()
+    mlp_ms, mlp_launches = eng.kernel_time(1 if args.mode == 'anisdf' else 0)
     cnts = torch.tensor([cnt.n_fine_sdf, cnt.n_fine_full, cnt.n_coarse, cnt.n_hit_pixels, cnt.n_shadow_rays], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(cnts)
     if rank == 0:
         ms = dt / args.steps * 1e3
-        achieved = (cnt.n_fine_sdf * F_SDF) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         kname = {'1': 'mlp_sdf_kernel', '2': 'mlp_sdf_pipe_kernel'}.get(os.environ.get('RA_MLP_GEN', '3'), 'mlp_sdf_stream_kernel')
+        units, f_unit = cnt.n_fine_sdf, F_SDF
+        if args.mode == 'anisdf':           # the volume path has no distance-only queries: its dominant kernel is the full query
+            kname, units, f_unit = 'mlp_full_kernel', cnt.n_fine_full, F_FULL_ANISDF
+        achieved = (units * f_unit) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel'
         line = {
             'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
@@ -158,8 +162,8 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
                          'traffic': hbm_traffic_per_launch(kname) if default_cmd else None, 'traffic_unit': 'B/launch (offline PMC pass of this command, profiles/r01_relight512_pmc.csv)',
                          'kernel': kname, 'launches': mlp_launches,
-                         'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': F_SDF,
-                         'units_per_launch': cnt.n_fine_sdf / max(mlp_launches, 1)},
+                         'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': f_unit,
+                         'units_per_launch': units / max(mlp_launches, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, H)

@@ -184,6 +184,8 @@ int ra_reset_counters(ra_ctx* ctx, void* stream);
 /* time (ms) spent in the fused MLP kernel launches since the last reset, measured with HIP
  * events on `stream`; n_launches receives the launch count.  Synchronises. */
 int ra_get_mlp_time(ra_ctx* ctx, float* ms, int* n_launches, void* stream);
+/* the same for one kernel family: kind 0 = fused distance query (K3), 1 = full query with normals / material / colour (K4) */
+int ra_get_kernel_time(ra_ctx* ctx, int kind, float* ms, int* n_launches, void* stream);
 int ra_enable_timing(ra_ctx* ctx, int on);
 /* 1 (default): exact 3-NN through the per-frame vertex BVH; 0: brute force over all vertices (validation path).
  * Takes effect at the next ra_set_frame. Both return identical neighbours. */

@@ -103,6 +103,7 @@ SYMBOLS = {
     'ra_get_counters': (C.c_int, [C.c_void_p, C.POINTER(ra_counters), C.c_void_p]),
     'ra_reset_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ra_get_mlp_time': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
+    'ra_get_kernel_time': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
     'ra_enable_timing': (C.c_int, [C.c_void_p, C.c_int]),
     'ra_set_knn_mode': (C.c_int, [C.c_void_p, C.c_int]),
     'ra_pose_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_pose_in), C.POINTER(ra_pose_out), C.c_void_p]),

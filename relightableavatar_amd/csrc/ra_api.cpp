@@ -867,14 +867,15 @@ int ra_enable_timing(ra_ctx* c, int on) {
     return 0;
 }
 
-int ra_get_mlp_time(ra_ctx* c, float* ms, int* n_launches, void* stream) {
-    RA_CHECK(c && ms && n_launches, "ra_get_mlp_time: null argument");
+int ra_get_kernel_time(ra_ctx* c, int kind, float* ms, int* n_launches, void* stream) {
+    RA_CHECK(c && ms && n_launches, "ra_get_kernel_time: null argument");
+    RA_CHECK(kind == 0 || kind == 1, "ra_get_kernel_time: kind must be 0 (distance query) or 1 (full query)");
     RA_HIP(hipSetDevice(c->device));
     RA_HIP(hipStreamSynchronize((hipStream_t)stream));
     float tot = 0.f;
     int n = 0;
     for (size_t i = 0; i < c->ev_used; ++i) {
-        if (c->ev_kind[i] != 0) continue;
+        if (c->ev_kind[i] != kind) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { tot += t; ++n; }
     }
@@ -882,6 +883,8 @@ int ra_get_mlp_time(ra_ctx* c, float* ms, int* n_launches, void* stream) {
     *n_launches = n;
     return 0;
 }
+
+int ra_get_mlp_time(ra_ctx* c, float* ms, int* n_launches, void* stream) { return ra_get_kernel_time(c, 0, ms, n_launches, stream); }
 
 // ---- test hooks: stage outputs for parity tests (not used by the renderers) -------------------
 int ra_debug_mlp(ra_ctx* c, const float* bpts, int n, float* resd, float* sdf, float* feat, void* stream) {

@@ -275,6 +275,12 @@ class Engine:
         check(self.lib.ra_get_mlp_time(self.ctx, C.byref(ms), C.byref(n), self.stream), 'ra_get_mlp_time')
         return float(ms.value), int(n.value)
 
+    def kernel_time(self, kind):
+        """(ms, launches) of one kernel family since the last reset: 0 = fused distance query (K3), 1 = full query (K4)."""
+        ms, n = C.c_float(), C.c_int()
+        check(self.lib.ra_get_kernel_time(self.ctx, int(kind), C.byref(ms), C.byref(n), self.stream), 'ra_get_kernel_time')
+        return float(ms.value), int(n.value)
+
     # ------------------------------------------------------------------ test hooks
     def debug_mlp(self, bpts, want_feat=True):
         d = self.device
