@@ -1,13 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/s for a 512x512 full-relight frame (16x32 light probe, DFSS visibility)
-on synthetic weights, N GPUs of one node (one process per GPU, rays dealt round-robin, one RCCL
+on synthetic weights, N GPUs of one node (one process per GPU, pixels dealt in 8x8 tiles, one RCCL
 all_gather per frame).  Prints ONE JSON line on rank 0 (see the contract in the task statement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--mode relight|sphere|anisdf]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--mode relight|sphere_tracing|anisdf|novel_light]
+
+`--gpus N` with N > 1 outside a torchrun environment makes this process a LAUNCHER: it never touches the GPU, starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (env:// rendezvous on 127.0.0.1, like the
+reference's train.py:116-122), relays rank 0's JSON line and exits with the child's status.  Under torchrun (RANK set, the way
+the driver starts it) the same file is the rank program.  `--backend gloo --dry` runs launcher + rank plumbing (process group,
+shard plan, frame all_gather, barrier, MAX reduce, JSON line) on CPU tensors without the HIP engine: the CPU test of the N > 1 path.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,15 +59,71 @@ def cpu_baseline(cfg, H, n_target=768, threads=16):
 
 
 def hbm_traffic_per_launch(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own
-    passes, tools/collect_profiles.sh): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_relight512_pmc.csv')
-    try:
-        rows = [l.strip().split(',') for l in open(path) if l.startswith(kernel + ',')]
-        v = {r[1]: (float(r[2]), int(r[3])) for r in rows}
-        return (2.0 * v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1] + v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]) * 1024.0
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary of this command (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in their own passes, tools/collect_profiles.sh rewrites it whenever kernels change): FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads.  Returns (bytes, file name)."""
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r[0-9][0-9]_relight512_pmc.csv')))
+    for path in reversed(files):
+        try:
+            rows = [l.strip().split(',') for l in open(path) if l.startswith(kernel + ',')]
+            v = {r[1]: (float(r[2]), int(r[3])) for r in rows}
+            return (2.0 * v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1] + v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]) * 1024.0, os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def launch_ranks(args, argv):
+    """parent of an N-rank job: has not initialised the GPU and never does (no exec of a GPU-initialised process either)."""
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    if r.returncode != 0 or not lines:
+        sys.stdout.write(r.stdout[-4000:])
+        raise SystemExit(r.returncode or 1)
+    print(lines[-1])
+    raise SystemExit(0)
+
+
+def dry_rank(args, rank, world):
+    """the rank program without the HIP engine: process group, shard plan, a stand-in render of this rank's rays, the frame
+    all_gather, barrier + MAX reduce, the JSON line.  What the gloo test of the N > 1 path runs."""
+    dist.init_process_group(args.backend)
+    H = args.size
+    base = synthetic.make_batch(H, H, seed=0, posed=True)
+    P = base.ray_o.shape[1]
+    ref = torch.stack([base.ray_d[0, :, 0], base.ray_d[0, :, 1], base.near[0], base.far[0]], -1)[None]       # a per-ray "image"
+
+    def step():
+        sb = shard.shard_batch(base, rank, world, 65536)
+        local = torch.stack([sb.ray_d[0, :, 0], sb.ray_d[0, :, 1], sb.near[0], sb.far[0]], -1)[None]
+        return shard.gather_maps(local, P, rank, world, batch=base)
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = torch.tensor([1.0 if torch.equal(out, ref) else 0.0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        dt = float(tt.item())
+        print(json.dumps({'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'dry run: no kernels, plumbing only',
+                          'config': {'workload': f'DRY {H}x{H}', 'backend': args.backend, 'gather_ok': bool(ok.item() == 1.0)},
+                          'roofline': None}))
+    dist.destroy_process_group()
+    if ok.item() != 1.0:
+        raise SystemExit('dry run: the gathered frame differs from the whole frame')
 
 
 def main():
@@ -73,11 +138,26 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ground', action='store_true', help='relight: add the ground-plane pass (cfg.vis_ground_shading, SURVEY.md 8f row N1)')
     ap.add_argument('--emulate-world', type=int, default=0, help='tuning aid: render only rank 0\'s shard of an N-rank job on one GPU (no collective); value is then NOT a whole-job rate')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL on ROCm; gloo only with --dry')
+    ap.add_argument('--dry', action='store_true', help='no HIP engine: launcher + process-group plumbing on CPU tensors (CPU test of the N > 1 path)')
+    ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != max(args.gpus, 1) and 'RANK' in os.environ and args.gpus != 1:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.dry:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'RANK' not in os.environ:
+            os.environ.setdefault('MASTER_PORT', '29577')
+            os.environ.update(RANK='0', WORLD_SIZE='1')
+        return dry_rank(args, rank, world)
+    if args.backend != 'nccl':
+        raise SystemExit('bench.py: the render path runs on MI355X GPUs over RCCL (backend nccl); gloo is for --dry')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs MI355X GPUs (the render path has no CPU fallback)')
     torch.cuda.set_device(local)
@@ -96,7 +176,8 @@ def main():
     net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
     net = net.to(dev).eval()
     renderer = make_renderer(cfg, net)
-    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0), dev)
+    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0,
+                                                    skin_noise=args.skin_noise), dev)
     P = base.ray_o.shape[1]
     wb0 = base.wbounds.clone()
     mask0 = base.mask_at_box.clone()
@@ -104,14 +185,15 @@ def main():
 
     def step():
         base.wbounds.copy_(wb0)     # a fresh batch per frame, as the reference's loader delivers
+        eng.set_frame(base, force=True)     # an animation poses a new body every frame: vertex blend, BVH build, bias folds are timed
         if args.ground:
             base.mask_at_box.copy_(mask0)   # the ground pass sets it to all-true in place (sphere_tracing_renderer.py:1103)
         if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
-            out = renderer.render(shard.shard_batch(base, rank, world))
+            out = renderer.render(shard.shard_batch(base, rank, world, cfg.render_chunk_size))
             rgb = torch.cat([out[n].rgb_map for n in base.novel_lights], dim=-1)
             return shard.gather_maps(rgb, P, rank, world, batch=base)
         if args.emulate_world > 1:
-            return renderer.render(shard.shard_batch(base, 0, args.emulate_world))
+            return renderer.render(shard.shard_batch(base, 0, args.emulate_world, cfg.render_chunk_size))
         return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world)
 
     def sync():
@@ -148,7 +230,8 @@ def main():
         if args.mode == 'anisdf':           # the volume path has no distance-only queries: its dominant kernel is the full query
             kname, units, f_unit = 'mlp_full_kernel', cnt.n_fine_full, F_FULL_ANISDF
         achieved = (units * f_unit) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-        default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel'
+        default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel' and not args.ground
+        traffic, traffic_src = hbm_traffic_per_launch(kname) if default_cmd else (None, None)
         line = {
             'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
@@ -160,11 +243,14 @@ def main():
                        'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
                        'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'8x8 pixel tiles dealt over {world} GPU(s) + one all_gather'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
-                         'traffic': hbm_traffic_per_launch(kname) if default_cmd else None, 'traffic_unit': 'B/launch (offline PMC pass of this command, profiles/r01_relight512_pmc.csv)',
+                         'traffic': traffic, 'traffic_unit': f'B/launch (offline PMC passes of this command, profiles/{traffic_src})',
                          'kernel': kname, 'launches': mlp_launches,
                          'avg_launch_ms': mlp_ms / max(mlp_launches, 1), 'flop_per_unit': f_unit,
                          'units_per_launch': units / max(mlp_launches, 1)},
         }
+        line['hit_pixels_per_sec'] = cnts[3].item() / dt          # the 84 % of rays that miss the box cost nothing: rays/s flatters
+        line['fine_queries_per_sec'] = cnts[0].item() / dt
+        line['config']['frame_setup'] = 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, H)
         print(json.dumps(line))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 1
+#define RA_ABI_VERSION 2
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -91,6 +91,21 @@ int ra_set_frame(ra_ctx* ctx, const ra_frame* frame, void* stream);
  * query. x: n x 3 world points -> sdf: n. */
 int ra_hdq_sdf(ra_ctx* ctx, const float* x_dev, int n, float dist_th, int smooth_transition,
                float* sdf_dev, void* stream);
+
+/* Network.inference_observed_distance_field with filtering=False (base_network.py:389-449): x are big-pose points,
+ * sdf = SDF(x + resd(x, pose)) -> sdf: n.  Runs the production distance-query kernel (K3) without the coarse level.  The
+ * filtered variant is the hierarchical query above on a frame whose posed body IS the template (pverts = tverts, A = I). */
+int ra_observed_sdf(ra_ctx* ctx, const float* bpts_dev, int n, float* sdf_dev, void* stream);
+
+/* Network.world_to_bigpose_transform / bigpose_to_world_transform (base_network.py:338-363): per point the 4x4
+ * w2b = big_A_bw @ affine_inverse(A_bw) @ affine_inverse([R | Th]) with the blended bone transforms of the point's 3 nearest
+ * vertices of the ctx's CURRENT frame (no distance filtering); invert != 0 returns affine_inverse(w2b) instead.  R (9) and
+ * Th (3) are device pointers to the world <- pose transform used in the composition: the backward variant searches the
+ * template (caller sets a frame with pverts = tverts, R = I, Th = 0) but composes with the real frame's R, Th.
+ * affine_inverse transposes the 3x3 block (blend_utils.py:11-15) also for blended, non-rigid matrices, as the reference does.
+ * out: n x 16 row-major. */
+int ra_bigpose_transform(ra_ctx* ctx, const float* x_dev, int n, const float* R_dev, const float* Th_dev, int invert,
+                         float* out_dev, void* stream);
 
 /* Network.forward in eval mode (relight_network.py:91-104 / base_network.py:496-515).
  * x, v: n x 3 (v may be NULL for the relight network); raw: n x ra_raw_channels(), zeros for
@@ -169,6 +184,15 @@ int ra_reshade(ra_ctx* ctx, const float* ray_o, const float* surf, const float* 
                int P, const float* probes_dev, int n_probes, int probe_h, int probe_w,
                float* rgb, float* shade, float* spec, void* stream);
 
+/* novel_light_sphere_tracing.render_ground (:70-99): re-shade the ground layer of the main pass under n_probes probes from its
+ * cached per-light visibility and cosine (ra_ground_out.lvis / .ldot of ALL frame pixels, P x 512 each): Lambert ground,
+ * rgb = linear2srgb(albedo / pi * sum_l lvis ldot area L_probe(l)), shade = sum / pi, spec = shade / 20 (no shading_albedo, no
+ * ground_shading_multiplier here).  albedo: attach_envmap != 0 -> the probe's image (images: n_probes x ih x iw x 3, or NULL ->
+ * the probe itself) sampled along ray_d (:79-83), else albedo_map (P x 3).  Outputs n_probes x P x 3 each, any may be NULL. */
+int ra_reshade_ground(ra_ctx* ctx, const float* ray_d, const float* albedo_map, const float* lvis, const float* ldot, int P,
+                      const float* probes_dev, int n_probes, int probe_h, int probe_w, const float* images_dev, int image_h, int image_w,
+                      int attach_envmap, float* rgb, float* albedo, float* shade, float* spec, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct ra_counters {       /* cumulative since ra_reset_counters; read with a sync  */
     uint64_t n_coarse;             /* 3-NN queries (K1)                                       */
@@ -214,6 +238,8 @@ typedef struct ra_ground_out {  /* device buffers with P rows, any may be NULL *
     void* shade;    /* (P,3) shade_map (multiplier applied) */
     void* spec;     /* (P,3) spec_map = shade / 20 */
     void* depth;    /* (P)   t clipped to +-env_r */
+    void* lvis;     /* (P,512) visibility after the distance fade (render_ground :505), cfg.vis_novel_light (:541-543) */
+    void* ldot;     /* (P,512) ground normal . light direction, not clamped (:504) */
 } ra_ground_out;
 
 /* ray_o, ray_d: (P,3); acc: (P) = 1 - human acc (pixels with acc <= 0 are not traced and come back as zeros);
@@ -277,6 +303,15 @@ int ra_debug_full(ra_ctx* ctx, const float* bpts_dev, int n, float* grad, float*
  * bpts/tpts n x 3, blended (A|big_A) rows n x 24 (zeros elsewhere); fine_count_host receives the count (synchronises) */
 int ra_debug_hdq(ra_ctx* ctx, const float* x_dev, int n, float dist_th, float* sdf_coarse, float* sdf_batch, int* nn_batch,
                  float* d2, float* bpts, float* tpts, float* mats, int* fine_count_host, void* stream);
+
+/* get_near_far_aabb (net_utils.py:1683-1712, return_raw) on n rays: the slab test the shadow-ray generator runs inline */
+int ra_debug_aabb(ra_ctx* ctx, const float* o_dev, const float* d_dev, int n, const float* bbox_host6, float* near_dev, float* far_dev, void* stream);
+/* light_visibility (sphere_tracing_renderer.py:265-344) for n surface points: surf, norm n x 3, acc n -> lvis, ldot n x 512 */
+int ra_debug_lvis(ra_ctx* ctx, const float* surf_dev, const float* norm_dev, const float* acc_dev, int n, const float* bbox_host6,
+                  const ra_trace_params* shadow, float near_offset, float* lvis_dev, float* ldot_dev, void* stream);
+/* Microfacet.__call__ (relight_utils.py:484-577): pts2l L x N x 3, pts2c / normal / albedo N x 3, rough N -> brdf L x N x 3 */
+int ra_debug_brdf(ra_ctx* ctx, const float* p2l_dev, const float* p2c_dev, const float* normal_dev, const float* albedo_dev,
+                  const float* rough_dev, int L, int N, float* brdf_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -291,8 +291,15 @@ def geodesic_knn(pts, verts, norm, tverts, K, th):
 class OracleNet:
     """Plain-weight view of the reference state_dict + frame-independent ops."""
 
-    def __init__(self, sd: dict, cfg):
+    def __init__(self, sd: dict, cfg, emulate: Optional[str] = None, kernel_like: bool = False):
+        """emulate: None (fp32, the reference's arithmetic) | 'f16' | 'bf16' — every nn.Linear of the MLPs rounds its input
+        and its weight to that type and accumulates in fp32 (what a 16-bit-operand MFMA does; SURVEY.md:305 probe).  It is the
+        floor any 16-bit-operand kernel can reach.  kernel_like additionally mirrors the HIP kernels' two deliberate
+        deviations from a plain operand rounding: the pose condition enters through an fp32 per-frame bias (never rounded), and
+        the coordinate / frequency-0 encoding channels of the SDF net's two encoding-fed layers are carried as hi + lo pairs."""
         self.cfg = cfg
+        self.emulate = {None: None, 'f32': None, 'f16': torch.float16, 'bf16': torch.bfloat16}[emulate]
+        self.kernel_like = bool(kernel_like) and self.emulate is not None
         f = lambda k: sd[k].detach().float().clone()
         self.resd = [(f(f'residual_deformation_network.mlp.linears.{i}.weight'),
                       f(f'residual_deformation_network.mlp.linears.{i}.bias')) for i in range(9)]
@@ -319,14 +326,36 @@ class OracleNet:
         g = self.global_env_map_
         return F.softplus(g.expand(*g.shape[:2], 3))   # relight_network.py:86-89
 
+    def _q(self, t):
+        return t if self.emulate is None else t.to(self.emulate).float()
+
+    def lin(self, x, w, b, exact_cols=None, hilo_cols=None):
+        """F.linear with the operand rounding of the emulation mode.  exact_cols: slice of input columns that stay fp32
+        (the kernel folds them into a bias); hilo_cols: index list of input columns fed as hi + lo pairs against the same
+        rounded weight (residual of the first rounding rounded again)."""
+        if self.emulate is None:
+            return F.linear(x, w, b)
+        xq, wq = self._q(x), self._q(w)
+        if self.kernel_like and hilo_cols is not None:
+            xq = xq.clone()
+            xq[..., hilo_cols] = xq[..., hilo_cols] + self._q(x[..., hilo_cols] - xq[..., hilo_cols])
+        if self.kernel_like and exact_cols is not None:
+            xq = xq.clone()
+            xq[..., exact_cols] = x[..., exact_cols]
+            wq = wq.clone()
+            wq[:, exact_cols] = w[:, exact_cols]
+        return F.linear(xq, wq, b)
+
     def residuals(self, bpts, cond):
         """base_network.py:34-42 + MLP net_utils.py:1263-1273 (ReLU, skip at 4 as cat([x, input]))."""
-        inp = torch.cat([positional_encoding(bpts, self.cfg.xyz_res), cond.expand(bpts.shape[0], -1)], dim=-1)
+        pe = positional_encoding(bpts, self.cfg.xyz_res)
+        inp = torch.cat([pe, cond.expand(bpts.shape[0], -1)], dim=-1)
         x = inp
         for i, (w, b) in enumerate(self.resd):
             if i == 4:
                 x = torch.cat([x, inp], dim=-1)
-            x = F.linear(x, w, b)
+            c0 = (0 if i == 0 else 256) + pe.shape[-1]
+            x = self.lin(x, w, b, exact_cols=slice(c0, c0 + cond.shape[-1]) if i in (0, 4) else None)
             if i < 8:
                 x = F.relu(x)
         return torch.tanh(x) * self.cfg.resd_limit
@@ -336,9 +365,17 @@ class OracleNet:
         inp = positional_encoding(cpts, self.cfg.sdf_res)
         x = inp
         for l, (w, b) in enumerate(self.sdf):
+            hilo = None
             if l == 4:
-                x = torch.cat([x, inp], dim=-1) / math.sqrt(2)
-            x = F.linear(x, w, b)
+                x = torch.cat([x, inp], dim=-1)
+                if self.emulate is None:
+                    x = x / math.sqrt(2)
+                else:
+                    w = w / math.sqrt(2)         # the kernel folds 1/sqrt(2) into lin4's weights
+                hilo = [x.shape[-1] - inp.shape[-1] + k for k in range(9)]
+            elif l == 0:
+                hilo = list(range(9))            # x, sin(x), cos(x)
+            x = self.lin(x, w, b, hilo_cols=hilo)
             if l < 8:
                 x = softplus100(x)
         return x[..., :1], x[..., 1:]
@@ -347,17 +384,17 @@ class OracleNet:
         """RenderNetwork.forward base_network.py:152-171."""
         net = torch.cat([positional_encoding(view, self.cfg.view_res), grad, feat], dim=-1)
         for i in range(3):
-            net = F.relu(F.linear(net, *self.color[i]))
+            net = F.relu(self.lin(net, *self.color[i]))
         net = torch.cat([net, cond.expand(net.shape[0], -1)], dim=-1)
-        net = F.relu(F.linear(net, *self.color[3]))
-        return torch.sigmoid(F.linear(net, *self.color[4]))
+        net = F.relu(self.lin(net, *self.color[3], exact_cols=slice(256, 256 + cond.shape[-1])))
+        return torch.sigmoid(self.lin(net, *self.color[4]))
 
     def material(self, feat):
         """relight_network.py:45-47,97-98: 256->128->128->{3,1}, Softplus(100), slope*sigmoid+bias."""
         def run(layers, slope, bias):
             x = feat
             for i, (w, b) in enumerate(layers):
-                x = F.linear(x, w, b)
+                x = self.lin(x, w, b)
                 if i < len(layers) - 1:
                     x = softplus100(x)
             return slope * torch.sigmoid(x) + bias
@@ -422,6 +459,51 @@ def hdq_sdf(net: OracleNet, x, fr, dist_th=None, smooth_transition=True, return_
         ret.smpl_sdf = smpl_sdf
         return ret
     return sdf
+
+
+def observed_sdf(net: OracleNet, x, fr, smooth_transition=False, filtering=False, dist_th=None):
+    """Network.inference_observed_distance_field base_network.py:389-449 (cfg.smpl_distance False): x are big-pose points;
+    sdf = SDF(x + resd(x)); with filtering the hierarchical blend against the TEMPLATE body (geodesic_knn on tverts / tnorm)."""
+    dist_th = net.cfg.dist_th if dist_th is None else dist_th
+    sdf = net.sdf_feat(x + net.residuals(x, fr.cond))[0]
+    if not filtering:
+        return sdf
+    sdf_batch, _, mask, _, _ = geodesic_knn(x, fr.tverts, fr.tnorm, fr.tverts, net.cfg.sample_vert_cnt, dist_th)
+    smpl_sdf = sdf_batch.mean(dim=-1, keepdim=True)
+    smpl_sdf = torch.where(smpl_sdf < -dist_th, smpl_sdf, smpl_sdf.abs())
+    net_sdf = sdf[mask]
+    if smooth_transition:
+        r = (net_sdf.abs() / dist_th).clip(0, 1)
+        net_sdf = smpl_sdf[mask] * r + net_sdf * (1 - r)
+    out = smpl_sdf.clone()
+    out[mask] = net_sdf
+    return out
+
+
+def affine_inverse(A):
+    """blend_utils.py:11-15: transposes the 3x3 block (exact only for rigid transforms) and keeps the last row."""
+    R, T, P = A[..., :3, :3], A[..., :3, 3:], A[..., 3:, :]
+    return torch.cat([torch.cat([R.mT, -R.mT @ T], dim=-1), P], dim=-2)
+
+
+def bigpose_transform(net: OracleNet, x, fr, backward=False, invert=False):
+    """Network.world_to_bigpose_transform / bigpose_to_world_transform base_network.py:338-363: blended bone transforms of
+    every point's 3 nearest vertices (transform=False -> no distance filtering, dist = 1e9), composed with the frame's R, Th."""
+    c = net.cfg
+    if backward:
+        ppts, verts, norm = x, fr.tverts, fr.tnorm
+    else:
+        ppts, verts, norm = (x - fr.Th) @ fr.R, fr.pverts, fr.pnorm
+    _, _, _, d2, nn = geodesic_knn(ppts, verts, norm, fr.tverts, c.sample_vert_cnt, 1e9)
+    w = (-d2 / (2 * c.blend_radius ** 2)).exp()
+    w = w / (w.sum(dim=-1, keepdim=True) + torch.finfo(w.dtype).eps)
+    bw = (w[..., None] * fr.weights[nn]).sum(dim=-2)
+    A_bw = (bw[:, :, None, None] * fr.A[None]).sum(dim=1)
+    big_A_bw = (bw[:, :, None, None] * fr.big_A[None]).sum(dim=1)
+    p2w = torch.eye(4)
+    p2w[:3, :3], p2w[:3, 3] = fr.R, fr.Th.reshape(3)
+    w2b = big_A_bw @ affine_inverse(A_bw) @ affine_inverse(p2w)[None]
+    return affine_inverse(w2b) if invert else w2b
 
 
 def forward_geometry(net: OracleNet, x, v, fr, dist_th=None):
@@ -755,9 +837,29 @@ def render_ground(net: OracleNet, ray_o, ray_d, acc, probe, fr, bbox):
     if c.tonemapping_rendering:
         rgb = linear2srgb(rgb)
     shade = shade.sum(0) * c.shading_albedo / math.pi
-    return odict(rgb_map=rgb, surf_map=surf, albedo_map=albedo, roughness_map=torch.ones_like(t), spec_map=shade / 20,
-                 norm_map=norm, shade_map=shade * c.ground_shading_multiplier, cpts_map=torch.zeros_like(surf),
-                 bpts_map=torch.zeros_like(surf), depth_map=t.clip(-c.env_r, c.env_r))
+    ret = odict(rgb_map=rgb, surf_map=surf, albedo_map=albedo, roughness_map=torch.ones_like(t), spec_map=shade / 20,
+                norm_map=norm, shade_map=shade * c.ground_shading_multiplier, cpts_map=torch.zeros_like(surf),
+                bpts_map=torch.zeros_like(surf), depth_map=t.clip(-c.env_r, c.env_r))
+    if c.vis_novel_light:                                                  # :541-543, (P,L) like the human layer's
+        ret.lvis_map, ret.ldot_map = lvis.T.contiguous(), ldot.T.contiguous()
+    return ret
+
+
+def blend_output_(acc_g, inds, grd, ret):
+    """blend_output_ + alpha_blend / alpha_times (sphere_tracing_renderer.py:396-451), un-batched maps: the human layer
+    (P rows) is scattered to the F frame pixels through inds and mixed with the ground layer by acc_g = 1 - human acc."""
+    for k in BLEND_KEYS:
+        if k in ret and k in grd:
+            sc = torch.zeros(grd[k].shape[0], *ret[k].shape[1:])
+            sc[inds] = ret[k]
+            ag = acc_g if grd[k].ndim == 1 else acc_g[:, None]
+            ret[k] = grd[k] * ag + sc * (1 - ag)
+        elif k in grd:
+            ret[k] = grd[k] * (acc_g if grd[k].ndim == 1 else acc_g[:, None])
+    sc = torch.zeros_like(acc_g)
+    sc[inds] = ret.acc_map
+    ret.acc_map = sc * (1 - acc_g)                                       # alpha_blend(acc, inds, zeros, acc_map) (:449)
+    return ret
 
 
 def render_sphere_tracing(net: OracleNet, batch, probe=None, mutate_bounds=True, ground_inds=None):
@@ -794,17 +896,11 @@ def render_sphere_tracing(net: OracleNet, batch, probe=None, mutate_bounds=True,
             wb[:, 1] += c.env_lvis.bbox_margin
             gouts.append(render_ground(net, g_o[a:b].float(), g_d[a:b].float(), acc_g[a:b], probe, fr, wb[0].float()))
         grd = odict({k: torch.cat([o[k] for o in gouts], dim=0) for k in gouts[0]})
-        for k in BLEND_KEYS:
-            if k in ret and k in grd:
-                sc = torch.zeros_like(grd[k])
-                sc[inds] = ret[k]
-                ag = acc_g if grd[k].ndim == 1 else acc_g[:, None]
-                ret[k] = grd[k] * ag + sc * (1 - ag)
-            elif k in grd:
-                ret[k] = grd[k] * (acc_g if grd[k].ndim == 1 else acc_g[:, None])
-        sc = torch.zeros(H * W)
-        sc[inds] = ret.acc_map
-        ret.acc_map = sc * (1 - acc_g)                                   # alpha_blend(acc, inds, zeros, acc_map) (:449)
+        grd.ray_o, grd.ray_d, grd.acc_map, grd.inds = g_o.float(), g_d.float(), acc_g, inds
+        if c.vis_novel_light:                                             # :1106-1107: kept apart for the per-probe re-shade
+            ret.ground = grd
+            return odict({k: (v if k == 'ground' else v[None]) for k, v in ret.items()})
+        ret = blend_output_(acc_g, inds, grd, ret)
         return odict({k: v[None] for k, v in ret.items()})
     acc = ret.acc_map
     for k in BLEND_KEYS:
@@ -838,16 +934,34 @@ def render_volume(net: OracleNet, batch):
     return odict({k: torch.cat([o[k] for o in outs])[None] for k in outs[0]})
 
 
-def render_novel_light(net: OracleNet, batch):
-    """novel_light_sphere_tracing.Renderer.render :103-221 with vis_ground_shading False (quirk 9:
-    re-shading consumes maps already premultiplied by acc)."""
+def reshade_ground(net: OracleNet, probe, ray_d, albedo_map, lvis, ldot, image=None):
+    """novel_light_sphere_tracing.render_ground :70-99 for one probe: Lambert ground from the cached (L,P) visibility / cosine."""
     c = net.cfg
-    main = render_sphere_tracing(net, batch)
+    xyz = net.light_xyz.reshape(-1, 3)
+    area = net.light_area.reshape(-1)
+    light = sample_envmap_image(probe, normalize(xyz))                     # (L,3): surf2light = normalize(xyz - 0)
+    albedo = sample_envmap_image(probe if image is None else image, ray_d) if c.ground_attach_envmap else albedo_map
+    shade = lvis[..., None] * ldot[..., None] * area[:, None, None] * light[:, None, :]
+    rgb = linear2srgb(((albedo / math.pi)[None] * shade).sum(0))
+    shade = shade.sum(0) / math.pi
+    return rgb, albedo, shade, shade / 20
+
+
+def render_novel_light(net: OracleNet, batch, ground_inds=None):
+    """novel_light_sphere_tracing.Renderer.render :103-221.  Without cfg.vis_ground_shading the re-shading consumes maps
+    already premultiplied by acc (quirk 9); with it (the README command) both layers stay un-premultiplied, each is re-shaded
+    per probe and blend_output_ merges them per light (:191-213) and for 'main' (:160-161)."""
+    c = net.cfg
+    main = render_sphere_tracing(net, batch, ground_inds=ground_inds)
+    grd = main.get('ground', None)
     relight = odict()
     visual = ['rgb_map', 'acc_map', 'norm_map', 'surf_map', 'bpts_map', 'cpts_map', 'spec_map', 'shade_map',
               'depth_map', 'albedo_map', 'roughness_map']
     if 'main' in c.test_light:
         relight.main = odict({k: main[k] for k in visual if k in main})
+        if grd is not None:
+            m = blend_output_(grd.acc_map, grd.inds, grd, odict({k: v[0] for k, v in relight.main.items()}))
+            relight.main = odict({k: v[None] for k, v in m.items()})
     for name, env in batch['novel_lights'].items():
         probe = env['probe'][0].float()
         rgbs, shades, specs = [], [], []
@@ -857,7 +971,16 @@ def render_novel_light(net: OracleNet, batch):
                                             main.albedo_map[0, a:b], main.roughness_map[0, a:b, None],
                                             main.lvis_map[0, a:b].T, main.ldot_map[0, a:b].T, want_spec=True)
             rgbs.append(rgb), shades.append(shade), specs.append(spec)
-        relight[name] = odict(rgb_map=torch.cat(rgbs)[None], shade_map=torch.cat(shades)[None], spec_map=torch.cat(specs)[None])
+        human = odict(rgb_map=torch.cat(rgbs), shade_map=torch.cat(shades), spec_map=torch.cat(specs))
+        if grd is not None:
+            image = env['image'][0].float() if 'image' in env else None
+            g_rgb, g_alb, g_shade, g_spec = reshade_ground(net, probe, grd.ray_d, grd.albedo_map, grd.lvis_map.T, grd.ldot_map.T, image)
+            ground = odict({k: grd[k] for k in visual if k in grd})
+            ground.update(rgb_map=g_rgb, albedo_map=g_alb, shade_map=g_shade, spec_map=g_spec)
+            full = odict({k: main[k][0] for k in visual if k in main})
+            full.update(human)
+            human = blend_output_(grd.acc_map, grd.inds, ground, full)
+        relight[name] = odict({k: v[None] for k, v in human.items()})
     relight._main_full = main
     return relight
 

@@ -10,6 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RA_LIB_PATH') or os.path.join(_HERE, 'librelightableavatar_hip.so')    # override: kernel experiments (tools/)
 _lib = None
+ABI_VERSION = 2          # RA_ABI_VERSION of include/relightableavatar.h
 
 
 class RaError(RuntimeError):
@@ -55,7 +56,7 @@ class ra_ground_params(C.Structure):
                 ('no_visibility', C.c_int), ('local_visibility', C.c_int)]
 
 
-GROUND_OUT_KEYS = ('rgb', 'surf', 'albedo', 'shade', 'spec', 'depth')
+GROUND_OUT_KEYS = ('rgb', 'surf', 'albedo', 'shade', 'spec', 'depth', 'lvis', 'ldot')
 
 
 class ra_ground_out(C.Structure):
@@ -90,6 +91,8 @@ SYMBOLS = {
     'ra_finalize_weights': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ra_set_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_frame), C.c_void_p]),
     'ra_hdq_sdf': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    'ra_observed_sdf': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'ra_bigpose_transform': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'ra_raw_channels': (C.c_int, [C.c_void_p]),
     'ra_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'ra_sphere_trace': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(ra_trace_params)] + [C.c_void_p] * 5),
@@ -100,6 +103,8 @@ SYMBOLS = {
                                          C.POINTER(ra_ground_params), C.POINTER(ra_ground_out), C.c_void_p]),
     'ra_blend_ground': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'ra_reshade': (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    'ra_reshade_ground': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] +
+                          [C.c_void_p] * 5),
     'ra_get_counters': (C.c_int, [C.c_void_p, C.POINTER(ra_counters), C.c_void_p]),
     'ra_reset_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ra_get_mlp_time': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
@@ -112,6 +117,10 @@ SYMBOLS = {
     'ra_gen_rays': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.c_void_p]),
     'ra_debug_mlp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_full': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ra_debug_aabb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ra_debug_lvis': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(ra_trace_params), C.c_float,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ra_debug_brdf': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'ra_debug_hdq': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 7 + [C.POINTER(C.c_int), C.c_void_p]),
 }
 
@@ -139,7 +148,7 @@ def lib():
         fn = getattr(L, name)      # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if L.ra_abi_version() != 1:
+    if L.ra_abi_version() != ABI_VERSION:
         raise RaError('ABI version mismatch')
     _lib = L
     return L

@@ -285,6 +285,54 @@ int ra_hdq_sdf(ra_ctx* c, const float* x, int n, float dist_th, int smooth, floa
     return 0;
 }
 
+int ra_observed_sdf(ra_ctx* c, const float* bpts, int n, float* sdf, void* stream) {
+    if (check_ready(c, "ra_observed_sdf")) return 1;
+    RA_CHECK(n >= 0 && (n == 0 || (bpts && sdf)), "ra_observed_sdf: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    int* idx = c->buf<int>("fine_idx", n, &err);
+    if (err) return 1;
+    launch_iota(idx, n, icnt(c, CNT_FINE), s);
+    MlpIO io{};
+    io.bpts = bpts; io.idx = idx; io.count = icnt(c, CNT_FINE); io.sdf = sdf; io.dist_th = 1.f; io.smooth = 0;
+    io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
+    {
+        Timer t(c, s, 0);
+        launch_mlp_sdf_stream(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+    }
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_bigpose_transform(ra_ctx* c, const float* x, int n, const float* R, const float* Th, int invert, float* out, void* stream) {
+    if (check_ready(c, "ra_bigpose_transform")) return 1;
+    RA_CHECK(n >= 0 && (n == 0 || (x && out && R && Th)), "ra_bigpose_transform: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    int* fine_idx = c->buf<int>("fine_idx", n, &err);
+    float* fb = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
+    float* sdfc = c->buf<float>("bt_sdf", n, &err);
+    float* sb = c->buf<float>("bt_sdf_batch", (size_t)n * 3, &err);
+    int* nb = c->buf<int>("bt_nn", (size_t)n * 3, &err);
+    float* d2 = c->buf<float>("bt_d2", (size_t)n * 3, &err);
+    float* bp = c->buf<float>("bt_bpts", (size_t)n * 3, &err);
+    float* tp = c->buf<float>("bt_tpts", (size_t)n * 3, &err);
+    float* mats = c->buf<float>("bt_mats", (size_t)n * 24, &err);
+    if (err) return 1;
+    RaySet rs{};
+    rs.mode = 0; rs.x = x;
+    HdqOut o{};
+    o.sdf = sdfc; o.fine_count = icnt(c, CNT_FINE); o.fine_idx = fine_idx; o.bpts = fb;
+    o.dbg_sdf_batch = sb; o.dbg_nn_batch = nb; o.dbg_d2 = d2; o.dbg_bpts = bp; o.dbg_tpts = tp; o.dbg_mats = mats;
+    o.counters = dcnt(c);
+    launch_hdq_coarse(c->fr, rs, n, 1e9f, c->cfg.blend_radius, o, s);      // transform=False -> filtering off: dist = 1e9 (:253-259)
+    launch_bigpose_compose(mats, d2, n, c->cfg.blend_radius, R, Th, invert, out, s);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
 int ra_forward(ra_ctx* c, const float* x, const float* v, int n, float dist_th, float* raw, void* stream) {
     if (check_ready(c, "ra_forward")) return 1;
     RA_CHECK(n >= 0 && (n == 0 || (x && raw)), "ra_forward: bad arguments");
@@ -546,11 +594,13 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
                                p->local_visibility, &lvis, &ldot, s)) return 1;
     auto zero = [&](void* dst, int C) { if (dst) hipMemsetAsync(dst, 0, (size_t)P * C * sizeof(float), s); };
     zero(out->rgb, 3); zero(out->albedo, 3); zero(out->shade, 3); zero(out->spec, 3);
+    zero(out->lvis, c->n_lights); zero(out->ldot, c->n_lights);
     GroundShade in{};
     in.g = g; in.t = t; in.surf = surf; in.hit_idx = hit_idx; in.hit_count = hit_count; in.lvis = lvis;
     in.ldir = c->light_dir.as<float>(); in.light_area = c->light_area.as<float>(); in.L = c->n_lights;
     in.probe = probe; in.ph = ph; in.pw = pw;
     in.rgb = (float*)out->rgb; in.albedo = (float*)out->albedo; in.shade = (float*)out->shade; in.spec = (float*)out->spec;
+    in.lvis_out = (float*)out->lvis; in.ldot_out = (float*)out->ldot;
     launch_ground_shade(in, c->cfg, s);
     if (out->surf) RA_HIP(hipMemcpyAsync(out->surf, surf, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->depth) RA_HIP(hipMemcpyAsync(out->depth, depth, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -626,6 +676,28 @@ int ra_reshade(ra_ctx* c, const float* ray_o, const float* surf, const float* no
         cfg.tonemapping = 1;      // novel_light_sphere_tracing.py:47 applies linear2srgb unconditionally
         launch_shade(in, cfg, s);
     }
+    c->n_shaded += (uint64_t)P * n_probes;
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_reshade_ground(ra_ctx* c, const float* ray_d, const float* albedo_map, const float* lvis, const float* ldot, int P,
+                      const float* probes, int n_probes, int ph, int pw, const float* images, int ih, int iw, int attach_envmap,
+                      float* rgb, float* albedo, float* shade, float* spec, void* stream) {
+    RA_CHECK(c && c->have_weights && c->cfg.relight, "ra_reshade_ground: needs a relight ctx with weights");
+    RA_CHECK(P >= 0 && n_probes >= 0, "ra_reshade_ground: bad sizes");
+    if (P == 0 || n_probes == 0) return 0;
+    RA_CHECK(ray_d && lvis && ldot && probes && ph > 0 && pw > 0, "ra_reshade_ground: null input");
+    RA_CHECK(attach_envmap || albedo_map, "ra_reshade_ground: albedo_map is needed when the probe is not attached to the ground");
+    RA_CHECK(!images || (ih > 0 && iw > 0), "ra_reshade_ground: bad image size");
+    RA_HIP(hipSetDevice(c->device));
+    GroundReshade in{};
+    in.ray_d = ray_d; in.albedo_map = albedo_map; in.lvis = lvis; in.ldot = ldot;
+    in.ldir = c->light_dir.as<float>(); in.light_area = c->light_area.as<float>(); in.L = c->n_lights;
+    in.probes = probes; in.n_probes = n_probes; in.ph = ph; in.pw = pw; in.images = images; in.ih = ih; in.iw = iw;
+    in.attach_envmap = attach_envmap; in.P = P;
+    in.rgb = rgb; in.albedo = albedo; in.shade = shade; in.spec = spec;
+    launch_ground_reshade(in, (hipStream_t)stream);
     c->n_shaded += (uint64_t)P * n_probes;
     RA_HIP(hipGetLastError());
     return 0;
@@ -929,6 +1001,43 @@ int ra_debug_full(ra_ctx* c, const float* bpts, int n, float* grad, float* sdf, 
     io.relight = c->cfg.relight;
     io.dbg_grad = grad; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
     launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_debug_aabb(ra_ctx* c, const float* o, const float* d, int n, const float* bbox, float* nr, float* fr, void* stream) {
+    RA_CHECK(c && n >= 0 && (n == 0 || (o && d && bbox && nr && fr)), "ra_debug_aabb: bad arguments");
+    RA_HIP(hipSetDevice(c->device));
+    launch_debug_aabb(o, d, n, bbox, nr, fr, (hipStream_t)stream);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_debug_lvis(ra_ctx* c, const float* surf, const float* norm, const float* acc, int n, const float* bbox, const ra_trace_params* shadow,
+                  float near_offset, float* lvis_out, float* ldot_out, void* stream) {
+    if (check_ready(c, "ra_debug_lvis")) return 1;
+    RA_CHECK(c->cfg.relight && c->n_lights > 0, "ra_debug_lvis: needs the relight network's light set");
+    RA_CHECK(n >= 0 && shadow && (n == 0 || (surf && norm && acc && bbox && lvis_out && ldot_out)), "ra_debug_lvis: bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int err = 0;
+    int* hit_idx = c->buf<int>("dl_hit", n, &err);
+    if (err) return 1;
+    launch_iota(hit_idx, n, icnt(c, CNT_HIT), s);          // every point is its own hit slot
+    float *lvis = nullptr, *ldot = nullptr;
+    if (light_visibility_stage(c, surf, norm, acc, hit_idx, icnt(c, CNT_HIT), n, bbox, near_offset, *shadow, 0, 0, &lvis, &ldot, s)) return 1;
+    RA_HIP(hipMemcpyAsync(lvis_out, lvis, (size_t)n * c->n_lights * 4, hipMemcpyDeviceToDevice, s));
+    RA_HIP(hipMemcpyAsync(ldot_out, ldot, (size_t)n * c->n_lights * 4, hipMemcpyDeviceToDevice, s));
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_debug_brdf(ra_ctx* c, const float* p2l, const float* p2c, const float* normal, const float* albedo, const float* rough, int L, int N,
+                  float* brdf, void* stream) {
+    RA_CHECK(c && c->have_cfg, "ra_debug_brdf: call ra_set_config first");
+    RA_CHECK(L >= 0 && N >= 0 && (L * N == 0 || (p2l && p2c && normal && albedo && rough && brdf)), "ra_debug_brdf: bad arguments");
+    RA_HIP(hipSetDevice(c->device));
+    launch_debug_brdf(p2l, p2c, normal, albedo, rough, L, N, c->cfg, brdf, (hipStream_t)stream);
     RA_HIP(hipGetLastError());
     return 0;
 }

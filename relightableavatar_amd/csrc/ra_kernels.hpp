@@ -91,6 +91,9 @@ struct ShadowGen {
     int* ray_count;
 };
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s);
+void launch_debug_aabb(const float* o, const float* d, int n, const float* bbox6, float* nr, float* fr, hipStream_t s);
+void launch_debug_brdf(const float* p2l, const float* p2c, const float* nrm, const float* alb, const float* rough, int L, int N, const ra_config& cfg,
+                       float* out, hipStream_t s);
 // reorder the hit list so that 64 consecutive hit pixels have neighbouring surface points (radix sort by Morton key)
 size_t sort_hits_temp_bytes(int P);
 int launch_sort_hits(const float* surf, const float* acc, int P, const float* bbox_min, unsigned* keys_in, unsigned* keys_out,
@@ -130,6 +133,10 @@ void launch_volume_samples(const float* ray_o, const float* ray_d, const float* 
 void launch_volume_composite(const float* raw, int C, const float* near_, const float* far_, int P, int S, float bg,
                              const ra_render_out& out, const int* perm, hipStream_t s);
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
+void launch_iota(int* idx, int n, int* count, hipStream_t s);      // idx[i] = i, *count = n
+// per point: w2b = big_A_bw @ affine_inverse(A_bw) @ affine_inverse([R|Th]) (or its affine_inverse) from the blended rows of the coarse level
+void launch_bigpose_compose(const float* mats, const float* d2, int n, float blend_radius, const float* R, const float* Th, int invert, float* out,
+                            hipStream_t s);
 void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s);
 
 // N2: ray generation + AABB culling (ra_trace.hip)
@@ -156,8 +163,19 @@ struct GroundShade {
     const float *ldir, *light_area; int L;
     const float* probe; int ph, pw;
     float *rgb, *albedo, *shade, *spec;   // P x 3 (full indexing), nullable
+    float *lvis_out, *ldot_out;           // P x L (full indexing, pre-zeroed), nullable: what the novel-light re-shade consumes
 };
 void launch_ground_shade(const GroundShade& in, const ra_config& cfg, hipStream_t s);
+struct GroundReshade {                    // novel_light_sphere_tracing.render_ground (:70-99)
+    const float *ray_d, *albedo_map;      // P x 3
+    const float *lvis, *ldot;             // P x L
+    const float *ldir, *light_area; int L;
+    const float* probes; int n_probes, ph, pw;
+    const float* images; int ih, iw;      // nullable
+    int attach_envmap, P;
+    float *rgb, *albedo, *shade, *spec;   // n_probes x P x 3, nullable
+};
+void launch_ground_reshade(const GroundReshade& in, hipStream_t s);
 
 // N4: envmap rotation + light-probe inset (ra_trace.hip)
 void launch_shift_envmap(const float* img, int H, int W, int C, float shift, float* out, hipStream_t s);

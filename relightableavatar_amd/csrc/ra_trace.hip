@@ -286,6 +286,29 @@ __global__ void light_dirs_kernel(const float* __restrict__ xyz, int L, float* _
 // workgroup = 64 neighbouring hit slots x 32 lights; a wave handles ONE light for the 64 slots at a time (so that the
 // traced rays it emits stay neighbours in the coarse level), 8 rounds cover the 32 lights.  lvis / ldot are [slot][light]:
 // they are staged in LDS and written as whole 128-byte rows (a direct store would touch 64 cache lines per instruction).
+// get_near_far_aabb (net_utils.py:1683-1712, return_raw path): direction components in (-1e-16, 1e-8) become +1e-8 in place
+// (:1698; the mirrored line :1699 then matches nothing, so tiny negatives stay), slab test
+__device__ __forceinline__ void aabb_near_far(const float* bbox, const float o[3], const float dir[3], float& nr, float& fr) {
+    float d[3] = {dir[0], dir[1], dir[2]};
+    nr = -3.0e38f; fr = 3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (d[c] < 1e-8f && d[c] > -1e-16f) d[c] = 1e-8f;
+        const float t0 = (bbox[c] - o[c]) / d[c], t1 = (bbox[3 + c] - o[c]) / d[c];
+        nr = fmaxf(nr, fminf(t0, t1));
+        fr = fminf(fr, fmaxf(t0, t1));
+    }
+}
+struct Box6 { float v[6]; };
+__global__ void debug_aabb_kernel(const float* __restrict__ o, const float* __restrict__ d, int n, Box6 b, float* __restrict__ nr, float* __restrict__ fr) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const float oo[3] = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    float a, f;
+    aabb_near_far(b.v, oo, dd, a, f);
+    nr[i] = a; fr[i] = f;
+}
+
 constexpr int SG_LIGHTS = 32;
 __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
     __shared__ float t_ldot[64][SG_LIGHTS + 1], t_lvis[64][SG_LIGHTS + 1];
@@ -324,16 +347,8 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
                 const bool front = (ldot > 0.f) && (acc > 0.f);                                           // :303
                 lv = 0.f;
                 if (front) {
-                    // get_near_far_aabb (net_utils.py:1683-1712), tiny components -> +1e-8
-                    float d[3] = {dx, dy, dz};
-                    nr = -3.0e38f; fr = 3.0e38f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (d[c] < 1e-8f && d[c] > -1e-16f) d[c] = 1e-8f;
-                        const float t0 = (g.bbox[c] - o[c]) / d[c], t1 = (g.bbox[3 + c] - o[c]) / d[c];
-                        nr = fmaxf(nr, fminf(t0, t1));
-                        fr = fminf(fr, fmaxf(t0, t1));
-                    }
+                    const float d[3] = {dx, dy, dz};
+                    aabb_near_far(g.bbox, o, d, nr, fr);
                     nr = fmaxf(nr, g.near_offset);                                                        // :311
                     fr = fmaxf(fr, g.near_offset);
                     trace = nr < fr;
@@ -442,6 +457,82 @@ __device__ __forceinline__ float srgb(float x) {                // relight_utils
     return (x <= 0.0031308f) ? x * 12.92f : 1.055f * powf(x + 1e-7f, 1.f / 2.4f) - (1.055f - 1.f);
 }
 
+// Microfacet.__call__ (relight_utils.py:484-577, cancel_cosine = True) split into its per-pixel and per-light parts;
+// safe_divide's in-place clamps of its arguments (the aliasing of cos^2 in _get_d / _get_g) are reproduced.
+struct MfView { float v[3], n[3], a2, v_dot_n, cos_v, g_den0; };
+__device__ __forceinline__ MfView mf_view(const float p2c[3], const float normal[3], float rough) {
+    MfView m;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { m.v[c] = p2c[c]; m.n[c] = normal[c]; }
+    fnormalize(m.v);
+    fnormalize(m.n);
+    const float alpha = rough * rough;
+    m.a2 = alpha * alpha;
+    m.v_dot_n = fminf(fmaxf(m.v[0] * m.n[0] + m.v[1] * m.n[1] + m.v[2] * m.n[2], 1e-4f), 1.f);
+    // view-only part of G (_get_g :580-595); cos_theta_v is clamped in place by the first safe_divide
+    float cos_v = m.n[0] * m.v[0] + m.n[1] * m.v[1] + m.n[2] * m.v[2];
+    {
+        const float eps = 1e-8f;
+        if (cos_v < eps && cos_v >= 0.f) cos_v = eps;
+        if (cos_v > -eps && cos_v <= 0.f) cos_v = -eps;
+    }
+    m.cos_v = cos_v;
+    float cvs = fminf(fmaxf(cos_v * cos_v, 0.f), 1.f);
+    float one_m = 1.f - cvs;
+    float tan_v_sq = safe_div(one_m, cvs);
+    tan_v_sq = fminf(fmaxf(tan_v_sq, 0.f), 1e10f);
+    m.g_den0 = 1.f + sqrtf(1.f + m.a2 * tan_v_sq);
+    return m;
+}
+// brdf[c] = glossy + albedo/pi * clip(l.n) (or the ablation variants); sbrdf = the albedo-0 value (:740)
+__device__ __forceinline__ void mf_light(const MfView& m, const float p2l[3], const float alb[3], const ra_config& cfg, float brdf[3], float& sbrdf) {
+    float pl[3] = {p2l[0], p2l[1], p2l[2]};
+    fnormalize(pl);
+    const float l_dot_n = fminf(fmaxf(pl[0] * m.n[0] + pl[1] * m.n[1] + pl[2] * m.n[2], 1e-4f), 1.f);
+    float hv[3] = {pl[0] + m.v[0], pl[1] + m.v[1], pl[2] + m.v[2]};
+    fnormalize(hv);
+    const float omc5 = 1.f - (pl[0] * hv[0] + pl[1] * hv[1] + pl[2] * hv[2]);
+    const float f = cfg.fresnel_f0 + (1.f - cfg.fresnel_f0) * (omc5 * omc5 * omc5 * omc5 * omc5);
+    // D (_get_d :598-608)
+    const float cos_m = hv[0] * m.n[0] + hv[1] * m.n[1] + hv[2] * m.n[2];
+    const float chi_d = cos_m > 0.f ? 1.f : 0.f;
+    float cms = cos_m * cos_m;
+    float omc = 1.f - cms;
+    const float tan_m_sq = safe_div(omc, cms);          // clamps cms in place
+    float dden = PI_F * (cms * cms) * ((m.a2 + tan_m_sq) * (m.a2 + tan_m_sq));
+    float dnum = m.a2 * chi_d;
+    const float dd = safe_div(dnum, dden);
+    // G
+    float cos_t = hv[0] * m.v[0] + hv[1] * m.v[1] + hv[2] * m.v[2];
+    float cvc = m.cos_v;
+    const float dv = safe_div(cos_t, cvc);
+    float gnum = (dv > 0.f ? 1.f : 0.f) * 2.f;
+    float gden = m.g_den0;
+    const float gg = safe_div(gnum, gden);
+    float mnum = f * gg * dd;
+    float mden = 4.f * 1.f * fabsf(m.v_dot_n);
+    const float glossy = safe_div(mnum, mden);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lam = alb[c] / PI_F * l_dot_n;
+        brdf[c] = cfg.lambert_only ? lam : (cfg.glossy_only ? glossy : glossy + lam);
+    }
+    sbrdf = cfg.lambert_only ? 0.f : glossy;
+}
+// test hook: the BRDF on arbitrary (light, point) direction pairs, p2l (L,N,3) like the reference's surf2light
+__global__ void debug_brdf_kernel(const float* __restrict__ p2l, const float* __restrict__ p2c, const float* __restrict__ nrm, const float* __restrict__ alb,
+                                  const float* __restrict__ rough, int L, int N, ra_config cfg, float* __restrict__ out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= L * N) return;
+    const int p = i % N;
+    const float v[3] = {p2c[3 * p], p2c[3 * p + 1], p2c[3 * p + 2]}, n[3] = {nrm[3 * p], nrm[3 * p + 1], nrm[3 * p + 2]};
+    const float a[3] = {alb[3 * p], alb[3 * p + 1], alb[3 * p + 2]}, l[3] = {p2l[3 * i], p2l[3 * i + 1], p2l[3 * i + 2]};
+    const MfView mv = mf_view(v, n, rough[p]);
+    float brdf[3], sb;
+    mf_light(mv, l, a, cfg, brdf, sb);
+    out[3 * i] = brdf[0]; out[3 * i + 1] = brdf[1]; out[3 * i + 2] = brdf[2];
+}
+
 // one wave per (pixel slot); lanes stride over the L lights; probes looped inside so the BRDF,
 // visibility and area weights are computed once per light for all probes.
 constexpr int MAXP = 8;
@@ -459,25 +550,9 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
         v[0] /= nn; v[1] /= nn; v[2] /= nn;
         fnormalize(v);
     }
-    float nrm[3] = {in.norm[3 * h], in.norm[3 * h + 1], in.norm[3 * h + 2]};
-    fnormalize(nrm);
+    const float nraw[3] = {in.norm[3 * h], in.norm[3 * h + 1], in.norm[3 * h + 2]};
     const float alb[3] = {in.albedo[3 * h], in.albedo[3 * h + 1], in.albedo[3 * h + 2]};
-    const float rough = in.rough[h];
-    const float alpha = rough * rough;
-    const float a2 = alpha * alpha;
-    const float v_dot_n = fminf(fmaxf(v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2], 1e-4f), 1.f);
-    // view-only part of G (_get_g :580-595); cos_theta_v is clamped in place by the first safe_divide
-    float cos_v = nrm[0] * v[0] + nrm[1] * v[1] + nrm[2] * v[2];
-    {
-        const float eps = 1e-8f;
-        if (cos_v < eps && cos_v >= 0.f) cos_v = eps;
-        if (cos_v > -eps && cos_v <= 0.f) cos_v = -eps;
-    }
-    float cvs = fminf(fmaxf(cos_v * cos_v, 0.f), 1.f);
-    float one_m = 1.f - cvs;
-    float tan_v_sq = safe_div(one_m, cvs);
-    tan_v_sq = fminf(fmaxf(tan_v_sq, 0.f), 1e10f);
-    const float g_den0 = 1.f + sqrtf(1.f + a2 * tan_v_sq);
+    const MfView mv = mf_view(v, nraw, in.rough[h]);
 
     float rgb[MAXP][3], shd[MAXP][3], spc[MAXP][3];
 #pragma unroll
@@ -491,42 +566,11 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
             const float nn = sqrtf(s2l[0] * s2l[0] + s2l[1] * s2l[1] + s2l[2] * s2l[2]) + 1e-8f;      // :715
             s2l[0] /= nn; s2l[1] /= nn; s2l[2] /= nn;
         }
-        float pl[3] = {s2l[0], s2l[1], s2l[2]};
-        fnormalize(pl);
-        const float l_dot_n = fminf(fmaxf(pl[0] * nrm[0] + pl[1] * nrm[1] + pl[2] * nrm[2], 1e-4f), 1.f);
-        float hv[3] = {pl[0] + v[0], pl[1] + v[1], pl[2] + v[2]};
-        fnormalize(hv);
-        const float omc5 = 1.f - (pl[0] * hv[0] + pl[1] * hv[1] + pl[2] * hv[2]);
-        const float f = cfg.fresnel_f0 + (1.f - cfg.fresnel_f0) * (omc5 * omc5 * omc5 * omc5 * omc5);
-        // D (_get_d :598-608)
-        const float cos_m = hv[0] * nrm[0] + hv[1] * nrm[1] + hv[2] * nrm[2];
-        const float chi_d = cos_m > 0.f ? 1.f : 0.f;
-        float cms = cos_m * cos_m;
-        float omc = 1.f - cms;
-        const float tan_m_sq = safe_div(omc, cms);          // clamps cms in place
-        float dden = PI_F * (cms * cms) * ((a2 + tan_m_sq) * (a2 + tan_m_sq));
-        float dnum = a2 * chi_d;
-        const float dd = safe_div(dnum, dden);
-        // G
-        float cos_t = hv[0] * v[0] + hv[1] * v[1] + hv[2] * v[2];
-        float cvc = cos_v;
-        const float dv = safe_div(cos_t, cvc);
-        float gnum = (dv > 0.f ? 1.f : 0.f) * 2.f;
-        float gden = g_den0;
-        const float gg = safe_div(gnum, gden);
-        float mnum = f * gg * dd;
-        float mden = 4.f * 1.f * fabsf(v_dot_n);
-        const float glossy = safe_div(mnum, mden);
+        float brdf[3], sbrdf;
+        mf_light(mv, s2l, alb, cfg, brdf, sbrdf);
         const float area = in.light_area[l];
         const float lv = in.lvis[(size_t)h * in.L + l];
         const float ld = in.ldot[(size_t)h * in.L + l];
-        float brdf[3], sbrdf;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float lam = alb[c] / PI_F * l_dot_n;
-            brdf[c] = cfg.lambert_only ? lam : (cfg.glossy_only ? glossy : glossy + lam);
-        }
-        sbrdf = cfg.lambert_only ? 0.f : glossy;             // albedo = 0 variant (:740)
         const float spec_ld = 1.f / (fabsf(1.f) + 1e-8f);    // :743
         for (int q = 0; q < in.n_probes; ++q) {
             float Lr[3];
@@ -650,6 +694,18 @@ inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TPB - 1) / TPB))
 
 }  // namespace
 
+void launch_debug_aabb(const float* o, const float* d, int n, const float* bbox6, float* nr, float* fr, hipStream_t s) {
+    if (n <= 0) return;
+    Box6 b; for (int k = 0; k < 6; ++k) b.v[k] = bbox6[k];
+    hipLaunchKernelGGL(debug_aabb_kernel, grid_for(n), dim3(TPB), 0, s, o, d, n, b, nr, fr);
+}
+
+void launch_debug_brdf(const float* p2l, const float* p2c, const float* nrm, const float* alb, const float* rough, int L, int N, const ra_config& cfg,
+                       float* out, hipStream_t s) {
+    if (L * N <= 0) return;
+    hipLaunchKernelGGL(debug_brdf_kernel, grid_for((long long)L * N), dim3(TPB), 0, s, p2l, p2c, nrm, alb, rough, L, N, cfg, out);
+}
+
 void launch_trace_init(const TraceState& ts, int n, const int* n_dev, const ra_trace_params& p, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(trace_init_kernel, grid_for(n), dim3(TPB), 0, s, ts, n, n_dev, p.offset, p.relax);
@@ -747,6 +803,8 @@ __global__ __launch_bounds__(TPB) void ground_shade_kernel(GroundShade in, ra_co
         const float k = lv * ldot * in.light_area[l];
 #pragma unroll
         for (int c = 0; c < 3; ++c) sum[c] += k * Lr[c];
+        if (in.lvis_out) in.lvis_out[(size_t)r * in.L + l] = lv;
+        if (in.ldot_out) in.ldot_out[(size_t)r * in.L + l] = ldot;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -761,6 +819,58 @@ __global__ __launch_bounds__(TPB) void ground_shade_kernel(GroundShade in, ra_co
             if (in.shade) in.shade[3 * r + c] = sh * in.g.shading_multiplier;
             if (in.spec) in.spec[3 * r + c] = sh / 20.f;
         }
+    }
+}
+
+// novel-light re-shade of the ground layer (novel_light_sphere_tracing.py:70-99): one wave per frame pixel, lanes stride the
+// lights, up to MAXP probes per pass share the 4 KB of cached visibility / cosine a pixel reads
+__global__ __launch_bounds__(TPB) void ground_reshade_kernel(GroundReshade in, int q0, int nq) {
+    const int p = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (p >= in.P) return;
+    float sum[MAXP][3];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) sum[q][0] = sum[q][1] = sum[q][2] = 0.f;
+    for (int l = lane; l < in.L; l += 64) {
+        const float ld[3] = {in.ldir[3 * l], in.ldir[3 * l + 1], in.ldir[3 * l + 2]};     // normalize(xyz - 0) (:76)
+        const float k = in.lvis[(size_t)p * in.L + l] * in.ldot[(size_t)p * in.L + l] * in.light_area[l];
+        for (int q = 0; q < nq; ++q) {
+            float Lr[3];
+            sample_probe(in.probes + (size_t)(q0 + q) * in.ph * in.pw * 3, in.ph, in.pw, ld, Lr);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum[q][c] += k * Lr[c];
+        }
+    }
+    const float d[3] = {in.ray_d[3 * p], in.ray_d[3 * p + 1], in.ray_d[3 * p + 2]};
+    for (int q = 0; q < nq; ++q) {
+        float alb[3];
+        if (in.attach_envmap) {
+            if (in.images) sample_probe(in.images + (size_t)(q0 + q) * in.ih * in.iw * 3, in.ih, in.iw, d, alb);
+            else sample_probe(in.probes + (size_t)(q0 + q) * in.ph * in.pw * 3, in.ph, in.pw, d, alb);
+        } else {
+            alb[0] = in.albedo_map[3 * p]; alb[1] = in.albedo_map[3 * p + 1]; alb[2] = in.albedo_map[3 * p + 2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = sum[q][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) {
+                const size_t k = ((size_t)(q0 + q) * in.P + p) * 3 + c;
+                if (in.rgb) in.rgb[k] = srgb(alb[c] / PI_F * a);
+                if (in.albedo) in.albedo[k] = alb[c];
+                if (in.shade) in.shade[k] = a / PI_F;
+                if (in.spec) in.spec[k] = a / PI_F / 20.f;
+            }
+        }
+    }
+}
+
+void launch_ground_reshade(const GroundReshade& in, hipStream_t s) {
+    if (in.P <= 0) return;
+    for (int q0 = 0; q0 < in.n_probes; q0 += MAXP) {
+        const int nq = in.n_probes - q0 < MAXP ? in.n_probes - q0 : MAXP;
+        hipLaunchKernelGGL(ground_reshade_kernel, grid_for((long long)in.P * 64), dim3(TPB), 0, s, in, q0, nq);
     }
 }
 
@@ -1076,6 +1186,65 @@ void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s)
 void launch_gather_rows(const int* hit_idx, const int* hit_count, int P, const float* src, int C, float* dst, hipStream_t s) {
     if (P <= 0) return;
     hipLaunchKernelGGL(gather_rows_kernel, grid_for((long long)P * C), dim3(TPB), 0, s, hit_idx, hit_count, src, C, dst);
+}
+
+__global__ void iota_kernel(int* __restrict__ idx, int n, int* __restrict__ count) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i == 0 && count) *count = n;
+    if (i < n) idx[i] = i;
+}
+void launch_iota(int* idx, int n, int* count, hipStream_t s) {
+    hipLaunchKernelGGL(iota_kernel, grid_for(n > 0 ? n : 1), dim3(TPB), 0, s, idx, n, count);
+}
+
+// 4x4 helpers of world_to_bigpose_transform (base_network.py:338-359); affine_inverse = [[R^T, -R^T t], [last row kept]]
+__device__ __forceinline__ void affine_inverse4(const float* A, float* o) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[4 * r + c] = A[4 * c + r];
+        o[4 * r + 3] = -(A[r] * A[3] + A[4 + r] * A[7] + A[8 + r] * A[11]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[12 + c] = A[12 + c];
+}
+__device__ __forceinline__ void matmul4(const float* A, const float* B, float* o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[4 * r + c] = A[4 * r] * B[c] + A[4 * r + 1] * B[4 + c] + A[4 * r + 2] * B[8 + c] + A[4 * r + 3] * B[12 + c];
+}
+__global__ void bigpose_compose_kernel(const float* __restrict__ mats, const float* __restrict__ d2, int n, float inv2r2, const float* __restrict__ R,
+                                       const float* __restrict__ Th, int invert, float* __restrict__ out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    // bottom-right element of a blended 4x4: sum_k w_k / (sum_k w_k + eps)  (base_network.py:288-290; bone matrices end in 1)
+    float ws = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ws += expf(-d2[3 * i + k] * inv2r2);
+    const float sden = ws + 1.1920928955078125e-07f;
+    float sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sb += expf(-d2[3 * i + k] * inv2r2) / sden;
+    float A[16], B[16], P2W[16], t0[16], t1[16], t2[16];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { A[e] = mats[(size_t)i * 24 + e]; B[e] = mats[(size_t)i * 24 + 12 + e]; }
+    A[12] = A[13] = A[14] = 0.f; A[15] = sb;
+    B[12] = B[13] = B[14] = 0.f; B[15] = sb;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { P2W[4 * r] = R[3 * r]; P2W[4 * r + 1] = R[3 * r + 1]; P2W[4 * r + 2] = R[3 * r + 2]; P2W[4 * r + 3] = Th[r]; }
+    P2W[12] = P2W[13] = P2W[14] = 0.f; P2W[15] = 1.f;
+    affine_inverse4(P2W, t0);         // w2p
+    affine_inverse4(A, t1);           // p2t
+    matmul4(B, t1, t2);               // (t2b @ p2t) @ w2p: torch evaluates the chain left to right
+    matmul4(t2, t0, t1);
+    if (invert) { affine_inverse4(t1, t0); for (int e = 0; e < 16; ++e) out[(size_t)i * 16 + e] = t0[e]; }
+    else for (int e = 0; e < 16; ++e) out[(size_t)i * 16 + e] = t1[e];
+}
+void launch_bigpose_compose(const float* mats, const float* d2, int n, float blend_radius, const float* R, const float* Th, int invert, float* out,
+                            hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(bigpose_compose_kernel, grid_for(n), dim3(TPB), 0, s, mats, d2, n, 1.f / (2.f * blend_radius * blend_radius), R, Th, invert, out);
 }
 
 void launch_fill(float* p, size_t n, float v, hipStream_t s) {

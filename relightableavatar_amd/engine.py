@@ -41,6 +41,7 @@ class Engine:
         assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None
+        self._frame_refs = None
         self._keep = []
 
     def __del__(self):
@@ -66,31 +67,68 @@ class Engine:
         check(self.lib.ra_finalize_weights(self.ctx, self.stream), 'ra_finalize_weights')
         self._frame_key = None
 
+    FRAME_KEYS = ('R', 'Th', 'poses', 'A', 'big_A', 'pverts', 'pnorm', 'tverts', 'weights')
+
+    def _cond_fix_source(self, batch):
+        """the pose the colour net is conditioned on in eval mode (base_network.py:501-503): with
+        `cfg.fix_material >= 0 or cfg.always_fix_material` it is train_motion.poses[:, cfg.fix_material] (so -1 selects the last
+        training pose) and a batch without train_motion is an error, exactly as in the reference; otherwise the current pose.
+        The relight network has no pose-conditioned head (relight_network.py:91-104)."""
+        if self.relight:
+            return None
+        c = self.cfg
+        if c.fix_material >= 0 or c.always_fix_material:
+            tm = batch.get('train_motion', None) if hasattr(batch, 'get') else None
+            if tm is None or 'poses' not in tm:
+                raise ValueError('cfg.fix_material / cfg.always_fix_material need batch.train_motion.poses (base_network.py:502-503)')
+            return tm['poses']
+        return batch['poses']
+
     def set_frame(self, batch, force=False):
-        """upload the SMPL frame state (batch keys of SURVEY.md section 8b)."""
-        key = tuple((batch[k].data_ptr(), batch[k]._version) for k in ('poses', 'pverts', 'A', 'R', 'Th'))
-        if key == self._frame_key and not force:
+        """upload the SMPL frame state (batch keys of SURVEY.md section 8b).  The upload is skipped only when every tensor of the
+        frame is the SAME live object (held by a strong reference, so its address cannot be recycled for another frame) at the
+        same in-place version as in the previous call, and the fixed-material index is unchanged."""
+        src = [batch[k] for k in self.FRAME_KEYS]
+        cf_src = self._cond_fix_source(batch)
+        refs = src + [cf_src]
+        key = tuple(None if t is None else t._version for t in refs) + (int(self.cfg.fix_material), bool(self.cfg.always_fix_material))
+        if (not force and self._frame_key == key and self._frame_refs is not None and len(self._frame_refs) == len(refs)
+                and all(a is b for a, b in zip(self._frame_refs, refs))):
             return
         d = self.device
-        t = {k: _f32(batch[k][0], d) for k in ('R', 'Th', 'poses', 'A', 'big_A', 'pverts', 'pnorm', 'tverts', 'weights')}
+        t = {k: _f32(batch[k][0], d) for k in self.FRAME_KEYS}
         cond_fix = None
-        if 'train_motion' in batch and self.cfg.fix_material >= 0:
-            cond_fix = _f32(batch['train_motion']['poses'][0, self.cfg.fix_material], d)
-        elif not self.relight:
-            cond_fix = t['poses']
+        if cf_src is not None:
+            cond_fix = t['poses'] if cf_src is batch['poses'] else _f32(cf_src[0, self.cfg.fix_material], d)
         fr = ra_frame(R=_ptr(t['R']), Th=_ptr(t['Th']), poses=_ptr(t['poses']), cond_fix=_ptr(cond_fix), A=_ptr(t['A']),
                       big_A=_ptr(t['big_A']), pverts=_ptr(t['pverts']), pnorm=_ptr(t['pnorm']), tverts=_ptr(t['tverts']),
                       weights=_ptr(t['weights']), n_verts=int(t['pverts'].shape[0]))
         assert t['weights'].shape[-1] == self.cfg.n_bones, 'batch.weights does not match cfg.n_bones'
         check(self.lib.ra_set_frame(self.ctx, C.byref(fr), self.stream), 'ra_set_frame')
         self._keep = [t, cond_fix]   # the library copies asynchronously on the stream
-        self._frame_key = key
+        self._frame_key, self._frame_refs = key, refs
 
     # ------------------------------------------------------------------ operators
     def hdq_sdf(self, x: torch.Tensor, dist_th: float, smooth: bool) -> torch.Tensor:
         x = _f32(x.reshape(-1, 3), self.device)
         out = torch.empty(x.shape[0], device=self.device, dtype=torch.float32)
         check(self.lib.ra_hdq_sdf(self.ctx, _ptr(x), x.shape[0], dist_th, int(smooth), _ptr(out), self.stream), 'ra_hdq_sdf')
+        return out
+
+    def observed_sdf(self, bpts: torch.Tensor) -> torch.Tensor:
+        """SDF(bpts + resd(bpts)) on big-pose points through the production distance-query kernel (no coarse level)."""
+        bpts = _f32(bpts.reshape(-1, 3), self.device)
+        out = torch.empty(bpts.shape[0], device=self.device, dtype=torch.float32)
+        check(self.lib.ra_observed_sdf(self.ctx, _ptr(bpts), bpts.shape[0], _ptr(out), self.stream), 'ra_observed_sdf')
+        return out
+
+    def bigpose_transform(self, x: torch.Tensor, R: torch.Tensor, Th: torch.Tensor, invert=False) -> torch.Tensor:
+        """(n,4,4) world -> big-pose transforms (or their affine inverses) of the points x against the current frame."""
+        x = _f32(x.reshape(-1, 3), self.device)
+        R, Th = _f32(R.reshape(3, 3), self.device), _f32(Th.reshape(3), self.device)
+        out = torch.empty(x.shape[0], 4, 4, device=self.device, dtype=torch.float32)
+        check(self.lib.ra_bigpose_transform(self.ctx, _ptr(x), x.shape[0], _ptr(R), _ptr(Th), int(invert), _ptr(out), self.stream),
+              'ra_bigpose_transform')
         return out
 
     def forward(self, x: torch.Tensor, v, dist_th: float) -> torch.Tensor:
@@ -153,6 +191,24 @@ class Engine:
         bb = (C.c_float * 6)(*[float(v) for v in bbox6])
         check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
                                               probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
+
+    def reshade_ground(self, ray_d, albedo_map, lvis, ldot, probes, images=None, attach_envmap=True):
+        """novel_light_sphere_tracing.render_ground (:70-99) for all probes at once: probes (n,h,w,3), optional images
+        (n,ih,iw,3) -> rgb, albedo, shade, spec each (n,P,3)."""
+        d = self.device
+        ray_d = _f32(ray_d.reshape(-1, 3), d)
+        P = ray_d.shape[0]
+        albedo_map = None if albedo_map is None else _f32(albedo_map.reshape(P, 3), d)
+        lvis, ldot = _f32(lvis.reshape(P, -1), d), _f32(ldot.reshape(P, -1), d)
+        probes = _f32(probes, d)
+        n, ph, pw = probes.shape[0], probes.shape[1], probes.shape[2]
+        images = None if images is None else _f32(images, d)
+        ih, iw = (images.shape[1], images.shape[2]) if images is not None else (0, 0)
+        outs = [torch.empty(n, P, 3, device=d) for _ in range(4)]
+        check(self.lib.ra_reshade_ground(self.ctx, _ptr(ray_d), _ptr(albedo_map), _ptr(lvis), _ptr(ldot), P, _ptr(probes), n, ph, pw,
+                                         _ptr(images), ih, iw, int(bool(attach_envmap)), *[_ptr(o) for o in outs], self.stream),
+              'ra_reshade_ground')
+        return tuple(outs)
 
     def blend_ground(self, ground, human, inds, acc):
         """blend_output_'s alpha_blend for one map: ground (F,C)/(F,) or None, human (P,C)/(P,) or None, inds (P) int64, acc (F)."""
@@ -299,6 +355,39 @@ class Engine:
         raw = torch.zeros(n, self.lib.ra_raw_channels(self.ctx), device=d)
         check(self.lib.ra_debug_full(self.ctx, _ptr(bpts), n, _ptr(grad), _ptr(sdf), _ptr(feat), _ptr(raw), self.stream), 'ra_debug_full')
         return grad, sdf, feat, raw
+
+    def debug_aabb(self, o, d, bbox6):
+        dv = self.device
+        o, d = _f32(o.reshape(-1, 3), dv), _f32(d.reshape(-1, 3), dv)
+        n = o.shape[0]
+        near, far = torch.empty(n, device=dv), torch.empty(n, device=dv)
+        bb = (C.c_float * 6)(*[float(v) for v in bbox6])
+        check(self.lib.ra_debug_aabb(self.ctx, _ptr(o), _ptr(d), n, bb, _ptr(near), _ptr(far), self.stream), 'ra_debug_aabb')
+        return near, far
+
+    def debug_lvis(self, surf, norm, acc, bbox6, lvis_cfg=None):
+        """light_visibility on given surface points: (n,512) lvis, ldot"""
+        dv = self.device
+        c = self.cfg
+        lv = c.obj_lvis if lvis_cfg is None else lvis_cfg
+        surf, norm, acc = _f32(surf.reshape(-1, 3), dv), _f32(norm.reshape(-1, 3), dv), _f32(acc.reshape(-1), dv)
+        n = surf.shape[0]
+        L = c.env_h * c.env_w
+        lvis, ldot = torch.empty(n, L, device=dv), torch.empty(n, L, device=dv)
+        bb = (C.c_float * 6)(*[float(v) for v in bbox6])
+        p = self.trace_params(lv, lv.dist_th, not c.no_dfss)
+        check(self.lib.ra_debug_lvis(self.ctx, _ptr(surf), _ptr(norm), _ptr(acc), n, bb, C.byref(p), float(lv.near_offset), _ptr(lvis), _ptr(ldot),
+                                     self.stream), 'ra_debug_lvis')
+        return lvis, ldot
+
+    def debug_brdf(self, p2l, p2c, normal, albedo, rough):
+        """p2l (L,N,3), others per point -> (L,N,3)"""
+        dv = self.device
+        L, N = p2l.shape[0], p2l.shape[1]
+        a = [_f32(t, dv) for t in (p2l.reshape(L * N, 3), p2c.reshape(N, 3), normal.reshape(N, 3), albedo.reshape(N, 3), rough.reshape(N))]
+        out = torch.empty(L, N, 3, device=dv)
+        check(self.lib.ra_debug_brdf(self.ctx, *[_ptr(t) for t in a], L, N, _ptr(out), self.stream), 'ra_debug_brdf')
+        return out
 
     def debug_hdq(self, x, dist_th):
         d = self.device

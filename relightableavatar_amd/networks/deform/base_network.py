@@ -4,6 +4,8 @@ Same class name, constructor contract (no arguments, everything from cfg), state
  and method surface the renderers use:
   forward(x, v, d, batch) -> dotdict(raw)                              base_network.py:496-515
   inference_world_distance_field(x, batch, smooth_transition, **kw)    base_network.py:385-387
+  inference_observed_distance_field(x, batch, smooth_transition, filtering, **kw)     base_network.py:447-449
+  world_to_bigpose_transform / bigpose_to_world_transform(x, batch)    base_network.py:338-363
   signed_distance_network.beta                                         base_network.py:74-76
 The modules below hold parameters only; all arithmetic runs in the HIP library through Engine.
 """
@@ -136,6 +138,54 @@ class Network(nn.Module):
         eng = self.set_frame(batch)
         dist_th = kwargs.get('dist_th', self.dist_th)
         return eng.hdq_sdf(x, dist_th, smooth_transition).view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def _template_frame(batch, identity_bones: bool):
+        """a frame whose posed body IS the template (pverts = tverts, pnorm = tnorm, R = I, Th = 0): what geodesic_knn sees when
+        the reference searches in space 't' (base_network.py:260-263) or filters big-pose points (:407-409)."""
+        tb = dotdict(batch)
+        tb.pverts, tb.pnorm = batch.tverts, batch.tnorm
+        tb.R = torch.eye(3, device=batch.R.device, dtype=batch.R.dtype)[None]
+        tb.Th = torch.zeros_like(batch.Th)
+        if identity_bones:        # big-pose points are queried as they are: no inverse skinning
+            eye = torch.eye(4, device=batch.A.device, dtype=batch.A.dtype).expand_as(batch.A).contiguous()
+            tb.A, tb.big_A = eye, eye
+        return tb
+
+    def inference_observed_distance_field(self, x: torch.Tensor, batch, smooth_transition=False, filtering=False, **kwargs) -> torch.Tensor:
+        """x: big-pose ("observed") points.  filtering=False: SDF(x + resd(x)).  filtering=True: the hierarchical query with the
+        template as the body (the reference's ablation mode; HIP kernels are the same as for the world-space query)."""
+        if not filtering:
+            return self.set_frame(batch).observed_sdf(x).view(*x.shape[:-1], 1)
+        tb = self._template_frame(batch, identity_bones=True)
+        eng = self.engine()
+        eng.set_frame(tb, force=True)
+        try:
+            return eng.hdq_sdf(x, kwargs.get('dist_th', self.dist_th), smooth_transition).view(*x.shape[:-1], 1)
+        finally:
+            eng.set_frame(batch, force=True)
+
+    def world_to_bigpose_transform(self, x: torch.Tensor, batch, backward=False, **kwargs) -> torch.Tensor:
+        """(B,P,4,4) = big_A_bw @ affine_inverse(A_bw) @ affine_inverse([R|Th]) per point, blended over the 3 nearest posed
+        vertices of x (backward: template vertices of x).  Th may be (B,3) or the dataset's (B,1,3) — the reference only
+        accepts the former (it concatenates Th[..., None] to R)."""
+        return self._transform(x, batch, backward, invert=False)
+
+    def bigpose_to_world_transform(self, x: torch.Tensor, batch, **kwargs) -> torch.Tensor:
+        return self._transform(x, batch, True, invert=True)
+
+    def _transform(self, x, batch, backward, invert):
+        eng = self.engine()
+        if backward:
+            eng.set_frame(self._template_frame(batch, identity_bones=False), force=True)
+        else:
+            eng.set_frame(batch)
+        try:
+            out = eng.bigpose_transform(x, batch.R[0], batch.Th.reshape(-1, 3)[0], invert)
+        finally:
+            if backward:
+                eng.set_frame(batch, force=True)
+        return out.view(*x.shape[:-1], 4, 4)
 
     def forward(self, x: torch.Tensor, v: torch.Tensor, d, batch, **kwargs):
         eng = self.set_frame(batch)

@@ -62,7 +62,7 @@ class Renderer(nn.Module):
         for k in names:
             w = width.get(k, 3)
             full[k] = torch.zeros((P, w) if w else (P,), device=dev)
-        for a, b in chunks(P, cfg.render_chunk_size):
+        for a, b in (batch.get('render_chunks', None) or chunks(P, cfg.render_chunk_size)):      # render_chunks: a shard's view of the frame's chunks (shard.py)
             # quirk (sphere_tracing_renderer.py:1020-1022): the box grows IN PLACE on the batch every chunk
             wb = batch.wbounds
             wb[:, 0] -= cfg.env_lvis.bbox_margin
@@ -86,15 +86,32 @@ class Renderer(nn.Module):
                 ret.lvis_map, ret.ldot_map = full.lvis[None], full.ldot[None]
         ret.envmap = envmap
         if ground:
-            ret = self._ground(batch, ret, eng, probe)
+            grd = self._ground(batch, ret, eng, probe)
+            if cfg.vis_novel_light:
+                ret.ground = grd             # the novel-light renderer re-shades both layers per probe, then blends (:1106-1107)
+            else:
+                ret = self.blend_output_(grd.acc_map, grd.inds, grd, ret, eng)
         return ret
 
     BLEND_KEYS = ('rgb_map', 'rfl_map', 'surf_map', 'albedo_map', 'roughness_map', 'norm_map', 'cpts_map', 'bpts_map', 'spec_map',
                   'depth_map', 'lvis_map', 'ldot_map', 'brdf_map', 'shade_map')
 
+    @classmethod
+    def blend_output_(cls, acc, inds, grd, ret, eng):
+        """blend_output_ (sphere_tracing_renderer.py:434-451): modifies and returns ret.  acc (1,F), inds (1,P) int64; maps of grd
+        are (1,F,C) / (1,F), maps of ret (1,P,C) / (1,P)."""
+        a, i = acc[0].contiguous(), inds[0].to(torch.int64).contiguous()
+        for k in cls.BLEND_KEYS:
+            if k in ret and k in grd:
+                ret[k] = eng.blend_ground(grd[k][0].contiguous(), ret[k][0], i, a)[None]
+            elif k in grd:
+                ret[k] = eng.blend_ground(grd[k][0].contiguous(), None, i, a)[None]
+        ret.acc_map = eng.blend_ground(None, ret.acc_map[0], i, a)[None]      # alpha_blend(acc, inds, zeros, acc_map) (:449)
+        return ret
+
     def _ground(self, batch, ret, eng, probe):
-        """Renderer.render :1084-1111: full-frame rays, acc = 1 - human acc on the in-box pixels, ground chunks (each growing
-        batch.wbounds again, :1054-1056), blend_output_."""
+        """Renderer.render :1084-1104: full-frame rays, acc = 1 - human acc on the in-box pixels, ground chunks (each growing
+        batch.wbounds again, :1054-1056).  Returns the ground layer (render_ground's dotdict + ray_o, ray_d, acc_map, inds)."""
         cfg = self.cfg
         dev = eng.device
         H, W = int(batch.meta.H.item()), int(batch.meta.W.item())
@@ -110,6 +127,9 @@ class Renderer(nn.Module):
         gp = eng.ground_params()
         out = dotdict({k: torch.zeros(F, 3, device=dev) for k in ('rgb', 'surf', 'albedo', 'shade', 'spec')})
         out.depth = torch.zeros(F, device=dev)
+        if cfg.vis_novel_light:              # cached for the per-probe re-shade (render_ground :541-543; 4 KB per frame pixel)
+            L = cfg.env_h * cfg.env_w
+            out.lvis, out.ldot = torch.zeros(F, L, device=dev), torch.zeros(F, L, device=dev)
         for a, b in chunks(F, cfg.render_chunk_size):
             wb = batch.wbounds
             wb[:, 0] -= cfg.env_lvis.bbox_margin
@@ -117,16 +137,11 @@ class Renderer(nn.Module):
             eng.render_ground_chunk(g_o[a:b], g_d[a:b], acc_g[a:b], wb[0].reshape(-1).tolist(), probe, gp,
                                     {k: v[a:b] for k, v in out.items()})
         n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, device=dev, dtype=torch.float32), dim=0)
-        grd = dotdict(rgb_map=out.rgb, surf_map=out.surf, albedo_map=out.albedo, roughness_map=torch.ones(F, device=dev),
-                      spec_map=out.spec, norm_map=n[None].expand(F, 3), shade_map=out.shade, cpts_map=torch.zeros(F, 3, device=dev),
-                      bpts_map=torch.zeros(F, 3, device=dev), depth_map=out.depth)
-        inds = inds.to(torch.int64).contiguous()
-        for k in self.BLEND_KEYS:
-            if k in ret and k in grd:
-                ret[k] = eng.blend_ground(grd[k].contiguous(), ret[k][0], inds, acc_g)[None]
-            elif k in grd:
-                ret[k] = eng.blend_ground(grd[k].contiguous(), None, inds, acc_g)[None]
-        ret.acc_map = eng.blend_ground(None, acc_h, inds, acc_g)[None]      # alpha_blend(acc, inds, zeros, acc_map) (:449)
-        ret.ground = dotdict(ray_o=g_o[None], ray_d=g_d[None], acc_map=acc_g[None], inds=inds[None])
+        grd = dotdict(rgb_map=out.rgb[None], surf_map=out.surf[None], albedo_map=out.albedo[None], roughness_map=torch.ones(1, F, device=dev),
+                      spec_map=out.spec[None], norm_map=n[None, None].expand(1, F, 3), shade_map=out.shade[None],
+                      cpts_map=torch.zeros(1, F, 3, device=dev), bpts_map=torch.zeros(1, F, 3, device=dev), depth_map=out.depth[None])
+        if 'lvis' in out:
+            grd.lvis_map, grd.ldot_map = out.lvis[None], out.ldot[None]
+        grd.ray_o, grd.ray_d, grd.acc_map, grd.inds = g_o[None], g_d[None], acc_g[None], inds.to(torch.int64)[None]
         batch.mask_at_box[:] = True                          # :1103
-        return ret
+        return grd

@@ -39,13 +39,15 @@ def _owner(P: int, world: int, batch, device) -> torch.Tensor:
 
 
 def plan(P: int, world: int, batch=None, device=None) -> dotdict:
-    """who owns which ray, and the index vectors of the exchange (identical on all ranks; cached per mask buffer)."""
+    """who owns which ray, and the index vectors of the exchange.  A pure function of (P, world, H, W, mask content), hence
+    identical on all ranks.  Cached per mask tensor OBJECT: the cache holds a strong reference to the mask, so its address
+    cannot be recycled for another frame's mask, and an in-place change bumps its version."""
     device = torch.device('cpu') if device is None else torch.device(device)
     mask = None if batch is None else batch.get('mask_at_box', None)
-    key = (P, world, str(device), None if mask is None else (mask.data_ptr(), mask._version))
-    pl = _PLANS.get(key)
-    if pl is not None:
-        return pl
+    key = (P, world, str(device))
+    hit = _PLANS.get(key)
+    if hit is not None and hit[0] is mask and hit[1] == (None if mask is None else mask._version):
+        return hit[2]
     owner = _owner(P, world, batch, device)
     counts = torch.bincount(owner, minlength=world)
     n_max = int(counts.max()) if P else 0
@@ -56,7 +58,7 @@ def plan(P: int, world: int, batch=None, device=None) -> dotdict:
                  idx=[order[int(starts[r]):int(starts[r]) + int(counts[r])] for r in range(world)])
     if len(_PLANS) > 16:
         _PLANS.clear()
-    _PLANS[key] = pl
+    _PLANS[key] = (mask, None if mask is None else mask._version, pl)
     return pl
 
 
@@ -69,8 +71,12 @@ def shard_indices(P: int, rank: int, world: int, batch=None, device=None) -> tor
     return plan(P, world, batch, device).idx[rank]
 
 
-def shard_batch(batch, rank: int, world: int):
-    """view of `batch` holding only this rank's rays (frame state is replicated)."""
+def shard_batch(batch, rank: int, world: int, render_chunk_size=None):
+    """view of `batch` holding only this rank's rays (frame state is replicated).
+    The single-GPU renderer grows batch.wbounds in place once per chunk of cfg.render_chunk_size rays (quirk 1), so a ray's
+    shadow-ray box depends on the chunk it falls in.  With `render_chunk_size` the shard carries `render_chunks`: the ranges of
+    ITS rays that belong to each chunk of the whole frame (rays keep their order inside a shard, so they are contiguous; empty
+    ranges still grow the box), which makes the merged shards identical to the single-GPU frame for multi-chunk frames too."""
     if world == 1:
         return batch
     P = batch.ray_o.shape[1]
@@ -79,6 +85,12 @@ def shard_batch(batch, rank: int, world: int):
     for k in RAY_KEYS:
         out[k] = batch[k][:, idx].contiguous()
     out.wbounds = batch.wbounds.clone()      # the renderer grows it in place per chunk (quirk 1)
+    if render_chunk_size is not None and P > 0:
+        import math
+        actual = math.ceil(P / math.ceil(P / render_chunk_size))          # chunkify's size rule (net_utils.py:323)
+        edges = torch.arange(0, P + actual, actual, device=idx.device).clamp(max=P)
+        pos = torch.searchsorted(idx, edges).tolist()                     # idx is ascending
+        out.render_chunks = [(pos[i], pos[i + 1]) for i in range(len(pos) - 1)]
     return out
 
 
@@ -105,7 +117,11 @@ def render_sharded(renderer, batch, keys=('rgb_map', 'acc_map'), rank=None, worl
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     P = batch.ray_o.shape[1]
-    out = renderer.render(shard_batch(batch, rank, world))
+    cfg = getattr(renderer, 'cfg', None)
+    if world > 1 and cfg is not None and cfg.get('vis_ground_shading', False):
+        raise ValueError('render_sharded: the ground-plane pass (cfg.vis_ground_shading) needs the whole frame\'s human layer '
+                         'and is not sharded; render it on one rank')
+    out = renderer.render(shard_batch(batch, rank, world, None if cfg is None else cfg.render_chunk_size))
     if world == 1:
         return dotdict({k: out[k] for k in keys})
     parts = [out[k] if out[k].ndim == 3 else out[k][..., None] for k in keys]

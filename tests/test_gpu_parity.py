@@ -10,9 +10,21 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
   traced surfaces .................... median |st err| < 2e-4; rays whose 16-iteration trace has not converged
                                        amplify sdf noise (occ = 500 d / t), so frame maps are judged by the
                                        fraction of pixels within tolerance + PSNR, not by max error
-  frames ............................. rgb PSNR >= 40 dB (relight/novel), >= 50 dB (sphere), >= 80 dB (volume)
+  frames ............................. SURVEY.md:409 contract for the 16-bit path: rgb PSNR >= 50 dB and max |err| <= 1e-2.
+      * asserted as such on the well-conditioned frames (smooth skinning field, where the reference's own sphere trace
+        converges): frame_relight_smooth, frame_novel_ground, volume frames;
+      * on the SURVEY 8d body (white noise in the skinning logits -> the world -> big-pose warp jumps by ~1 cm between
+        neighbouring query points, the REFERENCE's trace ends in a limit cycle on ~9 % of the hit rays, and a 1e-4 distance perturbation flips the
+        cycle's phase on ~1 % of the pixels) no 16-bit-operand arithmetic reaches it: tests/golden/precision_floor.json holds
+        the result of the operand-rounding emulation of the oracle (tools/precision_floor.py, SURVEY.md:305's experiment) on
+        the same frames — 48.2 dB f16 / 41.5 dB bf16 — and the HIP path is held to that floor (- 3 dB: which of the chaotic
+        pixels flip differs between two equally precise computations) and to >= 55 dB on the 98 % best pixels.
+  stage bisect ....................... test_mlp_stage_matches_the_operand_rounding_emulation: HIP sdf vs the kernel-like
+        emulation is several times closer than the emulation is to fp32, i.e. the in-kernel loss IS the operand rounding
+        (v_sin/v_cos encodings, scaled-domain softplus through v_exp/v_log and the f16 re-pack add nothing measurable).
 bf16 operands are available (cfg.mlp_dtype='bf16'); they are ~10x noisier (sdf mean err 5e-4) and tested loosely.
 """
+import json
 import os
 
 import numpy as np
@@ -81,6 +93,37 @@ def test_mlp_stage(ops, relight):
     assert float(e.max()) < 3e-4 and float(e.mean()) < 8e-5
     e = err(feat, ops['mlp_feat'])
     assert float(e.max()) < 2e-4 and float(e.mean()) < 3e-5
+
+
+def test_mlp_stage_production_kernel(ops, relight):
+    """the PRODUCTION distance-query kernel (streamed weights, register-resident activations) against the reference's own
+    MLP outputs, through Network.inference_observed_distance_field (base_network.py:447-449)"""
+    _, net, dev, body, eng = relight
+    sdf = net.inference_observed_distance_field(ops['mlp_bpts'][None].to(dev), body)
+    assert sdf.shape == (1, ops['mlp_bpts'].shape[0], 1)
+    e = err(sdf[0], ops['mlp_sdf'])
+    assert float(e.max()) < 3e-4 and float(e.mean()) < 8e-5
+
+
+def test_mlp_stage_matches_the_operand_rounding_emulation(relight):
+    """bisect of the precision gap: on 20 000 near-surface points the HIP kernel agrees with the oracle's
+    kernel-like f16 operand-rounding emulation much better than that emulation agrees with fp32 — the kernel loses nothing
+    beyond the rounding of MFMA operands."""
+    from oracle import ra_oracle as O
+    cfg, net, dev, body, eng = relight
+    g = torch.Generator().manual_seed(11)
+    d = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1)
+    bpts = d * (0.38 + 0.12 * torch.rand(20000, 1, generator=g))
+    sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+    fr = O._frame(synthetic.make_body(0, posed=True))
+    f32 = O.observed_sdf(O.OracleNet(sd, cfg), bpts, fr)[:, 0]
+    emu = O.observed_sdf(O.OracleNet(sd, cfg, emulate='f16', kernel_like=True), bpts, fr)[:, 0]
+    hip = eng.observed_sdf(bpts.to(dev)).cpu()
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt())
+    floor, gap, total = rms(emu, f32), rms(hip, emu), rms(hip, f32)
+    print(f'sdf rms: emulation-vs-fp32 {floor:.2e}, HIP-vs-emulation {gap:.2e}, HIP-vs-fp32 {total:.2e}')
+    assert total < 1.25 * floor, (total, floor)          # HIP is as close to fp32 as the emulation is
+    assert gap < 0.75 * floor, (gap, floor)              # and what separates HIP from the emulation is smaller than the rounding itself
 
 
 def test_mlp_stage_bf16(ops):
@@ -202,8 +245,43 @@ def test_frame_sphere_tracing(golden):
     assert psnr(out.rgb_map, ref['rgb_map']) > 50
 
 
+def trimmed_psnr(a, b, keep=0.98):
+    a, b = a.detach().float().cpu().reshape(-1, a.shape[-1]), torch.as_tensor(b).float().reshape(-1, a.shape[-1])
+    pp = (a - b).abs().amax(-1)
+    m = pp <= pp.kthvalue(max(1, int(round(keep * pp.numel())))).values
+    return float(-10 * torch.log10(((a - b)[m] ** 2).mean()))
+
+
+def floor_of(golden_dir_name, dtype='f16'):
+    here = os.path.dirname(os.path.abspath(__file__))
+    return json.load(open(os.path.join(here, 'golden', 'precision_floor.json')))[f'{golden_dir_name}:{dtype}']
+
+
+def test_frame_relight_smooth_meets_the_contract(golden):
+    """SURVEY.md:409: rgb PSNR >= 50 dB and max |err| <= 1e-2 against the reference — on the frame where the reference's
+    trace converges (smooth skinning field); the emulated-f16 floor of this frame is 64.7 dB / 6.1e-3"""
+    ref = golden('frame_relight_smooth.npz')
+    cfg, net, dev = build('relight', vis_specular_map=True)
+    from relightableavatar_amd.renderer import make_renderer
+    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']),
+                                                     skin_noise=float(ref['skin_noise'])), dev)
+    out = make_renderer(cfg, net).render(batch)
+    assert bool(((out.acc_map.cpu() > 0) == (T(ref['acc_map']) > 0)).all())
+    p, mx = psnr(out.rgb_map, ref['rgb_map']), float(err(out.rgb_map, ref['rgb_map']).max())
+    fl = floor_of('frame_relight_smooth.npz')['rgb_map']
+    print(f'frame_relight_smooth: rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]}), max {mx:.2e} (floor {fl["max_abs"]:.2e})')
+    assert p >= 50.0 and mx <= 1e-2
+    assert p >= fl['psnr'] - 3.0
+    assert float(err(out.albedo_map, ref['albedo_map']).max()) < 1e-3 and float(err(out.surf_map, ref['surf_map']).max()) < 2e-3
+    assert psnr(out.shade_map, ref['shade_map']) >= 50.0
+
+
 def test_frame_relight(golden):
     out, ref, batch, net = _frame('relight', 'frame_relight.npz', golden, vis_specular_map=True)
+    fl = floor_of('frame_relight.npz')['rgb_map']
+    p, pt = psnr(out.rgb_map, ref['rgb_map']), trimmed_psnr(out.rgb_map[0], ref['rgb_map'][0])
+    print(f'frame_relight (SURVEY 8d body): rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]}), 98 % best pixels {pt:.1f} dB (floor {fl["psnr_trim2pct"]})')
+    assert p >= fl['psnr'] - 3.0 and pt >= 55.0
     np.testing.assert_allclose(batch.wbounds.cpu().numpy(), ref['wbounds_after'], atol=1e-6)     # in-place bbox growth quirk
     assert bool(((out.acc_map.cpu() > 0) == (T(ref['acc_map']) > 0)).all())
     within(out, ref, 'albedo_map', 5e-4, 0.99)
@@ -213,7 +291,6 @@ def test_frame_relight(golden):
     within(out, ref, 'shade_map', 2e-2, 0.97)
     within(out, ref, 'spec_map', 5e-3, 0.97)
     within(out, ref, 'rgb_map', 1e-2, 0.97)
-    assert psnr(out.rgb_map, ref['rgb_map']) > 40
     c = net.engine().counters()
     assert c.n_hit_pixels == 256 and c.n_shadow_rays > 0 and c.n_fine_sdf > c.n_shadow_rays
 
@@ -227,7 +304,12 @@ def test_frame_novel_light(golden):
         within(out[n], sub, 'rgb_map', 1e-2, 0.97)
         within(out[n], sub, 'shade_map', 2e-2, 0.97)
         within(out[n], sub, 'spec_map', 5e-3, 0.97)
-        assert psnr(out[n].rgb_map, sub['rgb_map']) > 40
+        assert psnr(out[n].rgb_map, sub['rgb_map']) > 45 and trimmed_psnr(out[n].rgb_map[0], sub['rgb_map'][0]) > 55
+    # the cached per-light visibility / cosine of the main pass (what every probe is re-shaded from) against the reference's
+    sub = {k[len('probe00.'):]: v for k, v in ref.items() if k.startswith('probe00.')}
+    within(out['probe00'], sub, 'ldot_map', 2e-2, 0.97)          # n . l with the f16 normals
+    within(out['probe00'], sub, 'lvis_map', 3e-2, 0.97)          # DFSS penumbra values: sdf noise x sharp / (2 t)
+    assert float(err(out['probe00'].lvis_map, sub['lvis_map']).mean()) < 4e-3
 
 
 def test_reshade_is_linear_in_the_probe(relight):
@@ -565,3 +647,141 @@ def test_pose_frame_on_device(golden, relight):
     o2 = eng.pose_frame(sk.poses, sk.tjoints, sk.parents, T(sk.tverts).to(dev), T(sk.weights).to(dev), big_A, sk.faces, sk.Rh, sk.Th)
     assert torch.equal(o.pnorm, o2.pnorm) and torch.equal(o.pverts, o2.pverts)
 
+
+
+def test_frame_novel_ground(golden):
+    """the README's relight command (readme.md:64: vis_novel_light + vis_ground_shading): main + every probe, the human AND the
+    ground layer re-shaded per probe and blended per light (novel_light_sphere_tracing.py:70-99,138-213) vs the reference's
+    own frame (smooth skinning field -> the SURVEY.md:409 contract applies)"""
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('frame_novel_ground.npz')
+    kw = dict(vis_ground_shading=True, ground_normal=[float(v) for v in ref['ground_normal']],
+              ground_origin=[float(v) for v in ref['ground_origin']], render_chunk_size=int(ref['render_chunk_size']))
+    cfg, net, dev = build('novel_light', **kw)
+    H = int(ref['H'])
+    batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']), n_novel_lights=2,
+                                                     skin_noise=float(ref['skin_noise'])), dev)
+    rend = make_renderer(cfg, net)
+    m = batch.mask_at_box.reshape(1, -1).cpu()
+    rend.ground_inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]      # the scatter order of the CPU reference run
+    out = rend.render(batch)
+    np.testing.assert_allclose(batch.wbounds.cpu().numpy(), ref['wbounds_after'], atol=1e-6)
+    assert set(out.keys()) == {'main', 'probe00', 'probe01', 'diff'}
+    for name in ('main', 'probe00', 'probe01'):
+        sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+        o = out[name]
+        assert o.rgb_map.shape == (1, H * H, 3)
+        p, mx = psnr(o.rgb_map, sub['rgb_map']), float(err(o.rgb_map, sub['rgb_map']).max())
+        print(f'frame_novel_ground {name}: rgb PSNR {p:.1f} dB, max {mx:.2e}')
+        assert p >= 50.0 and mx <= 1e-2
+        assert psnr(o.shade_map, sub['shade_map']) >= 50.0 and float(err(o.spec_map, sub['spec_map']).max()) < 5e-3
+        assert float(err(o.albedo_map, sub['albedo_map']).max()) < 2e-3 and float(err(o.acc_map, sub['acc_map']).max()) < 2e-2
+    assert float((out.probe00.rgb_map - out.probe01.rgb_map).abs().max()) > 0.05
+
+
+def test_frame_anisdf_volume_128_samples(golden):
+    """BASELINE config 2's sample count (128 per ray; the depth-major tiled sample layout depends on S)"""
+    out, ref, _, _ = _frame('anisdf', 'frame_anisdf128.npz', golden)
+    assert int(ref['n_samples']) == 128
+    for k, tol in (('acc_map', 5e-4), ('depth_map', 1e-3), ('cpts_map', 2e-4), ('resd_map', 1e-5), ('norm_map', 2e-3), ('rgb_map', 3e-4)):
+        within(out, ref, k, tol, 1.0)
+    assert psnr(out.rgb_map, ref['rgb_map']) > 80 and float(err(out.rgb_map, ref['rgb_map']).max()) <= 1e-2
+
+
+def test_network_field_methods(golden, relight):
+    """the Network surface the reference renderer binds for its ablation modes (sphere_tracing_renderer.py:955-961)"""
+    _, net, dev, body, eng = relight
+    g = golden('fields.npz')
+    x = T(g['obs_x'])[None].to(dev)
+    assert float(err(net.inference_observed_distance_field(x, body)[0], g['obs_sdf']).max()) < 3e-4
+    assert float(err(net.inference_observed_distance_field(x, body, smooth_transition=True, filtering=True, dist_th=0.125)[0], g['obs_sdf_filtered']).max()) < 3e-4
+    assert float(err(net.inference_observed_distance_field(x, body, smooth_transition=False, filtering=True, dist_th=0.125)[0],
+                     g['obs_sdf_filtered_nosmooth']).max()) < 3e-4
+    # rows in point order here; the reference returns them in geodesic_knn's compaction order (w2b_inds / b2w_inds)
+    w2b = net.world_to_bigpose_transform(T(g['w2b_x'])[None].to(dev), body)
+    assert w2b.shape == (1, 300, 4, 4)
+    assert float(err(w2b[0].cpu()[T(g['w2b_inds'])], g['w2b']).max()) < 5e-6
+    b2w = net.bigpose_to_world_transform(x, body)
+    assert float(err(b2w[0].cpu()[T(g['b2w_inds'])], g['b2w']).max()) < 5e-6
+    # the frame state is restored after the template-space queries
+    s = net.inference_world_distance_field(T(golden('ops.npz')['hdq_x'])[None].to(dev), body, smooth_transition=True, dist_th=0.125)
+    assert float(err(s[0], golden('ops.npz')['hdq_sdf']).max()) < 3e-4
+
+
+def test_fix_material_rule(golden):
+    """base_network.py:501-503: with fix_material = -1 (always_fix_material) the colour net sees train_motion.poses[:, -1];
+    a batch without train_motion is an error, as in the reference"""
+    g = golden('fixmat.npz')
+    cfg, net, dev = build('anisdf', fix_material=-1)
+    body = synthetic.to_device(synthetic.make_body(0, posed=True), dev)
+    raw = net(T(g['x'])[None].to(dev), T(g['v'])[None].to(dev), 0.005, body).raw[0]
+    assert float(err(raw[:, 12:15], T(g['raw'])[:, 12:15]).max()) < 2e-3                # rgb under the last training pose
+    assert float(err(raw[:, 0:9], T(g['raw'])[:, 0:9]).max()) < 5e-6
+    cfg0, net0, _ = build('anisdf', fix_material=0)
+    raw0 = net0(T(g['x'])[None].to(dev), T(g['v'])[None].to(dev), 0.005, body).raw[0]
+    assert float((raw0[:, 12:15] - raw[:, 12:15]).abs().max()) > 1e-3
+    nb = synthetic.to_device(synthetic.make_body(0, posed=True), dev)
+    del nb['train_motion']
+    with pytest.raises(ValueError, match='train_motion'):
+        net(T(g['x'])[None].to(dev), T(g['v'])[None].to(dev), 0.005, nb)
+
+
+def test_new_frames_are_never_mistaken_for_the_cached_one():
+    """render frame A, free it, render frame B allocated the same way (CPU-resident batches that the renderer moves
+    itself): B must be rendered with B's pose — the cache keys on live tensor identity, never on recycled addresses"""
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('sphere_tracing')
+    rend = make_renderer(cfg, net)
+    outs = {}
+    for tag, seed in (('a', 0), ('b', 5), ('a2', 0)):
+        b = synthetic.make_batch(64, 64, seed=seed, posed=True, crop=16)            # CPU tensors, freed after each frame
+        outs[tag] = rend.render(b).rgb_map.clone()
+        del b
+    assert torch.equal(outs['a'], outs['a2'])
+    assert float((outs['a'] - outs['b']).abs().max()) > 1e-2
+    fresh_cfg, fresh_net, _ = build('sphere_tracing')
+    ref_b = make_renderer(fresh_cfg, fresh_net).render(synthetic.make_batch(64, 64, seed=5, posed=True, crop=16)).rgb_map
+    assert torch.equal(outs['b'], ref_b)
+
+
+def test_unused_stage_fixtures(ops, relight):
+    """fixtures of ops.npz that only the oracle used to read: the shadow-ray box clip incl. its direction-clamp quirk
+    (net_utils.py:1698), light_visibility on given surface points, the microfacet BRDF on arbitrary direction pairs"""
+    cfg, net, dev, body, eng = relight
+    near, far = eng.debug_aabb(ops['aabb_o'].to(dev), ops['aabb_d'].to(dev), ops['aabb_bounds'].reshape(-1).tolist())
+    e_n, e_f = err(near, ops['aabb_near']), err(far, ops['aabb_far'])
+    big = (T(np.abs(ops['aabb_near'].numpy()) > 1e6)) | (T(np.abs(ops['aabb_far'].numpy()) > 1e6))      # divisions by the 1e-8 clamp value
+    assert float(e_n[~big].max()) < 1e-5 and float(e_f[~big].max()) < 1e-5
+    assert float((e_n[big] / ops['aabb_near'][big].abs()).max()) < 1e-5 if bool(big.any()) else True
+    brdf = eng.debug_brdf(ops['mf_p2l'].to(dev), ops['mf_p2c'].to(dev), ops['mf_n'].to(dev), ops['mf_albedo'].to(dev), ops['mf_rough'].to(dev))
+    ref = ops['mf_brdf']
+    assert float((err(brdf, ref) / (ref.abs() + 1e-3)).max()) < 2e-3
+    lvis, ldot = eng.debug_lvis(ops['lv_surf'].to(dev), ops['lv_norm'].to(dev), ops['lv_acc'].to(dev), ops['lv_bbox'].reshape(-1).tolist())
+    assert float(err(ldot.T, ops['lv_ldot']).max()) < 1e-5
+    e = err(lvis.T, ops['lv_lvis'])
+    assert float(e.mean()) < 3e-3 and float((e < 3e-2).float().mean()) > 0.98
+    front = ops['lv_ldot'] > 1e-4
+    assert float(lvis.T.cpu()[ops['lv_ldot'] < -1e-4].abs().max()) == 0.0                  # back-facing lights: exactly 0
+
+
+def test_sharded_multi_chunk_frame_equals_the_whole_frame():
+    """a frame that spans several render chunks: the per-chunk in-place growth of batch.wbounds (quirk 1) makes a ray's shadow
+    box depend on its chunk; shards carry the frame's chunk boundaries (render_chunks), so merged shards == the whole frame"""
+    from relightableavatar_amd import shard
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight', render_chunk_size=2000)
+    rend = make_renderer(cfg, net)
+    base = synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True), dev)
+    P = base.ray_o.shape[1]
+    assert P > 3 * 2000
+    wb0 = base.wbounds.clone()
+    whole = rend.render(base).rgb_map.clone()
+    grown = base.wbounds.clone()
+    for world in (2, 3):
+        merged = torch.zeros_like(whole[0])
+        for r in range(world):
+            base.wbounds.copy_(wb0)
+            sb = shard.shard_batch(base, r, world, cfg.render_chunk_size)
+            merged[shard.shard_indices(P, r, world, base, merged.device)] = rend.render(sb).rgb_map[0]
+            assert torch.equal(sb.wbounds, grown)                                   # every shard grew the box as often as the frame did
+        assert torch.equal(merged, whole[0]), world

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f'{name} declared in the header but not exported'
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    assert L.ra_abi_version() == 1
+    assert L.ra_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define RA_ABI_VERSION (\d+)', hdr).group(1))
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -154,3 +154,79 @@ def test_sharded_render_gloo_world2(tmp_path):
                         '--master-port', '29611', str(script), REPO], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('ok') == 2
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` outside torchrun is a launcher: it starts 2 ranks under torch.distributed.run, which shard the
+    frame, gather it (gloo here, RCCL on the GPU box) and print ONE JSON line with n_gpus = 2 (--dry: no HIP engine)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--dry', '--size', '96', '--steps', '2',
+                        '--warmup', '1'], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0 and line['config']['gather_ok'] is True
+    # and the rank program refuses a world size that contradicts --gpus
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--dry', '--backend', 'gloo'], capture_output=True, text=True,
+                       env=dict(env, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29655'), timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stdout + r.stderr)
+
+
+def test_shards_carry_the_frames_chunk_boundaries():
+    """quirk 1 (per-chunk growth of batch.wbounds): a shard renders its rays chunk by chunk of the WHOLE frame"""
+    b = synthetic.make_batch(96, 96, seed=0)
+    P = b.ray_o.shape[1]
+    chunk = 700
+    full = chunks(P, chunk)
+    for world in (2, 3):
+        seen = torch.zeros(P, dtype=torch.long)
+        for r in range(world):
+            sb = shard.shard_batch(b, r, world, chunk)
+            idx = shard.shard_indices(P, r, world, b)
+            assert len(sb.render_chunks) == len(full)
+            assert sb.render_chunks[0][0] == 0 and sb.render_chunks[-1][1] == idx.numel()
+            for (a, e), (fa, fe) in zip(sb.render_chunks, full):
+                assert bool(((idx[a:e] >= fa) & (idx[a:e] < fe)).all())               # those rays do belong to that frame chunk
+                seen[idx[a:e]] += 1
+        assert bool((seen == 1).all())
+    assert 'render_chunks' not in shard.shard_batch(b, 0, 1, chunk)                  # world 1: the batch itself
+
+
+def test_sharded_ground_pass_is_rejected():
+    from relightableavatar_amd.base_utils import dotdict
+
+    class R:
+        cfg = make_cfg('relight', vis_ground_shading=True)
+    with pytest.raises(ValueError, match='ground'):
+        shard.render_sharded(R(), synthetic.make_batch(32, 32, seed=0), ('rgb_map',), 0, 2)
+
+
+def test_plan_cache_keys_on_the_live_mask_object():
+    """a new frame's mask at a recycled address must not hit the previous frame's plan"""
+    b1 = synthetic.make_batch(64, 64, seed=0)
+    P = b1.ray_o.shape[1]
+    p1 = shard.plan(P, 2, b1)
+    assert shard.plan(P, 2, b1) is p1                                                # same live mask, same version: cached
+    b2 = synthetic.make_batch(64, 64, seed=0)
+    b2.mask_at_box = b1.mask_at_box.clone()
+    assert shard.plan(P, 2, b2) is not p1                                            # another tensor object: recomputed
+    b1.mask_at_box[:] = b1.mask_at_box                                               # in-place write bumps the version
+    assert shard.plan(P, 2, b1) is not p1
+
+
+def test_fixed_material_source_rule():
+    """base_network.py:501-503 without a GPU: which pose conditions the colour net"""
+    import types
+    from relightableavatar_amd.engine import Engine
+    body = synthetic.make_body(0)
+    pick = lambda **kw: Engine._cond_fix_source(types.SimpleNamespace(relight=False, cfg=make_cfg('anisdf', **kw)), body)
+    assert pick(fix_material=0) is body.train_motion.poses
+    assert pick(fix_material=-1, always_fix_material=True) is body.train_motion.poses
+    assert pick(fix_material=-1, always_fix_material=False) is body.poses
+    nb = synthetic.make_body(0)
+    del nb['train_motion']
+    with pytest.raises(ValueError, match='train_motion'):
+        Engine._cond_fix_source(types.SimpleNamespace(relight=False, cfg=make_cfg('anisdf')), nb)
+    assert Engine._cond_fix_source(types.SimpleNamespace(relight=True, cfg=make_cfg('relight')), nb) is None

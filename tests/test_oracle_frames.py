@@ -110,3 +110,81 @@ def test_frame_ground(golden):
     _cmp(out, ref, 'spec_map', 5e-4, frac_ok=0.999)
     assert O.psnr(out.rgb_map, T(ref['rgb_map'])) > 60
 
+
+
+def test_frame_relight_smooth(golden):
+    """the well-conditioned relight frame (smooth skinning field: the reference's sphere trace converges)"""
+    ref = golden('frame_relight_smooth.npz')
+    net = _net('relight', True, vis_specular_map=True)
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=float(ref['skin_noise']))
+    out = O.render_sphere_tracing(net, batch)
+    assert bool(((out.acc_map > 0) == (T(ref['acc_map']) > 0)).all())
+    for k in ('surf_map', 'albedo_map', 'roughness_map'):
+        _cmp(out, ref, k, 1e-4)
+    _cmp(out, ref, 'norm_map', 4e-3)      # fp32 autograd vs the reference's: a few 1e-3 outliers where the blended 3x3 is ill-conditioned
+    _cmp(out, ref, 'rgb_map', 4e-4)
+    _cmp(out, ref, 'shade_map', 6e-4)     # penumbra values: fp32 re-association x (sharp / 2t)
+    assert O.psnr(out.rgb_map, T(ref['rgb_map'])) > 80
+
+
+def test_frame_novel_ground(golden):
+    """the README's relight command (readme.md:64): vis_novel_light + vis_ground_shading — per-probe re-shade of the human AND
+    the ground layer, blend_output_ per light and for 'main' (novel_light_sphere_tracing.py:138-213)"""
+    ref = golden('frame_novel_ground.npz')
+    net = _net('novel_light', True, **_ground_cfg(ref))
+    H = int(ref['H'])
+    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']), n_novel_lights=2, skin_noise=float(ref['skin_noise']))
+    m = batch.mask_at_box.reshape(1, -1)
+    inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]
+    out = O.render_novel_light(net, batch, ground_inds=inds)
+    np.testing.assert_allclose(batch.wbounds.numpy(), ref['wbounds_after'], atol=1e-6)
+    for name in ('main', 'probe00', 'probe01'):
+        sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+        assert out[name].rgb_map.shape == (1, H * H, 3)
+        _cmp(out[name], sub, 'rgb_map', 4e-4)
+        _cmp(out[name], sub, 'shade_map', 4e-4)
+        _cmp(out[name], sub, 'spec_map', 1e-4)
+        _cmp(out[name], sub, 'albedo_map', 1e-5)
+        _cmp(out[name], sub, 'acc_map', 1e-4)
+        _cmp(out[name], sub, 'norm_map', 2e-3)
+    assert float((out.probe00.rgb_map - out.probe01.rgb_map).abs().max()) > 0.05      # the probes do light the frame differently
+
+
+def test_frame_anisdf128(golden):
+    """BASELINE config 2's sample count (128 per ray, base.yaml:78)"""
+    ref = golden('frame_anisdf128.npz')
+    assert int(ref['n_samples']) == 128
+    net = _net('anisdf', False, n_samples=128)
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']))
+    out = O.render_volume(net, batch)
+    for k in ('acc_map', 'depth_map', 'cpts_map', 'bpts_map', 'resd_map'):
+        _cmp(out, ref, k, 1e-4)
+    _cmp(out, ref, 'norm_map', 1e-3)
+    _cmp(out, ref, 'rgb_map', 1e-4)
+
+
+def test_network_field_methods(golden):
+    """inference_observed_distance_field (plain / filtered) and the two transform methods (base_network.py:338-363,389-449)"""
+    g = golden('fields.npz')
+    net = _net('relight', True)
+    fr = O._frame(synthetic.make_body(0, posed=True))
+    x = T(g['obs_x'])
+    assert float((O.observed_sdf(net, x, fr) - T(g['obs_sdf'])).abs().max()) < 2e-6
+    assert float((O.observed_sdf(net, x, fr, True, True, 0.125) - T(g['obs_sdf_filtered'])).abs().max()) < 2e-6
+    assert float((O.observed_sdf(net, x, fr, False, True, 0.125) - T(g['obs_sdf_filtered_nosmooth'])).abs().max()) < 2e-6
+    # the reference returns the rows in geodesic_knn's compaction order (topk(sorted=False), implementation-defined): w2b_inds
+    assert float((O.bigpose_transform(net, T(g['w2b_x']), fr)[T(g['w2b_inds'])] - T(g['w2b'])).abs().max()) < 2e-6
+    assert float((O.bigpose_transform(net, x, fr, backward=True, invert=True)[T(g['b2w_inds'])] - T(g['b2w'])).abs().max()) < 2e-6
+
+
+def test_fix_material_minus_one(golden):
+    """cfg.fix_material = -1 with always_fix_material: the colour net is conditioned on the LAST training pose (base_network.py:502)"""
+    g = golden('fixmat.npz')
+    assert int(g['fix_material']) == -1
+    net = _net('anisdf', False, fix_material=-1)
+    body = synthetic.make_body(0, posed=True)
+    raw, _ = O.network_forward(net, T(g['x']), T(g['v']), O._frame(body))
+    assert float((raw - T(g['raw'])).abs().max()) < 2e-5
+    net0 = _net('anisdf', False, fix_material=0)
+    raw0, _ = O.network_forward(net0, T(g['x']), T(g['v']), O._frame(body))
+    assert float((raw0[:, 12:15] - T(g['raw'])[:, 12:15]).abs().max()) > 1e-3       # the other pose gives another colour

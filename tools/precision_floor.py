@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Precision floor of 16-bit MFMA operands on the golden frames (CPU, oracle only — test infrastructure).
+
+Renders each golden relight frame with the oracle's operand-rounding emulation (every nn.Linear input and weight rounded to
+f16 / bf16, fp32 accumulate — what SURVEY.md:305 measured — in the kernel-like variant: pose condition through an fp32 bias,
+hi + lo coordinates on the SDF net's encoding-fed layers) and compares with the REFERENCE's own fp32 output
+(tests/golden/frame_*.npz).  No 16-bit-operand kernel can be closer to the reference than this on that frame; the GPU parity
+tests hold the HIP path to these floors (tests/test_gpu_parity.py) and tests/test_oracle_emulation.py re-derives one of them.
+
+    python tools/precision_floor.py            # rewrites tests/golden/precision_floor.json (about 4 minutes on 8 cores)
+
+Findings recorded in DESIGN.md section 2: on the SURVEY 8d body (per-vertex noise in the skinning logits) the world -> big-pose
+warp jumps by ~1 cm wherever the nearest vertices change, the reference's own 16-iteration sphere trace ends in a limit cycle on ~9 % of the hit
+~9 % of the hit rays, and a 1e-4 distance perturbation flips the phase of that cycle on ~1 % of the pixels (4 mm surface jumps, 0.05 rgb):
+the rgb PSNR of ANY 16-bit path is set by those one or two pixels.  With a spatially smooth skinning field (skin_noise = 0, a
+real SMPL body's situation) the trace converges and f16 operands reproduce the reference to > 60 dB.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ra_oracle as O                      # noqa: E402
+from relightableavatar_amd import synthetic            # noqa: E402
+from relightableavatar_amd.config import make_cfg      # noqa: E402
+
+FRAMES = {'frame_relight.npz': 2.0, 'frame_relight_smooth.npz': 0.0}
+
+
+def stats(a, b):
+    a, b = a.float().reshape(-1, a.shape[-1]), b.float().reshape(-1, b.shape[-1])
+    e = (a - b).abs()
+    per_pix = e.amax(-1)
+    keep = per_pix <= per_pix.kthvalue(max(1, int(round(0.98 * per_pix.numel())))).values      # drop the worst 2 % of the pixels
+    return dict(psnr=round(O.psnr(a, b), 2), psnr_trim2pct=round(O.psnr(a[keep], b[keep]), 2), max_abs=float(e.max()),
+                n_over_1e2=int((e > 1e-2).sum()), mean_abs=float(e.mean()))
+
+
+def frame_floor(fname, skin_noise, emu):
+    ref = dict(np.load(os.path.join(ROOT, 'tests', 'golden', fname)))
+    cfg = make_cfg('relight', vis_specular_map=True)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg, emulate=emu, kernel_like=True)
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=skin_noise)
+    out = O.render_sphere_tracing(net, batch)
+    return {k: stats(out[k][0], torch.from_numpy(ref[k])[0]) for k in ('rgb_map', 'shade_map', 'norm_map', 'surf_map')}
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    res = {'_about': 'emulated 16-bit-operand oracle vs the reference fp32 goldens; written by tools/precision_floor.py'}
+    for fname, sn in FRAMES.items():
+        for emu in ('f16', 'bf16'):
+            t0 = time.time()
+            res[f'{fname}:{emu}'] = frame_floor(fname, sn, emu)
+            print(fname, emu, f'{time.time() - t0:.0f} s', json.dumps(res[f'{fname}:{emu}']['rgb_map']), flush=True)
+    with open(os.path.join(ROOT, 'tests', 'golden', 'precision_floor.json'), 'w') as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
