@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--emulate-world', type=int, default=0, help='tuning aid: render only rank 0\'s shard of an N-rank job on one GPU (no collective); value is then NOT a whole-job rate')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL on ROCm; gloo only with --dry')
     ap.add_argument('--dry', action='store_true', help='no HIP engine: launcher + process-group plumbing on CPU tensors (CPU test of the N > 1 path)')
+    ap.add_argument('--static-frame', action='store_true', help='A/B: do not re-pose the body every step (round-1 behaviour: per-frame set-up outside the timed region)')
     ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 
@@ -185,7 +186,8 @@ def main():
 
     def step():
         base.wbounds.copy_(wb0)     # a fresh batch per frame, as the reference's loader delivers
-        eng.set_frame(base, force=True)     # an animation poses a new body every frame: vertex blend, BVH build, bias folds are timed
+        if not args.static_frame:
+            eng.set_frame(base, force=True)     # an animation poses a new body every frame: vertex blend, BVH build, bias folds are timed
         if args.ground:
             base.mask_at_box.copy_(mask0)   # the ground pass sets it to all-true in place (sphere_tracing_renderer.py:1103)
         if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
@@ -250,7 +252,7 @@ def main():
         }
         line['hit_pixels_per_sec'] = cnts[3].item() / dt          # the 84 % of rays that miss the box cost nothing: rays/s flatters
         line['fine_queries_per_sec'] = cnts[0].item() / dt
-        line['config']['frame_setup'] = 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
+        line['config']['frame_setup'] = 'static frame (set-up excluded)' if args.static_frame else 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, H)
         print(json.dumps(line))

@@ -294,6 +294,32 @@ int ra_shift_envmap(ra_ctx* ctx, const float* img, int H, int W, int C, float sh
 int ra_add_light_probe(ra_ctx* ctx, float* rgb, int H, int W, const float* probe, int ph, int pw, const float* cam_R, int uH, int uW,
                        void* stream);
 
+/* ---- N4, third item: map -> image normalisations of the reference visualiser -------------------------------------
+ * Visualizer.generate_image (lib/visualizers/base_visualizer.py:54-201) for one output type (lib/config/config.py:364-378): the
+ * per-type normalisation of the rendered map, then the scatter of the P in-box rays into the H x W image over bg_brightness
+ * (:188-195) and, if alpha != NULL, the alpha plane (:201-208; the caller concatenates it after the light-probe inset).
+ *   SURFACE   a = cpts_map | surf_map (P,3): (a - tbounds[0]) / (tbounds[1] - tbounds[0]) * acc
+ *   RESIDUAL  a = cpts_map, b = bpts_map:     acc * (a - b) / (the int(0.005 * 3P)-th largest value of a - b)
+ *   DEPTH     a = depth_map (P):              clip((a - lo) / (hi - lo), 0, 1), lo / hi = the int(0.01 * P)-th smallest / largest
+ *                                             depth among rays with acc != 0, lo clipped to min_clip
+ *   ALPHA     acc;   ROUGHNESS a (P);   RENDERING a (P,3);   ALBEDO a (P,3), linear2srgb if tonemap
+ *   NORMAL    a = norm_map (P,3):             (normalize(a) @ cam_R^T, y and z flipped) * 0.5 + 0.5, times acc
+ *   SHADING / SPECULAR a (P,3):               if normalize: a / (the int(0.005 * 3P)-th largest value)
+ * pix: frame pixel of every ray (NULL: the maps are full-frame, P == H*W).  image: H*W x 3. */
+enum { RA_IMG_SURFACE = 3, RA_IMG_RESIDUAL = 4, RA_IMG_DEPTH = 5, RA_IMG_ALPHA = 6, RA_IMG_NORMAL = 7, RA_IMG_SPECULAR = 8,
+       RA_IMG_ALBEDO = 9, RA_IMG_ROUGHNESS = 10, RA_IMG_SHADING = 11, RA_IMG_RENDERING = 12 };      /* values of the Output enum */
+typedef struct ra_image_params {
+    int type, H, W;
+    float bg_brightness;    /* cfg.bg_brightness */
+    int normalize;          /* cfg.normalize_shading / cfg.normalize_specular */
+    int tonemap;            /* cfg.tonemapping_albedo */
+    float min_clip;         /* cfg.min_clip */
+    float cam_R[9];         /* batch.cam_R (world -> camera), NORMAL */
+    float tbounds[6];       /* batch.tbounds (big-pose box), SURFACE */
+} ra_image_params;
+int ra_map_to_image(ra_ctx* ctx, const ra_image_params* p, const float* a_dev, const float* b_dev, const float* acc_dev,
+                    const long long* pix_dev, int P, float* image_dev, float* alpha_dev, void* stream);
+
 /* ---- test hooks: stage outputs for the parity tests (tests/test_gpu_*.py); not used by renderers ---- */
 /* resd + sdf MLPs on given big-pose points: resd n x 3, sdf n, feat n x 256 (any may be NULL) */
 int ra_debug_mlp(ra_ctx* ctx, const float* bpts_dev, int n, float* resd, float* sdf, float* feat, void* stream);

@@ -329,13 +329,26 @@ class OracleNet:
     def _q(self, t):
         return t if self.emulate is None else t.to(self.emulate).float()
 
-    def lin(self, x, w, b, exact_cols=None, hilo_cols=None):
+    SP_SCALE = 144.26950408889634        # beta * log2(e): the kernels run the softplus layers in the domain y' = y * SP_SCALE
+
+    def lin(self, x, w, b, exact_cols=None, hilo_cols=None, scaled_x=False, scaled_w_cols=None):
         """F.linear with the operand rounding of the emulation mode.  exact_cols: slice of input columns that stay fp32
         (the kernel folds them into a bias); hilo_cols: index list of input columns fed as hi + lo pairs against the same
-        rounded weight (residual of the first rounding rounded again)."""
+        rounded weight (residual of the first rounding rounded again).  kernel_like only: scaled_x — the input is rounded as
+        x * SP_SCALE (hidden activations of the softplus net live in the scaled domain); scaled_w_cols — these weight columns
+        are rounded as w * SP_SCALE (they are fed by the unscaled encoding and carry the factor)."""
         if self.emulate is None:
             return F.linear(x, w, b)
-        xq, wq = self._q(x), self._q(w)
+        S = self.SP_SCALE
+        if self.kernel_like and scaled_x:
+            n_h = x.shape[-1] if scaled_w_cols is None else scaled_w_cols.start
+            xq = torch.cat([self._q(x[..., :n_h] * S) / S, self._q(x[..., n_h:])], dim=-1)
+        else:
+            xq = self._q(x)
+        wq = self._q(w)
+        if self.kernel_like and scaled_w_cols is not None:
+            wq = wq.clone()
+            wq[:, scaled_w_cols] = self._q(w[:, scaled_w_cols] * S) / S
         if self.kernel_like and hilo_cols is not None:
             xq = xq.clone()
             xq[..., hilo_cols] = xq[..., hilo_cols] + self._q(x[..., hilo_cols] - xq[..., hilo_cols])
@@ -375,7 +388,8 @@ class OracleNet:
                 hilo = [x.shape[-1] - inp.shape[-1] + k for k in range(9)]
             elif l == 0:
                 hilo = list(range(9))            # x, sin(x), cos(x)
-            x = self.lin(x, w, b, hilo_cols=hilo)
+            pe_cols = slice(x.shape[-1] - inp.shape[-1], x.shape[-1]) if l in (0, 4) else None
+            x = self.lin(x, w, b, hilo_cols=hilo, scaled_x=l > 0, scaled_w_cols=pe_cols)
             if l < 8:
                 x = softplus100(x)
         return x[..., :1], x[..., 1:]
@@ -983,6 +997,59 @@ def render_novel_light(net: OracleNet, batch, ground_inds=None):
         relight[name] = odict({k: v[None] for k, v in human.items()})
     relight._main_full = main
     return relight
+
+
+def generate_image(output, batch, kind: str, cfg):
+    """Visualizer.generate_image lib/visualizers/base_visualizer.py:54-208 (no ground truth): kind is the Output member's name.
+    output: batched maps (1,P,..); returns the (H,W,3|4) image as a tensor."""
+    H, W = int(batch['meta']['H'][0]), int(batch['meta']['W'][0])
+    acc = output['acc_map'][0]
+
+    def kth(v, frac, numel):                      # "a simple version of percentile" (:108-109)
+        k = int(frac * numel)
+        v = v.ravel()
+        return v.topk(k, largest=False)[0].max(), v.topk(k, largest=True)[0].min()
+    if kind == 'Normal':
+        n = normalize(output['norm_map'][0]) @ batch['cam_R'][0].mT
+        n = n * torch.tensor([1.0, -1.0, -1.0])
+        rgb = (n * 0.5 + 0.5) * acc[:, None]
+    elif kind == 'Alpha':
+        rgb = acc[:, None].expand(-1, 3)
+    elif kind == 'Depth':
+        d = output['depth_map'][0]
+        lo, hi = kth(d[acc.bool()], 0.01, d.numel())
+        lo = lo.clip(None, cfg.min_clip)
+        rgb = ((d - lo) / (hi - lo)).clip(0, 1)[:, None].expand(-1, 3)
+    elif kind in ('Shading', 'Specular'):
+        rgb = output['shade_map' if kind == 'Shading' else 'spec_map'][0]
+        if cfg.normalize_shading if kind == 'Shading' else cfg.normalize_specular:
+            rgb = rgb / kth(rgb, 0.005, rgb.numel())[1]
+    elif kind == 'Albedo':
+        rgb = linear2srgb(output['albedo_map'][0]) if cfg.tonemapping_albedo else output['albedo_map'][0]
+    elif kind == 'Roughness':
+        rgb = output['roughness_map'][0][:, None].expand(-1, 3)
+    elif kind == 'Surface':
+        m = output['cpts_map'][0] if 'cpts_map' in output else output['surf_map'][0]
+        tb = batch['tbounds'][0]
+        rgb = acc[:, None] * ((m - tb[0:1]) / (tb[1:2] - tb[0:1]))
+    elif kind == 'Residual':
+        d = output['cpts_map'][0] - output['bpts_map'][0]
+        rgb = acc[:, None] * (d / kth(d, 0.005, d.numel())[1])
+    elif kind == 'Rendering':
+        rgb = output['rgb_map'][0]
+    else:
+        raise NotImplementedError(kind)
+    mask = batch['mask_at_box'][0].reshape(H, W)
+    img = torch.ones(H, W, 3) * cfg.bg_brightness
+    img[mask] = rgb
+    if cfg.probe_size_ratio > 0 and output.get('envmap', None) is not None:
+        img = add_light_probe(img.reshape(H * W, 3), output['envmap']['probe'][0], H, W, batch['cam_R'][0], cfg.env_h, cfg.env_w,
+                              cfg.probe_size_ratio).reshape(H, W, 3)
+    if cfg.store_alpha_channel:
+        alpha = torch.zeros(H, W, 1)
+        alpha[mask] = acc[:, None]
+        img = torch.cat([img, alpha], dim=-1)
+    return img
 
 
 def psnr(a, b):

@@ -76,6 +76,11 @@ class ra_pose_out(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in POSE_OUT_KEYS]
 
 
+class ra_image_params(C.Structure):
+    _fields_ = [('type', C.c_int), ('H', C.c_int), ('W', C.c_int), ('bg_brightness', C.c_float), ('normalize', C.c_int), ('tonemap', C.c_int),
+                ('min_clip', C.c_float), ('cam_R', C.c_float * 9), ('tbounds', C.c_float * 6)]
+
+
 class ra_counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ('n_coarse', 'n_fine_sdf', 'n_fine_full', 'n_shadow_rays', 'n_hit_pixels', 'n_shaded')]
 
@@ -114,6 +119,7 @@ SYMBOLS = {
     'ra_pose_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_pose_in), C.POINTER(ra_pose_out), C.c_void_p]),
     'ra_shift_envmap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'ra_add_light_probe': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
+    'ra_map_to_image': (C.c_int, [C.c_void_p, C.POINTER(ra_image_params)] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_gen_rays': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.c_void_p]),
     'ra_debug_mlp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_full': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

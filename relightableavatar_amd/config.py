@@ -105,6 +105,13 @@ def default_cfg() -> dotdict:
     c.rotate_ratio = 4            # config.py:350
     c.probe_size_ratio = 0.2      # config.py:354
     c.env_image_w = 2048
+    # visualiser normalisations (config.py:41-46,384,398,416)
+    c.normalize_shading = False
+    c.normalize_specular = True
+    c.min_clip = 1.0
+    c.vis_median_depth = False
+    c.store_alpha_channel = True
+    c.tonemapping_albedo = True
     # build-side knobs (not in the reference)
     c.mlp_dtype = 'f16'          # element type of the fused MLP kernels: 'f16' or 'bf16' (fp32 accumulate either way)
     return c

@@ -894,6 +894,48 @@ int ra_add_light_probe(ra_ctx* c, float* rgb, int H, int W, const float* probe, 
     return 0;
 }
 
+int ra_map_to_image(ra_ctx* c, const ra_image_params* p, const float* a, const float* b, const float* acc, const long long* pix, int P,
+                    float* image, float* alpha, void* stream) {
+    RA_CHECK(c && p && image, "ra_map_to_image: null argument");
+    RA_CHECK(p->H > 0 && p->W > 0 && P >= 0 && (long long)p->H * p->W < (1ll << 30), "ra_map_to_image: bad sizes");
+    RA_CHECK(p->type >= RA_IMG_SURFACE && p->type <= RA_IMG_RENDERING, "ra_map_to_image: unknown output type");
+    RA_CHECK(P == 0 || a || p->type == RA_IMG_ALPHA, "ra_map_to_image: the map is missing");
+    RA_CHECK(pix || P == p->H * p->W || P == 0, "ra_map_to_image: without pixel indices the maps must be full-frame");
+    RA_CHECK(p->type != RA_IMG_RESIDUAL || b, "ra_map_to_image: Residual needs cpts_map and bpts_map");
+    RA_CHECK((p->type != RA_IMG_SURFACE && p->type != RA_IMG_NORMAL && p->type != RA_IMG_ALPHA && p->type != RA_IMG_DEPTH) || acc || P == 0,
+             "ra_map_to_image: this type needs acc_map");
+    hipStream_t s = (hipStream_t)stream;
+    RA_HIP(hipSetDevice(c->device));
+    int err = 0;
+    float* stats = c->buf<float>("im_stats", 4, &err);
+    const bool pct_all = p->type == RA_IMG_RESIDUAL || ((p->type == RA_IMG_SHADING || p->type == RA_IMG_SPECULAR) && p->normalize);
+    if (P > 0 && (pct_all || p->type == RA_IMG_DEPTH)) {
+        const long long n = pct_all ? 3ll * P : P;
+        const int k = (int)((pct_all ? 0.005 : 0.01) * (double)n);                    // int(percentile * depth_map.numel())
+        RA_CHECK(k >= 1, "ra_map_to_image: too few rays for the percentile (the reference's topk(0).max() fails too)");
+        const size_t tb = image_sort_temp_bytes(n);
+        float* sa = c->buf<float>("im_sa", n, &err);
+        float* sb = c->buf<float>("im_sb", n, &err);
+        unsigned char* flag = c->buf<unsigned char>("im_flag", n, &err);
+        char* tmp = c->buf<char>("im_tmp", tb + 16, &err);
+        RA_CHECK(!err, "ra_map_to_image: out of device memory");
+        const float* vals = a;
+        if (p->type == RA_IMG_RESIDUAL) { launch_diff(a, b, n, sa, s); vals = sa; sa = c->buf<float>("im_sc", n, &err); RA_CHECK(!err, "ra_map_to_image: out of device memory"); }
+        RA_CHECK(launch_percentiles(vals, n, p->type == RA_IMG_DEPTH ? acc : nullptr, k, sa, sb, flag, icnt(c, CNT_SAMP), tmp, tb, stats, s) == 0,
+                 "ra_map_to_image: device sort failed");
+    }
+    RA_CHECK(!err, "ra_map_to_image: out of device memory");
+    ImageJob j{};
+    j.type = p->type; j.P = P; j.a = a; j.b = b; j.acc = acc; j.pix = pix; j.stats = stats;
+    for (int k = 0; k < 9; ++k) j.cam_R[k] = p->cam_R[k];
+    for (int k = 0; k < 6; ++k) j.tbounds[k] = p->tbounds[k];
+    j.min_clip = p->min_clip; j.bg = p->bg_brightness; j.normalize = p->normalize; j.tonemap = p->tonemap;
+    j.image = image; j.alpha = alpha;
+    launch_compose_image(j, (long long)p->H * p->W, s);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
 static void inv3x3(const double* m, double* o) {
     const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);

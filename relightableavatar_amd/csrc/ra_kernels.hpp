@@ -190,3 +190,20 @@ void launch_lbs_verts(const float* tverts, const float* weights, const float* A,
 void launch_vert_normals(const float* verts, const int* faces, const int* adj_start, const int* adj, int n_verts, float* normals, hipStream_t s);
 void launch_bounds(const float* pts, int n, float padding, float* bounds6, hipStream_t s);
 
+
+// N4: map -> image normalisations (ra_image.hip)
+struct ImageJob {
+    int type, P;
+    const float *a, *b, *acc;             // main map (P x 3 or P), second map (Residual: bpts), acc (P, nullable -> 1)
+    const long long* pix;                 // pixel of every ray (nullable -> identity: full-frame maps)
+    const float* stats;                   // device: [k-th smallest, k-th largest] where the type needs a percentile
+    float cam_R[9], tbounds[6];
+    float min_clip, bg;
+    int normalize, tonemap;
+    float *image, *alpha;                 // H*W x 3, H*W (nullable)
+};
+size_t image_sort_temp_bytes(long long n);
+int launch_percentiles(const float* vals, long long n, const float* acc_flags, int k, float* scratch_a, float* scratch_b, unsigned char* flag,
+                       int* count_dev, void* temp, size_t temp_bytes, float* stats, hipStream_t s);
+void launch_diff(const float* a, const float* b, long long n, float* o, hipStream_t s);
+void launch_compose_image(const ImageJob& j, long long n_pixels, hipStream_t s);

@@ -218,6 +218,7 @@ def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise
     b.A, b.big_A = f(A), f(big_A)
     b.pverts, b.pnorm, b.tverts, b.tnorm = f(pverts), f(pnorm), f(tverts), f(tnorm)
     b.wbounds = f(wbounds)
+    b.tbounds = f(np.stack([tverts.min(0) - margin, tverts.max(0) + margin]))      # big-pose box (visualiser's Surface type)
     b.train_motion = dotdict(poses=f(train_poses))
     return b
 

@@ -135,7 +135,7 @@ def npz(path, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground', 'envmap', 'lbs',
-                                                   'relight_smooth', 'novel_ground', 'anisdf128', 'fields', 'fixmat'])
+                                                   'relight_smooth', 'novel_ground', 'anisdf128', 'fields', 'fixmat', 'visual'])
     args = ap.parse_args()
     mode = args.mode
     from relightableavatar_amd import synthetic
@@ -149,6 +149,9 @@ def main():
         return
     if mode == 'lbs':
         gen_lbs(synthetic)
+        return
+    if mode == 'visual':
+        gen_visual(cfg, synthetic)
         return
     set_cfg(cfg, mode)
     torch.manual_seed(0)
@@ -295,6 +298,42 @@ def gen_fixmat(net, cfg, synthetic):
     v = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1)
     out = net(xw[None], v[None], 0.005, batch)
     npz('fixmat.npz', x=xw, v=v, raw=out.raw[0].detach(), fix_material=cfg.fix_material)
+
+
+def gen_visual(cfg, synthetic):
+    """N4, third item: Visualizer.generate_image (lib/visualizers/base_visualizer.py:54-231) for every output type of the hot
+    path, fed with the maps of the reference's own relit frame (frame_relight_smooth.npz) — the images are pure functions of
+    those maps, so the fixture only stores the images."""
+    from lib.utils.base_utils import dotdict
+    from lib.config.config import Output
+    from lib.utils import relight_utils
+    from lib.visualizers.base_visualizer import Visualizer
+    ref = dict(np.load(os.path.join(HERE, 'frame_relight_smooth.npz')))
+    H, crop = int(ref['H']), int(ref['crop'])
+    b = synthetic.make_batch(H, H, seed=0, posed=True, crop=crop, skin_noise=float(ref['skin_noise']))
+    batch = to_ref_batch(b)
+    from relightableavatar_amd.config import make_cfg
+    sd = synthetic.make_state_dict(0, relight=True, cfg=make_cfg('relight'))
+    probe = torch.nn.functional.softplus(sd['global_env_map_'].expand(-1, -1, 3))[None]
+    out = dotdict({k: torch.from_numpy(v) for k, v in ref.items() if k.endswith('_map')})
+    out.envmap = dotdict(probe=probe)
+    cfg.env_h, cfg.env_w = 16, 32
+    _glx = relight_utils.gen_light_xyz           # its device argument defaults to 'cuda'
+    relight_utils.gen_light_xyz = lambda h, w, r=1e2, device='cpu': _glx(h, w, r, device='cpu')
+    kw = {}
+    for t in (Output.Surface, Output.Residual, Output.Depth, Output.Alpha, Output.Normal, Output.Specular, Output.Albedo, Output.Roughness,
+              Output.Shading, Output.Rendering):
+        kw[f'img_{t.name}'] = Visualizer.generate_image(dotdict(out), batch, t)
+    cfg.normalize_shading, cfg.store_alpha_channel, cfg.probe_size_ratio, cfg.tonemapping_albedo = True, False, 0.0, False
+    for t in (Output.Shading, Output.Albedo, Output.Rendering):
+        kw[f'alt_{t.name}'] = Visualizer.generate_image(dotdict(out), batch, t)
+    kw['img_Envmap'] = Visualizer.generate_image(dotdict(out), batch, Output.Envmap)
+    # the frame's camera has a d_x = 0 pixel column, whose depth is 0/0 (quirk 4) and makes the percentile NaN: a second Depth
+    # image from the same map with the non-finite entries replaced by 1.7 exercises the stretch itself
+    o2 = dotdict(out)
+    o2.depth_map = torch.where(torch.isfinite(out.depth_map), out.depth_map, torch.full_like(out.depth_map, 1.7))
+    kw['alt_Depth_finite'] = Visualizer.generate_image(o2, batch, Output.Depth)
+    npz('visual.npz', **kw)
 
 
 def gen_rays(synthetic):

@@ -102,7 +102,7 @@ def test_mlp_stage_production_kernel(ops, relight):
     sdf = net.inference_observed_distance_field(ops['mlp_bpts'][None].to(dev), body)
     assert sdf.shape == (1, ops['mlp_bpts'].shape[0], 1)
     e = err(sdf[0], ops['mlp_sdf'])
-    assert float(e.max()) < 3e-4 and float(e.mean()) < 8e-5
+    assert float(e.max()) < 6e-4 and float(e.mean()) < 8e-5      # the f16 operand-rounding emulation itself: max 3.4e-4, rms 8e-5
 
 
 def test_mlp_stage_matches_the_operand_rounding_emulation(relight):
@@ -123,7 +123,7 @@ def test_mlp_stage_matches_the_operand_rounding_emulation(relight):
     floor, gap, total = rms(emu, f32), rms(hip, emu), rms(hip, f32)
     print(f'sdf rms: emulation-vs-fp32 {floor:.2e}, HIP-vs-emulation {gap:.2e}, HIP-vs-fp32 {total:.2e}')
     assert total < 1.25 * floor, (total, floor)          # HIP is as close to fp32 as the emulation is
-    assert gap < 0.75 * floor, (gap, floor)              # and what separates HIP from the emulation is smaller than the rounding itself
+    assert gap < 0.6 * floor, (gap, floor)               # and what separates HIP from the emulation is smaller than the rounding itself
 
 
 def test_mlp_stage_bf16(ops):
@@ -769,11 +769,11 @@ def test_sharded_multi_chunk_frame_equals_the_whole_frame():
     box depend on its chunk; shards carry the frame's chunk boundaries (render_chunks), so merged shards == the whole frame"""
     from relightableavatar_amd import shard
     from relightableavatar_amd.renderer import make_renderer
-    cfg, net, dev = build('relight', render_chunk_size=2000)
+    cfg, net, dev = build('relight', render_chunk_size=700)
     rend = make_renderer(cfg, net)
     base = synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True), dev)
     P = base.ray_o.shape[1]
-    assert P > 3 * 2000
+    assert P > 3 * 700
     wb0 = base.wbounds.clone()
     whole = rend.render(base).rgb_map.clone()
     grown = base.wbounds.clone()
@@ -785,3 +785,43 @@ def test_sharded_multi_chunk_frame_equals_the_whole_frame():
             merged[shard.shard_indices(P, r, world, base, merged.device)] = rend.render(sb).rgb_map[0]
             assert torch.equal(sb.wbounds, grown)                                   # every shard grew the box as often as the frame did
         assert torch.equal(merged, whole[0]), world
+
+
+def test_visualiser_normalisations(golden, relight):
+    """N4, third item: Visualizer.generate_image through ra_map_to_image / ra_add_light_probe vs the reference's
+    own images (visual.npz) for every output type of the hot path, from the reference frame's maps (so no MLP noise enters)"""
+    from relightableavatar_amd import config
+    from relightableavatar_amd.base_utils import dotdict
+    from relightableavatar_amd.visualizers import Output, Visualizer
+    cfg, net, dev, body, eng = relight
+    g = golden('visual.npz')
+    ref = golden('frame_relight_smooth.npz')
+    H = int(ref['H'])
+    batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']), skin_noise=float(ref['skin_noise'])), dev)
+    out = dotdict({k: T(v).to(dev) for k, v in ref.items() if k.endswith('_map')})
+    out.envmap = dotdict(probe=net.global_env_map[None])
+    config.set_active_cfg(cfg)
+    Visualizer.engine = eng
+    for t in (Output.Surface, Output.Residual, Output.Depth, Output.Alpha, Output.Normal, Output.Specular, Output.Albedo, Output.Roughness,
+              Output.Shading, Output.Rendering):
+        img = T(Visualizer.generate_image(out, batch, t))
+        r = T(g[f'img_{t.name}'])
+        assert img.shape == r.shape == (H, H, 4), t
+        assert bool((img.isnan() == r.isnan()).all()), t
+        assert float((img - r).nan_to_num(0.0).abs().max()) < 5e-5, (t, float((img - r).nan_to_num(0.0).abs().max()))
+    alt = make_cfg('relight', normalize_shading=True, store_alpha_channel=False, probe_size_ratio=0.0, tonemapping_albedo=False)
+    config.set_active_cfg(alt)
+    for t in (Output.Shading, Output.Albedo, Output.Rendering):
+        img = T(Visualizer.generate_image(out, batch, t))
+        assert img.shape == (H, H, 3) and float((img - T(g[f'alt_{t.name}'])).abs().max()) < 5e-5, t
+    o2 = dotdict(out)
+    o2.depth_map = torch.where(torch.isfinite(out.depth_map), out.depth_map, torch.full_like(out.depth_map, 1.7))
+    img = T(Visualizer.generate_image(o2, batch, Output.Depth))
+    assert bool(torch.isfinite(img).all()) and float((img - T(g['alt_Depth_finite'])).abs().max()) < 5e-5
+    assert np.array_equal(Visualizer.generate_image(out, batch, Output.Envmap), g['img_Envmap'])
+    config.set_active_cfg(cfg)
+    # full-frame maps (what the ground pass returns): no scatter, identity pixel order
+    full = dotdict(rgb_map=torch.rand(1, H * H, 3, device=dev), acc_map=torch.rand(1, H * H, device=dev))
+    img = T(Visualizer.generate_image(full, batch, Output.Rendering))
+    assert torch.equal(img[..., :3].reshape(-1, 3)[H * 30:], full.rgb_map[0].cpu()[H * 30:])          # below the probe inset
+    assert torch.equal(img[..., 3].reshape(-1), full.acc_map[0].cpu())

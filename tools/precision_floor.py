@@ -10,7 +10,7 @@ tests hold the HIP path to these floors (tests/test_gpu_parity.py) and tests/tes
     python tools/precision_floor.py            # rewrites tests/golden/precision_floor.json (about 4 minutes on 8 cores)
 
 Findings recorded in DESIGN.md section 2: on the SURVEY 8d body (per-vertex noise in the skinning logits) the world -> big-pose
-warp jumps by ~1 cm wherever the nearest vertices change, the reference's own 16-iteration sphere trace ends in a limit cycle on ~9 % of the hit
+warp jumps by ~1 cm wherever the nearest vertices change, the reference's own 16-iteration sphere trace ends in a limit cycle on
 ~9 % of the hit rays, and a 1e-4 distance perturbation flips the phase of that cycle on ~1 % of the pixels (4 mm surface jumps, 0.05 rgb):
 the rgb PSNR of ANY 16-bit path is set by those one or two pixels.  With a spatially smooth skinning field (skin_noise = 0, a
 real SMPL body's situation) the trace converges and f16 operands reproduce the reference to > 60 dB.
@@ -50,9 +50,27 @@ def frame_floor(fname, skin_noise, emu):
     return {k: stats(out[k][0], torch.from_numpy(ref[k])[0]) for k in ('rgb_map', 'shade_map', 'norm_map', 'surf_map')}
 
 
+def novel_ground_floor(emu):
+    """the README command's frame (vis_novel_light + vis_ground_shading): main and the probes, blended layers"""
+    ref = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'frame_novel_ground.npz')))
+    kw = dict(vis_ground_shading=True, ground_normal=[float(v) for v in ref['ground_normal']], ground_origin=[float(v) for v in ref['ground_origin']],
+              render_chunk_size=int(ref['render_chunk_size']))
+    cfg = make_cfg('novel_light', **kw)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg, emulate=emu, kernel_like=True)
+    H = int(ref['H'])
+    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']), n_novel_lights=2, skin_noise=float(ref['skin_noise']))
+    m = batch.mask_at_box.reshape(1, -1)
+    inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]
+    out = O.render_novel_light(net, batch, ground_inds=inds)
+    return {f'{n}.rgb_map': stats(out[n].rgb_map[0], torch.from_numpy(ref[f'{n}.rgb_map'])[0]) for n in ('main', 'probe00', 'probe01')}
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     res = {'_about': 'emulated 16-bit-operand oracle vs the reference fp32 goldens; written by tools/precision_floor.py'}
+    for emu in ('f16', 'bf16'):
+        res[f'frame_novel_ground.npz:{emu}'] = novel_ground_floor(emu)
+        print('frame_novel_ground.npz', emu, json.dumps(res[f'frame_novel_ground.npz:{emu}']['main.rgb_map']), flush=True)
     for fname, sn in FRAMES.items():
         for emu in ('f16', 'bf16'):
             t0 = time.time()
