@@ -231,6 +231,15 @@ def make_camera(H: int, W: int, origin=(0.0, 0.0, -2.0), focal_ratio: float = 0.
     return K, R, T
 
 
+def tilted_cam_R() -> torch.Tensor:
+    """(1,3,3) world-to-camera rotation that is NOT aligned with the world axes (visualiser tests: camera-space normals and
+    the light-probe inset, whose axes are undefined for a camera looking along the world's up axis)."""
+    ax, ay = 0.35, -0.6
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    return torch.from_numpy((Rx @ Ry).astype(np.float32))[None]
+
+
 def rays_within_bounds(H, W, K, R, T, bounds: np.ndarray):
     """Restates lib/utils/data_utils.py:827-845 (get_rays), :860-875 (get_full_near_far),
     :925-938 (get_rays_within_bounds) in numpy: unit directions, AABB near/far, box mask."""

@@ -17,7 +17,7 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
         neighbouring query points, the REFERENCE's trace ends in a limit cycle on ~9 % of the hit rays, and a 1e-4 distance perturbation flips the
         cycle's phase on ~1 % of the pixels) no 16-bit-operand arithmetic reaches it: tests/golden/precision_floor.json holds
         the result of the operand-rounding emulation of the oracle (tools/precision_floor.py, SURVEY.md:305's experiment) on
-        the same frames — 48.2 dB f16 / 41.5 dB bf16 — and the HIP path is held to that floor (- 3 dB: which of the chaotic
+        the same frames — 50.6 dB / max 4.7e-2 with f16, 40.2 dB with bf16 — and the HIP path is held to that floor (- 3 dB: which of the chaotic
         pixels flip differs between two equally precise computations) and to >= 55 dB on the 98 % best pixels.
   stage bisect ....................... test_mlp_stage_matches_the_operand_rounding_emulation: HIP sdf vs the kernel-like
         emulation is several times closer than the emulation is to fp32, i.e. the in-kernel loss IS the operand rounding
@@ -673,7 +673,9 @@ def test_frame_novel_ground(golden):
         assert o.rgb_map.shape == (1, H * H, 3)
         p, mx = psnr(o.rgb_map, sub['rgb_map']), float(err(o.rgb_map, sub['rgb_map']).max())
         print(f'frame_novel_ground {name}: rgb PSNR {p:.1f} dB, max {mx:.2e}')
-        assert p >= 50.0 and mx <= 1e-2
+        # 100 human pixels at 1.7 cm per pixel: one interior pixel whose brightest light grazes the body sits at 1.1e-2 in `main`
+        # (a single light's visibility changing by 0.2 moves the tone-mapped value that far); everything else is below 3e-3
+        assert p >= 60.0 and mx <= 2e-2 and int((err(o.rgb_map, sub['rgb_map']) > 1e-2).sum()) <= 3
         assert psnr(o.shade_map, sub['shade_map']) >= 50.0 and float(err(o.spec_map, sub['spec_map']).max()) < 5e-3
         assert float(err(o.albedo_map, sub['albedo_map']).max()) < 2e-3 and float(err(o.acc_map, sub['acc_map']).max()) < 2e-2
     assert float((out.probe00.rgb_map - out.probe01.rgb_map).abs().max()) > 0.05
@@ -798,6 +800,7 @@ def test_visualiser_normalisations(golden, relight):
     ref = golden('frame_relight_smooth.npz')
     H = int(ref['H'])
     batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']), skin_noise=float(ref['skin_noise'])), dev)
+    batch.cam_R = synthetic.tilted_cam_R().to(dev)
     out = dotdict({k: T(v).to(dev) for k, v in ref.items() if k.endswith('_map')})
     out.envmap = dotdict(probe=net.global_env_map[None])
     config.set_active_cfg(cfg)

@@ -49,7 +49,7 @@ def test_committed_floor_is_reproducible(golden):
     assert abs(p - f['psnr']) < 1.0, (p, f)                       # thread-count dependent summation order moves it a little
     assert f['psnr'] >= 60 and f['max_abs'] <= 1e-2               # f16 operands meet the contract where the trace converges
     g = floors['frame_relight.npz:f16']['rgb_map']
-    assert g['psnr'] < 50 <= g['psnr_trim2pct']                   # ... and cannot on the SURVEY 8d body: 2 % of the pixels decide
+    assert g['max_abs'] > 1e-2 and g['psnr_trim2pct'] > g['psnr'] + 10     # ... and cannot on the SURVEY 8d body: 2 % of the pixels decide
     assert floors['frame_relight.npz:bf16']['rgb_map']['psnr'] < g['psnr'] - 4
 
 
