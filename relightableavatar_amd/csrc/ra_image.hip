@@ -25,9 +25,15 @@ __global__ void diff_kernel(const float* __restrict__ a, const float* __restrict
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i < n) o[i] = a[i] - b[i];
 }
-__global__ void pad_tail_kernel(float* __restrict__ p, const int* __restrict__ cnt, int n) {       // unselected tail sorts last
+// torch.topk ranks every NaN above +inf whatever its sign bit (x86 produces 0/0 = -nan, the GPU +nan); the radix sort orders
+// bit patterns, so NaNs are made the canonical positive quiet NaN first, and the unselected tail gets the largest pattern of all
+__global__ void canon_nan_kernel(const float* __restrict__ v, long long n, float* __restrict__ o) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) { const float x = v[i]; o[i] = x != x ? __uint_as_float(0x7FC00000u) : x; }
+}
+__global__ void pad_tail_kernel(float* __restrict__ p, const int* __restrict__ cnt, int n) {
     const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i < n && i >= *cnt) p[i] = __builtin_inff();
+    if (i < n && i >= *cnt) p[i] = __uint_as_float(0x7FFFFFFFu);
 }
 // "a simple version of percentile" (:108-109): lo = the k-th smallest, hi = the k-th largest of the n sorted values
 __global__ void pick_kernel(const float* __restrict__ sorted, const int* __restrict__ n_dev, int n_host, int k, float* __restrict__ stats) {
@@ -54,7 +60,8 @@ __global__ void compose_kernel(ImageJob j) {
         break;
     case RA_IMG_DEPTH: {                                                         // :98-114
         const float lo = fminf(j.stats[0], j.min_clip), hi = j.stats[1];
-        const float v = fminf(fmaxf((a[i] - lo) / (hi - lo), 0.f), 1.f);
+        float v = (a[i] - lo) / (hi - lo);
+        v = v != v ? v : fminf(fmaxf(v, 0.f), 1.f);                              // torch.clip keeps NaN (the d_x = 0 rays of quirk 4)
         rgb[0] = rgb[1] = rgb[2] = v;
         break;
     }
@@ -107,19 +114,21 @@ size_t image_sort_temp_bytes(long long n) {
 // stats[0], stats[1] <- k-th smallest / k-th largest of vals[0..n) (flag != nullptr: only where flag is set)
 int launch_percentiles(const float* vals, long long n, const float* acc_flags, int k, float* scratch_a, float* scratch_b, unsigned char* flag,
                        int* count_dev, void* temp, size_t temp_bytes, float* stats, hipStream_t s) {
-    const float* keys = vals;
     const int* n_dev = nullptr;
+    hipLaunchKernelGGL(canon_nan_kernel, grid_for(n), dim3(TPB), 0, s, vals, n, scratch_b);
+    const float* keys = scratch_b;
     if (acc_flags) {
         hipLaunchKernelGGL(flags_kernel, grid_for(n), dim3(TPB), 0, s, acc_flags, (int)n, flag);
-        if (hipcub::DeviceSelect::Flagged(temp, temp_bytes, vals, flag, scratch_a, count_dev, (int)n, s) != hipSuccess) return 1;
+        if (hipcub::DeviceSelect::Flagged(temp, temp_bytes, scratch_b, flag, scratch_a, count_dev, (int)n, s) != hipSuccess) return 1;
         // the radix sort takes a host-side count: all n slots are sorted, the tail beyond the selected count padded with +inf
         // (no read-back of the count); pick_kernel indexes with the device count
         hipLaunchKernelGGL(pad_tail_kernel, grid_for(n), dim3(TPB), 0, s, scratch_a, count_dev, (int)n);
         keys = scratch_a;
         n_dev = count_dev;
     }
-    if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, scratch_b, (int)n, 0, 32, s) != hipSuccess) return 1;
-    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(1), 0, s, scratch_b, n_dev, (int)n, k, stats);
+    float* sorted = keys == scratch_b ? scratch_a : scratch_b;
+    if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, (int)n, 0, 32, s) != hipSuccess) return 1;
+    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(1), 0, s, sorted, n_dev, (int)n, k, stats);
     return 0;
 }
 
