@@ -57,7 +57,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    DevBuf* bufs[] = {&c->warena, &c->sarena, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
+    DevBuf* bufs[] = {&c->warena, &c->sarena, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
                       &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs,
                       &c->adj_start, &c->adj_list, &c->adj_dfaces};
@@ -98,6 +98,9 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
     HostNets& H = c->host;
     if (upload(c->warena, H.warena.data(), H.warena.size() * 2, s)) return 1;
     if (upload(c->sarena, H.sarena.data(), H.sarena.size() * 2, s)) return 1;
+    if (upload(c->fwd_arena, H.fwd_arena.data(), H.fwd_arena.size() * 2, s)) return 1;
+    if (upload(c->bwd_arena, H.bwd_arena.data(), H.bwd_arena.size() * 2, s)) return 1;
+    if (upload(c->shead_row, H.shead_row.data(), H.shead_row.size() * 4, s)) return 1;
     if (upload(c->barena, H.barena.data(), H.barena.size() * 4, s)) return 1;
     if (upload(c->cond_r0, H.cond_r0.data(), H.cond_r0.size() * 4, s)) return 1;
     if (upload(c->cond_r4, H.cond_r4.data(), H.cond_r4.size() * 4, s)) return 1;
@@ -212,6 +215,23 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     return 0;
 }
 
+// the full query on the compacted fine list: second generation (forward with tape + reverse-mode backward + heads) for f16,
+// the forward-mode first generation for bf16 or RA_K4_GEN=1 (A/B)
+int full_query(ra_ctx* c, const FullIO& io, int n, hipStream_t s) {
+    static const int gen = getenv("RA_K4_GEN") ? atoi(getenv("RA_K4_GEN")) : 2;
+    Timer t(c, s, 1);
+    if (gen == 2 && c->cfg.mlp_f16) {
+        int err = 0;
+        char* tape = c->buf<char>("k4_tape", mlp_full_rev_tape_bytes(n), &err);
+        if (err) return 1;
+        launch_mlp_fwd_tape(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, n, s);
+        launch_mlp_bwd_heads(c->host.mat, c->host.col, c->bwd_arena.p, c->host.bwd_frags, c->barena.as<float>(), c->shead_row.as<float>(), c->fr, io, tape, n, s);
+    } else {
+        launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+    }
+    return 0;
+}
+
 // Network.forward (eval) on n (or *n_dev) points: raw[n][C], zero for non-fine points
 int forward_pass(ra_ctx* c, const float* x, const float* v, int n, const int* n_dev, float th, float* raw, hipStream_t s) {
     if (n <= 0) return 0;
@@ -236,10 +256,7 @@ int forward_pass(ra_ctx* c, const float* x, const float* v, int n, const int* n_
     io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
     io.relight = c->cfg.relight;
     io.counters = dcnt(c);
-    {
-        Timer t(c, s, 1);
-        launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
-    }
+    if (full_query(c, io, n, s)) return 1;
     return 0;
 }
 
@@ -1042,7 +1059,10 @@ int ra_debug_full(ra_ctx* c, const float* bpts, int n, float* grad, float* sdf, 
     io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
     io.relight = c->cfg.relight;
     io.dbg_grad = grad; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
-    launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+    if (getenv("RA_DBG_GC")) { io.dbg_gc = grad; io.dbg_grad = nullptr; }       // debugging aid: d sdf / d cpts instead
+    io.dbg_layer = getenv("RA_DBG_LAYER") ? atoi(getenv("RA_DBG_LAYER")) : -1;
+    if (getenv("RA_DBG_PE")) { io.dbg_pe = feat; io.dbg_feat = nullptr; RA_HIP(hipMemsetAsync(feat, 0, (size_t)n * 256 * 4, s)); }   // encoding-slot gradients in feat[:, :128]
+    if (full_query(c, io, n, s)) return 1;
     RA_HIP(hipGetLastError());
     return 0;
 }

@@ -111,6 +111,9 @@ struct FullIO {             // geometry + material / colour forward with tangent
     float* dbg_grad;        // n_slots x 3  d sdf / d bpts
     float* dbg_feat;        // n_slots x 256
     float* dbg_sdf;         // n_slots
+    float* dbg_gc;          // n_slots x 3  d sdf / d cpts (second-generation kernel only)
+    float* dbg_pe;          // n_slots x 128 gradients wrt the encoding slots [sdf h0 | sdf h1 | resd h0 | resd h1] (debugging aid, pre-zeroed)
+    int dbg_layer;          // debugging aid: which delta (B fragments) of the backward pass goes to dbg_pe (n_slots x 256), -1 = encoding slots
     DevCounters* counters;  // nullable
 };
 
@@ -125,6 +128,13 @@ void launch_mlp_sdf_stream(const GeoNet& net, const void* sarena, const float* b
                            const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
 void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const void* warena,
                      const float* barena, const FrameState& fr, const FullIO& io, int max_slots, bool f16w, hipStream_t stream);
+
+// second-generation K4 (ra_mlp_grad.hip): forward with tape + reverse-mode backward + heads, f16 only
+size_t mlp_full_rev_tape_bytes(int max_slots);
+void launch_mlp_fwd_tape(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape,
+                         int max_slots, hipStream_t stream);
+void launch_mlp_bwd_heads(const MatNet& mat, const ColNet& col, const void* bwd_arena, int bwd_frags, const float* barena, const float* shead_row,
+                          const FrameState& fr, const FullIO& io, const char* tape, int max_slots, hipStream_t stream);
 
 // --- error plumbing ---------------------------------------------------------------------------
 void ra_set_error(const std::string& msg);

@@ -10,6 +10,10 @@ struct HostNets {
     float beta = 0.1f;
     std::vector<uint16_t> warena;
     std::vector<uint16_t> sarena;      // gen-3 K3 weight stream (consumption order, 1952 fragments of 1 KB)
+    std::vector<uint16_t> fwd_arena;   // K4 forward stream: sarena + the 256 feature rows (2080 fragments)
+    std::vector<uint16_t> bwd_arena;   // K4 backward stream: transposed geometry layers, then the material / colour head
+    int bwd_geo_frags = 0, bwd_frags = 0;
+    std::vector<float> shead_row;      // lin8 row 0 (sdf) in fp32: seed of the backward pass
     std::vector<float> barena;
     std::vector<float> cond_r0, b_r0, cond_r4, b_r4, cond_c3, b_c3;   // fp32 cond slices [256][cond]
     std::vector<float> light_xyz, light_area, light_sharp;
@@ -30,7 +34,7 @@ struct ra_ctx {
     std::map<std::string, std::vector<float>> state_dict;
     HostNets host;
     // device copies
-    DevBuf warena, sarena, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
+    DevBuf warena, sarena, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
     int n_lights = 0;
     // frame
     FrameState fr{};

@@ -6,6 +6,7 @@
 #include "ra_ctx.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -112,6 +113,39 @@ int pe_chan_sdf(int q, int h) {
     return -1;
 }
 
+// the 32 + 32 input slots of the colour net's first layer that are not features: PE4 of the big-pose view direction
+// (27 channels: x | per frequency sin xyz, cos xyz) and the world normal (3): slot q < 12 -> frequency q/3, axis q%3, sin (h=0) / cos (h=1);
+// q = 12..14 -> view direction (h=0) / normal (h=1)
+int pe_chan_col(int q, int h) {
+    if (q < 12) return 3 + 6 * (q / 3) + 3 * h + q % 3;
+    if (q < 15) return h ? 27 + (q - 12) : (q - 12);
+    return -1;
+}
+// the 3 seeds of the residual head's transposed layer live in slots 0..2 of lane half 0
+int chan_head3(int q, int h) { return (h == 0 && q < 3) ? q : -1; }
+
+Mat transpose(const Mat& M, int rows_pad = 0) {
+    Mat o(M.cols > rows_pad ? M.cols : rows_pad, M.rows);
+    for (int r = 0; r < M.rows; ++r)
+        for (int c = 0; c < M.cols; ++c) o.at(c, r) = M.at(r, c);
+    return o;
+}
+
+// rows of a transposed encoding block in D-fragment order: row 32*blk + 8q + 4h + i <-> encoding slot s = 16*blk + 4q + i of
+// lane half h <-> channel chan(s, h); channels >= n_real (the duplicated "lo" columns) and empty slots give zero rows.
+// W: forward matrix [out][channels]; result [64][out]
+template <typename ChanFn>
+Mat transpose_pe(const Mat& W, ChanFn chan, int n_real) {
+    Mat o(64, W.rows);
+    for (int r = 0; r < 64; ++r) {
+        const int blk = r / 32, rr = r % 32, q = rr / 8, h = (rr % 8) / 4, i = rr % 4;
+        const int c = chan(16 * blk + 4 * q + i, h);
+        if (c < 0 || c >= n_real || c >= W.cols) continue;
+        for (int j = 0; j < W.rows; ++j) o.at(r, j) = W.at(j, c);
+    }
+    return o;
+}
+
 Mat slice_cols(const Mat& M, int c0, int c1) {
     Mat o(M.rows, c1 - c0);
     for (int r = 0; r < M.rows; ++r)
@@ -169,7 +203,8 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
     Packer P;
     P.half = c.mlp_f16 != 0;
     HostNets& H = ctx->host;
-    Mat Rm[8], Rpe4, Rhead, Sm[8], Spe4, Shead;     // kept for the gen-3 weight stream
+    Mat Rm[8], Rpe4, Rhead, Sm[8], Spe4, Shead, Sfeat;     // kept for the weight streams
+    Mat C0a, C0b, C1, C2, C3, Chead, M0, M1, Mhead;
     // ---- residual deformation
     const std::string rp = "residual_deformation_network.mlp.linears.";
     const int in_ch = xyz_dim + cond;
@@ -232,6 +267,7 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
             H.geo.shead = P.add(slice_rows(W, 0, 1), std::vector<float>(b.begin(), b.begin() + 1), 32);
             H.geo.sfeat = P.add(slice_rows(W, 1, 257), std::vector<float>(b.begin() + 1, b.end()), 256);
             Shead = slice_rows(W, 0, 1);
+            Sfeat = slice_rows(W, 1, 257);
         } else {
             H.geo.s[l] = P.add(W, b, 256);
             Sm[l] = W;
@@ -251,16 +287,21 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         if (!get_wn(sd, "render_network.l0", 256, in0, W, b, err)) return 1;
         H.col.c0a = P.add(slice_cols(W, view_dim + 3, in0), b, 256);
         H.col.c0b = P.add(slice_cols(W, 0, view_dim + 3), std::vector<float>(), 256);
+        C0a = slice_cols(W, view_dim + 3, in0); C0b = slice_cols(W, 0, view_dim + 3);
         if (!get_wn(sd, "render_network.l1", 256, 256, W, b, err)) return 1;
         H.col.c1 = P.add(W, b, 256);
+        C1 = W;
         if (!get_wn(sd, "render_network.l2", 256, 256, W, b, err)) return 1;
         H.col.c2 = P.add(W, b, 256);
+        C2 = W;
         if (!get_wn(sd, "render_network.l3", 256, 256 + cond, W, b, err)) return 1;
         H.col.c3 = P.add(slice_cols(W, 0, 256), b, 256);
+        C3 = slice_cols(W, 0, 256);
         H.cond_c3 = slice_cols(W, 256, 256 + cond).v;
         H.b_c3 = b;
         if (!get_wn(sd, "render_network.l4", 3, 256, W, b, err)) return 1;
         H.col.chead = P.add(W, b, 32);
+        Chead = W;
     }
     // ---- material heads (relight)
     if (c.relight) {
@@ -287,6 +328,7 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         H.mat.m0 = P.add(m0, b0, 256);
         H.mat.m1 = P.add(m1, b1, 256);
         H.mat.mhead = P.add(mh, bh, 32);
+        M0 = m0; M1 = m1; Mhead = mh;
         if (!get(sd, "light_xyz_", H.light_xyz) || !get(sd, "light_area", H.light_area) || !get(sd, "light_sharp", H.light_sharp)) { err = "missing light_xyz_/light_area/light_sharp"; return 1; }
         if (H.light_xyz.size() != H.light_area.size() * 3 || H.light_area.size() != H.light_sharp.size() || H.light_area.size() > RA_N_LIGHTS_MAX) { err = "bad light buffer shapes"; return 1; }
     }
@@ -301,6 +343,61 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         S.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
         if (S.w.size() != (size_t)1952 * 512) { err = "internal: weight stream has " + std::to_string(S.w.size() / 512) + " fragments, expected 1952"; return 1; }
         H.sarena = S.w;
+    }
+    {   // K4 (reverse mode) streams, same fragment order / K permutation as the gen-3 stream.
+        // forward: the gen-3 stream + the 256 feature rows of lin8 (head output, no activation; unscaled weights on scaled inputs)
+        StreamBuilder F;
+        F.half = P.half;
+        F.w = H.sarena;
+        F.add(&Sfeat, nullptr, pe_chan_sdf, 256, 1.f);
+        if (F.w.size() != (size_t)2080 * 512) { err = "internal: forward stream of the full query has " + std::to_string(F.w.size() / 512) + " fragments"; return 1; }
+        H.fwd_arena = F.w;
+        // backward (unscaled weights; gradients are carried times GRAD_SCALE in the kernel): u = W_l^T delta_l, rows = input
+        // features of layer l; the encoding-fed layers end in 64 rows of encoding-channel gradients (D-fragment order)
+        StreamBuilder B;
+        B.half = P.half;
+        const float inv_sp = 1.f;
+        for (int l = 7; l >= 1; --l) {
+            Mat T = transpose(Sm[l], 256);                       // l == 4: 205 real rows, the rest zero
+            B.add(&T, nullptr, pe_chan_sdf, 256, inv_sp);
+            if (l == 4) { Mat Tp = transpose_pe(Spe4, pe_chan_sdf, sdf_dim); B.add(&Tp, nullptr, pe_chan_sdf, 64, inv_sp); }
+        }
+        { Mat Tp = transpose_pe(Sm[0], pe_chan_sdf, sdf_dim);
+          if (getenv("RA_EXP_SWAP")) { Mat Sw(64, Tp.cols); for (int r = 0; r < 64; ++r) for (int k = 0; k < Tp.cols; ++k) Sw.at(r, k) = Tp.at((r + 32) % 64, k); Tp = Sw; }
+          B.add(&Tp, nullptr, pe_chan_sdf, 64, inv_sp); }
+        {   // residual head: 3 seeds -> 256 rows, as a 4-k-step "encoding" layer
+            Mat T = transpose(Rhead, 256);                       // [256][3]
+            B.add(nullptr, &T, chan_head3, 256, 1.f);
+        }
+        for (int l = 7; l >= 1; --l) {
+            Mat T = transpose(Rm[l], 256);
+            B.add(&T, nullptr, pe_chan_resd, 256, 1.f);
+            if (l == 4) { Mat Tp = transpose_pe(Rpe4, pe_chan_resd, xyz_dim); B.add(&Tp, nullptr, pe_chan_resd, 64, 1.f); }
+        }
+        { Mat Tp = transpose_pe(Rm[0], pe_chan_resd, xyz_dim); B.add(&Tp, nullptr, pe_chan_resd, 64, 1.f); }
+        H.bwd_geo_frags = (int)(B.w.size() / 512);
+        // heads on the features: material (softplus, scaled domain: the layer fed by the unscaled features carries the factor)
+        // or colour net (ReLU; first layer = 16 feature k-steps + 4 k-steps of [PE4(view) | normal])
+        const float sp = 144.26950408889634f;
+        if (c.relight) {
+            Mat M0s = M0;
+            for (auto& x : M0s.v) x *= sp;
+            B.add(&M0s, nullptr, pe_chan_col, 256, 1.f);
+            B.add(&M1, nullptr, pe_chan_col, 256, 1.f);
+            B.add(&Mhead, nullptr, pe_chan_col, 32, 1.f);
+        } else if (H.has_color) {
+            // interleave per row block: 16 hidden k-steps (features) then 4 encoding k-steps (view / normal)
+            B.add(&C0a, &C0b, pe_chan_col, 256, 1.f);
+            B.add(&C1, nullptr, pe_chan_col, 256, 1.f);
+            B.add(&C2, nullptr, pe_chan_col, 256, 1.f);
+            B.add(&C3, nullptr, pe_chan_col, 256, 1.f);
+            B.add(&Chead, nullptr, pe_chan_col, 32, 1.f);
+        }
+        if ((B.w.size() / 512) % 16) { err = "internal: backward stream is not a whole number of stages"; return 1; }
+        H.bwd_arena = B.w;
+        H.bwd_frags = (int)(B.w.size() / 512);
+        H.shead_row.assign(256, 0.f);
+        for (int k = 0; k < 256; ++k) H.shead_row[k] = Shead.at(0, k);
     }
     H.warena = P.w;
     H.barena = P.b;

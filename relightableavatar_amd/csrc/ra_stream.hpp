@@ -1,0 +1,212 @@
+// Shared machinery of the streamed-weight MLP kernels (ra_mlp_stream.hip: K3 distance query; ra_mlp_grad.hip: K4 full
+// query in reverse mode): element traits, the LDS weight ring fed by one LDS-DMA stream per workgroup, and the row-block
+// primitive whose D fragment is, after the epilogue, the next layer's B fragment.  See ra_mlp_stream.hip for the design notes.
+#pragma once
+#include "ra_common.hpp"
+#include <type_traits>
+
+#ifndef RA_SCHED
+#define RA_SCHED 0     // 1: pin the per-MFMA-slot instruction order with sched_barrier(0) (A/B: 1 % slower)
+#endif
+#ifndef RA_ABL
+#define RA_ABL 0      // compile-time ablations for timing experiments (tools/): results are garbage when != 0
+#endif
+
+namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int ACT_RELU = 1, ACT_SOFTPLUS = 2;
+constexpr float INV_2PI = 0.15915494309189535f;
+constexpr float SP_SCALE = 144.26950408889634f;     // beta * log2(e), beta = 100 (net_utils.py:1298)
+constexpr float SP_INV = 0.0069314718055994531f;    // ln(2) / beta
+constexpr int ST_MAXW = 8;                          // waves per workgroup: 8 (tile = 256 points), or 4 / 2 for small launches
+constexpr int ST_RING = 8;                          // ring stages
+constexpr int ST_STAGE_BYTES = 16384;               // 16 fragments of 1 KB
+constexpr int ST_FRAGS = 1952;                      // fragments per tile
+constexpr int ST_STAGES = ST_FRAGS / 16;            // 122
+constexpr int ST_AHEAD = ST_RING - 2;               // stages in flight: stage st+6 refills the slot of stage st-2, whose reads
+                                                    // were all consumed by MFMAs issued before the barrier (no lgkmcnt wait needed)
+constexpr int ST_PF = 4;                            // A fragments read ahead of their MFMA
+constexpr int BIAS_ROWS = 18;                       // resd 0..7, rhead, sdf 0..7, shead
+
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <typename E> struct Tr;
+template <> struct Tr<bf16> {
+    typedef bf16x8 x8; typedef bf16x2 x2;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Tr<f16> {
+    typedef f16x8 x8; typedef f16x2 x2;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename E>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    typename Tr<E>::x2 v;
+    v[0] = (E)a; v[1] = (E)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// max(z, 0) as ONE compiler-visible instruction (v_med3_f32 z, 0, +inf): fmaxf() adds a canonicalising self-max, and an
+// inline-asm v_max hides the read of a just-written MFMA accumulator from the hazard recogniser (no wait states inserted:
+// wrong values as soon as the scheduler places it right behind the producing MFMA)
+__device__ __forceinline__ float max0(float z) { return __builtin_amdgcn_fmed3f(z, 0.f, 3.0e38f); }     // finite bound: with +inf LLVM folds it back to two v_max
+
+template <int ACT>
+__device__ __forceinline__ float act(float z) {
+    if (ACT == ACT_RELU || RA_ABL == 1) return max0(z);
+    // scaled-domain softplus: z = beta*log2(e) * pre-activation, result = beta*log2(e) * softplus
+    const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(z));
+    return max0(z) + __builtin_amdgcn_logf(1.f + e);
+}
+
+template <typename E> struct StSmem {
+    E ring[ST_RING * ST_STAGE_BYTES / 2];
+    float bias[BIAS_ROWS * 256];
+    int count;
+};
+
+// two consecutive 1 KB fragments: global (uniform base + per-lane offset) -> LDS (uniform base + lane * 16)
+// (no instruction offset: on LDS-DMA loads it would also move the LDS destination)
+__device__ __forceinline__ void glds16x2(const char* sbase, unsigned voff, unsigned voff2, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, %4, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "v"(voff2), "s"(sbase), "s"(lds_dst) : "memory", "scc");
+}
+
+// the weight stream as seen by one wave of an NW-wave workgroup (each wave moves 16 / NW fragments of every stage)
+template <typename E, int NW, int STAGES = ST_STAGES>
+struct Pipe {
+    static constexpr int FPW = 16 / NW;
+    const char* g;          // weight stream (uniform)
+    unsigned voff;          // per lane: wave * FPW * 1024 + lane * 16
+    const char* ring;       // LDS ring (generic pointer), + lane * 16
+    unsigned ring_addr;     // LDS byte address of the ring + wave * FPW * 1024 (wave-uniform)
+    unsigned slot;          // ring slot of the stage being read (wave-uniform)
+    int sstage;             // its position in the tile's stream, 0 .. ST_STAGES-1 (wave-uniform)
+    const char* rd;         // ring + slot * 16 KB + lane * 16
+    typename Tr<E>::x8 af[ST_PF];
+
+    __device__ __forceinline__ void issue(int stream_stage, unsigned ring_slot) {
+        const char* sb = g;
+        asm volatile("" : "+s"(sb));            // keeps the 244 per-stage addresses from being precomputed (and spilled)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + ring_slot * ST_STAGE_BYTES);
+        const char* src = sb + (size_t)(RA_ABL == 7 ? (stream_stage & 1) : stream_stage) * ST_STAGE_BYTES;
+        if (RA_ABL != 5 && RA_ABL != 6) {
+#pragma unroll
+            for (int j = 0; j < FPW / 2; ++j) glds16x2(src, voff + j * 2048, voff + j * 2048 + 1024, dst + j * 2048);
+        }
+    }
+    // the next stage of the stream becomes readable; the ring slot two stages back is refilled ST_AHEAD stages ahead.
+    // The stage position is run-time state (SGPRs), so the code below only depends on a fragment's position in its stage.
+    __device__ __forceinline__ void sync_stage() {
+#ifdef RA_SYNC_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // experiment: no counted wait
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1)) : "memory");
+#endif
+        if (RA_ABL != 4 && RA_ABL != 6) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = (slot + 1) & (ST_RING - 1);
+        sstage = sstage + 1 == STAGES ? 0 : sstage + 1;
+        int ahead = sstage + ST_AHEAD;
+        ahead = ahead >= STAGES ? ahead - STAGES : ahead;
+        issue(ahead, (slot + ST_AHEAD) & (ST_RING - 1));
+        rd = ring + slot * ST_STAGE_BYTES;
+    }
+    // FM: position of the fragment in its 16-fragment stage
+    template <int FM>
+    __device__ __forceinline__ void fetch() {
+        if (FM == 0) sync_stage();
+        af[FM % ST_PF] = *reinterpret_cast<const typename Tr<E>::x8*>(rd + FM * 1024);
+    }
+};
+
+template <typename E> using X8 = typename Tr<E>::x8;
+
+// accumulators of a row block start at the bias of their rows: lane (c, h), acc[4q + i] <-> row 8q + 4h + i
+__device__ __forceinline__ void init_acc(f32x16& acc, const float* bias_rb, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_rb + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = bv[i];
+    }
+}
+
+// One row block: KS MFMAs (fragments F0.. of the tile's stream) into `acc`, interleaved with the pending epilogue
+// of `accPrev` (activation ACT_PREV) into the B fragments o0, o1.  Bm: hidden-part B fragments (KS >= 16),
+// Bp: encoding B fragments (KS == 4 or the last 4 k-steps of KS == 20).
+template <typename E, int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT>
+__device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4],
+                                          u32x4& o0, u32x4& o1, const float* bias_rb, int h) {
+    init_acc(acc, bias_rb, h);
+    float ta[16], tb[16];
+    static_for<0, KS>([&](auto ks_) {
+        constexpr int ks = decltype(ks_)::value;
+        const u32x4 bw = (KS == 4) ? Bp[ks & 3] : (ks < 16 ? Bm[ks & 15] : Bp[ks & 3]);
+        acc = Tr<E>::mfma(P.af[(FM0 + ks) % ST_PF], __builtin_bit_cast(X8<E>, bw), acc);
+        if constexpr (!(TAIL && ks + ST_PF >= KS)) P.template fetch<(FM0 + ks + ST_PF) % 16>();
+        if constexpr (PENDING) {
+            // Pending row block, element by element.  The softplus chain exp2 -> +1 -> log2 -> +max is software-pipelined
+            // over four MFMA slots so that no VALU op waits on one issued in the same slot (in-order issue: a stalled
+            // transcendental chain would hold back the next MFMA).  LAST: last slot whose results may still be written.
+            static_for<0, 16>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS && RA_ABL != 1 && RA_ABL != 3 && RA_ABL != 6;
+                constexpr int DEPTH = SP ? 3 : 0;
+                constexpr int LAST = (KS == 4) ? 3 : (EARLY ? 13 : KS - 1);
+                constexpr int s0 = (KS == 4) ? 0 : (e * (LAST - DEPTH + 1)) / 16;
+                if constexpr (SP && KS != 4) {
+                    if constexpr (s0 == ks) { ta[e] = __builtin_amdgcn_exp2f(-__builtin_fabsf(accPrev[e])); tb[e] = max0(accPrev[e]); }
+                    if constexpr (s0 + 1 == ks) ta[e] = 1.f + ta[e];
+                    if constexpr (s0 + 2 == ks) ta[e] = __builtin_amdgcn_logf(ta[e]);
+                    if constexpr (s0 + 3 == ks) ta[e] = ta[e] + tb[e];
+                } else if constexpr (SP) {          // 4-MFMA row blocks (first layer): one stage of all 16 elements per slot
+                    if constexpr (ks == 0) { ta[e] = __builtin_amdgcn_exp2f(-__builtin_fabsf(accPrev[e])); tb[e] = max0(accPrev[e]); }
+                    if constexpr (ks == 1) ta[e] = 1.f + ta[e];
+                    if constexpr (ks == 2) ta[e] = __builtin_amdgcn_logf(ta[e]);
+                    if constexpr (ks == 3) ta[e] = ta[e] + tb[e];
+                } else {
+                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e] = (RA_ABL == 3 || RA_ABL == 6) ? accPrev[e] : max0(accPrev[e]);
+                }
+                constexpr int sdone = (KS == 4) ? (SP ? 3 : e / 4) : s0 + DEPTH;
+                if constexpr ((e & 1) && sdone == ks) {
+                    const unsigned w = (RA_ABL == 3 || RA_ABL == 6) ? __builtin_bit_cast(unsigned, ta[e]) : pack2<E>(ta[e - 1], ta[e]);
+                    if constexpr (e < 8) o0[e >> 1] = w; else o1[(e >> 1) & 3] = w;
+                }
+            });
+        }
+        if (RA_SCHED) __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// a 256-row layer: 8 row blocks; on entry `accB` holds the pending last row block of the previous layer (if PEND_IN,
+// activation ACT_IN, destination Bm[14], Bm[15]); on exit accB holds this layer's pending row block 7.
+template <typename E, int NW, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
+__device__ __forceinline__ void layer(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16],
+                                      const float* bias, int h) {
+    row_block<E, NW, 0, KS, ACT_IN, PEND_IN, true, false>(P, accA, accB, Bm, Bp, Bm[14], Bm[15], bias, h);
+    row_block<E, NW, (1 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], bias + 32, h);
+    row_block<E, NW, (2 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], bias + 64, h);
+    row_block<E, NW, (3 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], bias + 96, h);
+    row_block<E, NW, (4 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], bias + 128, h);
+    row_block<E, NW, (5 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], bias + 160, h);
+    row_block<E, NW, (6 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], bias + 192, h);
+    row_block<E, NW, (7 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], bias + 224, h);
+}
+
+
+}  // namespace
