@@ -230,7 +230,8 @@ def main():
         kname = {'1': 'mlp_sdf_kernel', '2': 'mlp_sdf_pipe_kernel'}.get(os.environ.get('RA_MLP_GEN', '3'), 'mlp_sdf_stream_kernel')
         units, f_unit = cnt.n_fine_sdf, F_SDF
         if args.mode == 'anisdf':           # the volume path has no distance-only queries: its dominant kernel is the full query
-            kname, units, f_unit = 'mlp_full_kernel', cnt.n_fine_full, F_FULL_ANISDF
+            # second-generation full query = two kernels per launch (forward with tape, reverse-mode backward + colour net); the timer brackets both
+            kname, units, f_unit = ('mlp_full_kernel' if os.environ.get('RA_K4_GEN') == '1' else 'mlp_fwd_tape_kernel+mlp_bwd_heads_kernel'), cnt.n_fine_full, F_FULL_ANISDF
         achieved = (units * f_unit) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel' and not args.ground
         traffic, traffic_src = hbm_traffic_per_launch(kname) if default_cmd else (None, None)

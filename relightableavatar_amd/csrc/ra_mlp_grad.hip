@@ -28,8 +28,14 @@ namespace {
 
 constexpr int FW_STAGES = 130;                         // 2080 fragments: gen-3 stream + 128 fragments of feature rows
 constexpr float GRAD_SCALE = 16.f;
-#ifndef RA_K4_NW
-#define RA_K4_NW 8            // waves per workgroup of the two kernels (8: two waves per SIMD, 256 registers each; 4: one wave, 512)
+// waves per workgroup (8: two waves per SIMD, 256 registers each; 4: one wave per SIMD, 512 registers).  The tape is indexed
+// by 32-point group (slot / 32), so the two kernels need not agree.  Forward: 4 — at 8 the tape stores and sign-bit
+// bookkeeping push it to ~90 spilled registers (6.4 ms against 5.6 ms per 2.1 M points)
+#ifndef RA_K4_NW_F
+#define RA_K4_NW_F 8
+#endif
+#ifndef RA_K4_NW_B
+#define RA_K4_NW_B 8
 #endif
 #ifndef RA_TAPE_N
 #define RA_TAPE_N (2 * FPW + 2)
@@ -42,10 +48,16 @@ constexpr int TP_BITS = 147456;                        // residual net: 8 layers
 constexpr int TP_GEO = 155648;                         // per point (lanes 0..31): cpts xyz, sdf
 constexpr int TP_WAVE = 156672;
 
+#ifdef RA_DBG_SLOTS
+constexpr bool DBGE = true;
+#else
+constexpr bool DBGE = false;      // per-encoding-slot gradient dump (tools/dbg_grad.py RA_DBG_PE): build with -DRA_DBG_SLOTS
+#endif
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SOFTPLUS = 2, EPI_LINEAR = 3, EPI_RELU_BITS = 4, EPI_GRAD_RELU = 5, EPI_GRAD_SP = 6, EPI_PEJAC = 7 };
 
 struct EpiAux {
     u32x4 t0, t1;        // EPI_GRAD_SP: taped activations y' of the pending row block (f16 pairs, D-fragment order)
+    u32x4 n0, n1;        // ... of the NEXT pending row block, taken from the tape queue just before this block's weight-stage turnover
     unsigned bits;       // EPI_RELU_BITS: shift register of sign bits; EPI_GRAD_RELU: the pending block's 16 bits in [15:0] (bit 15-e)
     float scale;         // EPI_LINEAR: factor applied before packing
     char* st;            // forward: where the next finished row block's two fragments go (per lane), nullptr = no tape
@@ -83,7 +95,7 @@ struct Epi {
             // the pending block holds the gradients of 16 encoding slots of this lane half (s = 16 PB + e): trig channels
             // contract with 2^f cos(2 pi (2^f x / 2 pi + h / 4))  (h = 0: d sin = cos, h = 1: d cos = -sin), identity channels add
             constexpr int s = 16 * PB + e, NT = 3 * L;
-            if constexpr (s0 == ks) { if (x.dbg) x.dbg[s] += a[e] * (1.f / GRAD_SCALE); }
+            if constexpr (DBGE && s0 == ks) { if (x.dbg) x.dbg[s] += a[e] * (1.f / GRAD_SCALE); }
             if constexpr (s < NT) {
                 if constexpr (s0 == ks) ta[e] = __builtin_amdgcn_cosf(x.rev[s % 3] * (float)(1 << (s / 3)) + 0.25f * (float)h);
                 if constexpr (s0 + 1 == ks) x.g[s % 3] = __builtin_fmaf(a[e] * (float)(1 << (s / 3)), ta[e], x.g[s % 3]);
@@ -113,10 +125,28 @@ struct Epi {
 
 // One row block: KS MFMAs into `acc` (bias-initialised or zero), interleaved with the pending epilogue EPI of `accPrev`
 // into the B fragments o0, o1 (or into aux.g for EPI_PEJAC).  After the block, the finished fragments go to the tape if aux.st.
-template <typename E, int FM0, int KS, int EPI, bool EARLY, bool TAIL, bool BIAS, int L, bool LO, int PB = 0, typename PipeT>
+// accumulators start at the bias of their rows; bias_l = table row + 4 * (lane half) ALREADY added and laundered through an empty
+// asm by the caller: with the lane part folded into ~150 distinct loop-invariant LDS addresses the compiler hoists them all
+// out of the tile loop and spills them (90 spilled registers in the 8-wave forward kernel)
+__device__ __forceinline__ void init_acc_l(f32x16& acc, const float* bias_l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = bv[i];
+    }
+}
+
+struct NoTape { template <int K> __device__ __forceinline__ void take(u32x4&, u32x4&) {} };
+
+// TK >= 0: the tape fragments of the NEXT pending block are taken from the queue (slot TK) in the MFMA slot right before
+// this block's stage turnover (P.fetch<0>: counted wait + barrier + the next weight DMA): the compiler's wait for those loads
+// cannot tell them from the weight DMA it does not see, so it drains the queue — cheap only where the youngest DMA is a whole
+// block old, i.e. exactly there.
+template <typename E, int FM0, int KS, int EPI, bool EARLY, bool TAIL, bool BIAS, int L, bool LO, int PB = 0, int TK = -1, typename PipeT, typename TQ = NoTape>
 __device__ __forceinline__ void rbg(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4& o0, u32x4& o1,
-                                    const float* bias_rb, int h, EpiAux& aux) {
-    if constexpr (BIAS) init_acc(acc, bias_rb, h);
+                                    const float* bias_rb, int h, EpiAux& aux, TQ* tq = nullptr) {
+    if constexpr (BIAS) init_acc_l(acc, bias_rb);
     else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -126,6 +156,10 @@ __device__ __forceinline__ void rbg(PipeT& P, f32x16& acc, const f32x16& accPrev
         constexpr int ks = decltype(ks_)::value;
         const u32x4 bw = (KS == 4) ? Bp[ks & 3] : (ks < 16 ? Bm[ks & 15] : Bp[ks & 3]);
         acc = Tr<E>::mfma(P.af[(FM0 + ks) % ST_PF], __builtin_bit_cast(X8<E>, bw), acc);
+        if constexpr (TK >= 0 && (FM0 + ks + ST_PF) % 16 == 0) {
+            tq->template take<TK>(aux.n0, aux.n1);
+            asm volatile("" : "+v"(aux.n0), "+v"(aux.n1));          // the loads are waited for HERE
+        }
         if constexpr (!(TAIL && ks + ST_PF >= KS)) P.template fetch<(FM0 + ks + ST_PF) % 16>();
         if constexpr (EPI != EPI_NONE) {
             static_for<0, 16>([&](auto e_) {
@@ -150,6 +184,9 @@ __device__ __forceinline__ void flush(const f32x16& accPrev, u32x4& o0, u32x4& o
 }
 
 __device__ __forceinline__ void tape_store2(EpiAux& aux, const u32x4& a, const u32x4& b) {
+#ifdef RA_EXP_NOTAPE
+    return;         // timing experiment: results are garbage
+#endif
     if (aux.st) {
         *reinterpret_cast<u32x4*>(aux.st) = a;
         *reinterpret_cast<u32x4*>(aux.st + 1024) = b;
@@ -242,7 +279,7 @@ __device__ __forceinline__ void pipe_init(PipeT& P, const void* stream, SM& sm, 
     for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
 }
 
-template <typename E, int NW>
+template <typename E, int NW, bool DBG>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba, FrameState fr,
                                                                     FullIO io, char* __restrict__ tape) {
     __shared__ __attribute__((aligned(16))) FwSmem<E> sm;
@@ -282,7 +319,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         f32x16 accA, accB;
         // ---- residual deformation net (ReLU, sign bits to the tape)
         pe_frags_g<E, 10, false>(Bp, x, h);
-        const float* bias = sm.bias;
+        const float* bias = sm.bias + 4 * h;
+        asm volatile("" : "+v"(bias));
         fwd_layer<E, 4, EPI_RELU_BITS, EPI_NONE, 2>(P, accA, accB, B0, Bp, B0, bias, h, aux, bits_out);
         fwd_layer<E, 16, EPI_RELU_BITS, EPI_RELU_BITS, 2>(P, accA, accB, B0, Bp, B1, bias + 256, h, aux, bits_out);
         fwd_layer<E, 16, EPI_RELU_BITS, EPI_RELU_BITS, 2>(P, accA, accB, B1, Bp, B0, bias + 512, h, aux, bits_out);
@@ -301,7 +339,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         }
         // ---- signed distance net (softplus, scaled domain, activations to the tape), head, feature rows
         aux.st = tw + TP_SDF + lane * 16;
-        bias = sm.bias + 9 * 256;
+        bias = sm.bias + 9 * 256 + 4 * h;
+        asm volatile("" : "+v"(bias));
         pe_frags_g<E, 8, true>(Bp, cp, h);
         fwd_layer<E, 4, EPI_SOFTPLUS, EPI_NONE, 1>(P, accA, accB, B0, Bp, B0, bias, h, aux, bits_out);
         fwd_layer<E, 16, EPI_SOFTPLUS, EPI_SOFTPLUS, 1>(P, accA, accB, B0, Bp, B1, bias + 256, h, aux, bits_out);
@@ -336,7 +375,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
             flush<E, EPI_LINEAR, 0, false>(accA, B0[14], B0[15], h, aux);
             tape_store2(aux, B0[14], B0[15]);
         }
-        if (io.dbg_feat && s < count) {          // test hook: features as the heads will see them (f16 values)
+        if (DBG && io.dbg_feat && s < count) {          // test hook: features as the heads will see them (f16 values)
 #pragma unroll
             for (int k = 0; k < 16; ++k)
 #pragma unroll
@@ -348,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         if (h == 0) {
             float4 gv = make_float4(cp[0], cp[1], cp[2], sdf);
             *reinterpret_cast<float4*>(tw + TP_GEO + c * 16) = gv;
-            if (io.dbg_sdf && s < count) io.dbg_sdf[s] = sdf;
+            if (DBG && io.dbg_sdf && s < count) io.dbg_sdf[s] = sdf;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -381,8 +420,8 @@ struct TapeQ {
         ++next;
     }
     template <int K01>
-    __device__ __forceinline__ void take(EpiAux& aux) {
-        aux.t0 = q[K01][0]; aux.t1 = q[K01][1];
+    __device__ __forceinline__ void take(u32x4& d0, u32x4& d1) {
+        d0 = q[K01][0]; d1 = q[K01][1];
         issue<K01>();
     }
 };
@@ -393,35 +432,37 @@ struct TapeQ {
 template <typename E, int EPI, int IN, int L, bool LO, typename PipeT, typename TQ>
 __device__ __forceinline__ void bwd_layer(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16], int h, EpiAux& aux,
                                           TQ& tq, const unsigned (&bw_in)[4], const unsigned (&bw)[4]) {
-    // bw_in: sign-bit words of the pending block's layer (EPI_GRAD_RELU, IN == 1); bw: of this layer's output features
-    auto pre = [&](auto n_, const unsigned (&words)[4]) {      // prepare aux for the pending block n (0..7) of a layer
+    // bw_in: sign-bit words of the pending block's layer (EPI_GRAD_RELU, IN == 1); bw: of this layer's output features.
+    // EPI_GRAD_SP: on entry aux.t0/t1 hold the tape of the pending block (IN == 1); every row block i takes the tape of block
+    // i of THIS layer's output (its epilogue is pending during block i + 1) — on exit aux.t0/t1 = block 7's.
+    constexpr bool SP = EPI == EPI_GRAD_SP;
+    auto bits = [&](auto n_, const unsigned (&words)[4]) {
         constexpr int n = decltype(n_)::value;
-        if constexpr (EPI == EPI_GRAD_SP) tq.template take<(n & 1)>(aux);
         if constexpr (EPI == EPI_GRAD_RELU) aux.bits = (n & 1) ? words[n >> 1] : (words[n >> 1] >> 16);
     };
+    auto adv = [&]() { if constexpr (SP) { aux.t0 = aux.n0; aux.t1 = aux.n1; } };
     u32x4 dum0, dum1;
     if constexpr (IN == 1) {
-        pre(std::integral_constant<int, 7>{}, bw_in);
-        rbg<E, 0, 16, EPI, true, false, false, L, LO>(P, accA, accB, Bm, Bp, Bm[14], Bm[15], nullptr, h, aux);
-    } else if constexpr (IN == 2) {
-        rbg<E, 0, 16, EPI_PEJAC, false, false, false, L, LO, 1>(P, accA, accB, Bm, Bp, dum0, dum1, nullptr, h, aux);
+        bits(std::integral_constant<int, 7>{}, bw_in);
+        rbg<E, 0, 16, EPI, true, false, false, L, LO, 0, SP ? 0 : -1>(P, accA, accB, Bm, Bp, Bm[14], Bm[15], nullptr, h, aux, &tq);
     } else {
-        rbg<E, 0, 16, EPI_NONE, false, false, false, L, LO>(P, accA, accB, Bm, Bp, dum0, dum1, nullptr, h, aux);
+        rbg<E, 0, 16, EPI_NONE, false, false, false, L, LO, 0, SP ? 0 : -1>(P, accA, accB, Bm, Bp, dum0, dum1, nullptr, h, aux, &tq);
     }
-    pre(std::integral_constant<int, 0>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], nullptr, h, aux);
-    pre(std::integral_constant<int, 1>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], nullptr, h, aux);
-    pre(std::integral_constant<int, 2>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], nullptr, h, aux);
-    pre(std::integral_constant<int, 3>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], nullptr, h, aux);
-    pre(std::integral_constant<int, 4>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], nullptr, h, aux);
-    pre(std::integral_constant<int, 5>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], nullptr, h, aux);
-    pre(std::integral_constant<int, 6>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], nullptr, h, aux);
+    adv(); bits(std::integral_constant<int, 0>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 1 : -1>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], nullptr, h, aux, &tq);
+    adv(); bits(std::integral_constant<int, 1>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 0 : -1>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], nullptr, h, aux, &tq);
+    adv(); bits(std::integral_constant<int, 2>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 1 : -1>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], nullptr, h, aux, &tq);
+    adv(); bits(std::integral_constant<int, 3>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 0 : -1>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], nullptr, h, aux, &tq);
+    adv(); bits(std::integral_constant<int, 4>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 1 : -1>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], nullptr, h, aux, &tq);
+    adv(); bits(std::integral_constant<int, 5>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 0 : -1>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], nullptr, h, aux, &tq);
+    adv(); bits(std::integral_constant<int, 6>{}, bw);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 1 : -1>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], nullptr, h, aux, &tq);
+    adv();
 }
 
 // the two encoding-gradient row blocks that follow a transposed layer fed by the encoding (W_pe^T delta: 64 rows):
@@ -431,8 +472,7 @@ __device__ __forceinline__ void bwd_layer(PipeT& P, f32x16& accA, f32x16& accB, 
 template <typename E, int EPI, bool EARLY, int L, bool LO, bool SWAP = false, typename PipeT, typename TQ>
 __device__ __forceinline__ void bwd_pe_blocks(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&Bin)[16], const u32x4 (&Bp)[4], u32x4& o14, u32x4& o15, int h,
                                               EpiAux& aux, TQ& tq, const unsigned (&bw)[4]) {
-    if constexpr (EPI == EPI_GRAD_SP) tq.template take<1>(aux);
-    if constexpr (EPI == EPI_GRAD_RELU) aux.bits = bw[3];
+    if constexpr (EPI == EPI_GRAD_RELU) aux.bits = bw[3];        // EPI_GRAD_SP: aux.t0/t1 already hold block 7's tape
     flush<E, EPI, L, LO>(accB, o14, o15, h, aux);              // the layer's last row block, stand-alone
     u32x4 d0, d1;
     rbg<E, 0, 16, EPI_NONE, false, false, false, L, LO>(P, accA, accB, Bin, Bp, d0, d1, nullptr, h, aux);
@@ -475,7 +515,7 @@ template <typename E> struct BwSmem {
     int count;
 };
 
-template <typename E, int NW, int STAGES, bool RELIGHT>
+template <typename E, int NW, int STAGES, bool RELIGHT, bool DBG>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, ColNet col, const void* __restrict__ stream, const float* __restrict__ ba,
                                                                      const float* __restrict__ shead_row, FrameState fr, FullIO io, const char* __restrict__ tape) {
     __shared__ __attribute__((aligned(16))) BwSmem<E> sm;
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
 
     Pipe<E, NW, STAGES> P;
     pipe_init(P, stream, sm, wave, lane, NW, STAGES);
-    const float* w8 = sm.bias + 5 * 256;
+
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int s = tile * TM + wave * 32 + c;
@@ -523,12 +563,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         f32x16 accA, accB;
         EpiAux aux;
         aux.st = nullptr; aux.bits = 0u; aux.scale = 1.f;
-        float* const dbg_base = (io.dbg_pe && io.dbg_layer < 0 && live) ? io.dbg_pe + (size_t)s * 128 + h * 32 : nullptr;      // [sdf: 2 x 32 | resd: 2 x 32]
-        aux.dbg = io.dbg_layer == -1 ? dbg_base : nullptr;
+        float* const dbg_base = (DBG && io.dbg_pe && io.dbg_layer < 0 && live) ? io.dbg_pe + (size_t)s * 128 + h * 32 : nullptr;      // [sdf: 2 x 32 | resd: 2 x 32]
+        aux.dbg = (DBG && io.dbg_layer == -1) ? dbg_base : nullptr;
         const unsigned nob[4] = {0u, 0u, 0u, 0u};
         // ---- seed of the sdf net: delta_7 = sigma'(z_7) * lin8[0, :] (times GRAD_SCALE), straight into B fragments
         {
             const char* t7 = tw + TP_SDF + (7 * 8 * 2) * 1024 + lane * 16;
+            const float* w8 = sm.bias + 5 * 256 + 4 * h;
+            asm volatile("" : "+v"(w8), "+v"(t7));
 #pragma unroll
             for (int rb = 0; rb < 8; ++rb) {
                 const u32x4 a0 = *reinterpret_cast<const u32x4*>(t7 + (rb * 2) * 1024);
@@ -537,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float y = half_of<E>(e < 8 ? a0[e >> 1] : a1[(e >> 1) & 3], e & 1);
-                    const int row = 32 * rb + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const int row = 32 * rb + 8 * (e >> 2) + (e & 3);                 // + 4 h inside w8
                     d[e] = (1.f - __builtin_amdgcn_exp2f(-y)) * (w8[row] * GRAD_SCALE);
                 }
 #pragma unroll
@@ -545,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
             }
         }
         auto dumpB = [&](const u32x4 (&Bf)[16], int which) {          // debugging aid: delta fragments as fp32, feature-major
-            if (io.dbg_pe && io.dbg_layer == which && live) {
+            if (DBG && io.dbg_pe && io.dbg_layer == which && live) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
 #pragma unroll
@@ -570,10 +612,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         bwd_layer<E, EPI_GRAD_SP, 1, 8, true>(P, accA, accB, B0, Bp, B1, h, aux, tq, nob, nob);       // lin5^T -> delta_4
         dumpB(B1, 4);
         bwd_layer<E, EPI_GRAD_SP, 1, 8, true>(P, accA, accB, B1, Bp, B0, h, aux, tq, nob, nob);       // lin4^T (205 rows) -> delta_3
-        if (io.dbg_layer == -2) aux.dbg = dbg_base;
+        if (DBG && io.dbg_layer == -2) aux.dbg = dbg_base;
         bwd_pe_blocks<E, EPI_GRAD_SP, false, 8, true>(P, accA, accB, B1, Bp, B0[14], B0[15], h, aux, tq, nob);   // lin4's encoding columns
-        if (io.dbg_layer == -2) aux.dbg = nullptr;
-        if (io.dbg_layer == -3) aux.dbg = dbg_base;
+        if (DBG && io.dbg_layer == -2) aux.dbg = nullptr;
+        if (DBG && io.dbg_layer == -3) aux.dbg = dbg_base;
         dumpB(B0, 3);
         bwd_layer<E, EPI_GRAD_SP, 0, 8, true>(P, accA, accB, B0, Bp, B1, h, aux, tq, nob, nob);       // lin3^T -> delta_2
         dumpB(B1, 2);
@@ -589,8 +631,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         float gc[3];        // GRAD_SCALE * d sdf / d cpts
 #pragma unroll
         for (int k = 0; k < 3; ++k) gc[k] = aux.g[k] + __shfl_xor(aux.g[k], 32);
-        if (io.dbg_gc && live && h == 0) { io.dbg_gc[3 * s] = gc[0] / GRAD_SCALE; io.dbg_gc[3 * s + 1] = gc[1] / GRAD_SCALE; io.dbg_gc[3 * s + 2] = gc[2] / GRAD_SCALE; }
-        if (aux.dbg) aux.dbg += 64;
+        if (DBG && io.dbg_gc && live && h == 0) { io.dbg_gc[3 * s] = gc[0] / GRAD_SCALE; io.dbg_gc[3 * s + 1] = gc[1] / GRAD_SCALE; io.dbg_gc[3 * s + 2] = gc[2] / GRAD_SCALE; }
+        if (DBG && aux.dbg) aux.dbg += 64;
         // ---- residual net backward, seeded with d resd_k / d z_k * g_k = resd_limit (1 - tanh^2 z_k) g_k
         {
             float sd[3];
@@ -654,7 +696,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         float g[3];         // d sdf / d bpts = g_c + J_resd^T g_c
 #pragma unroll
         for (int k = 0; k < 3; ++k) g[k] = (gc[k] + aux.g[k] + __shfl_xor(aux.g[k], 32)) * (1.f / GRAD_SCALE);
-        if (io.dbg_grad && live && h == 0) { io.dbg_grad[3 * s] = g[0]; io.dbg_grad[3 * s + 1] = g[1]; io.dbg_grad[3 * s + 2] = g[2]; }
+        if (DBG && io.dbg_grad && live && h == 0) { io.dbg_grad[3 * s] = g[0]; io.dbg_grad[3 * s + 1] = g[1]; io.dbg_grad[3 * s + 2] = g[2]; }
         // ---- per-point geometry outputs (both lane halves compute them: the colour net's encoding needs them in both)
         const float occ = sdf_to_occ_r(sdfv, io.beta);
         float nrm[3], bv[3] = {0.f, 0.f, 0.f};
@@ -702,10 +744,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         float o4[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned* nobits = nullptr;
         aux.st = nullptr;
+        const float* hb = sm.bias + 4 * h;
+        asm volatile("" : "+v"(hb));
         if constexpr (RELIGHT) {
-            fwd_layer<E, 16, EPI_SOFTPLUS, EPI_NONE, 0>(P, accA, accB, B0, Bp, B1, sm.bias, h, aux, nobits);
-            fwd_layer<E, 16, EPI_SOFTPLUS, EPI_SOFTPLUS, 0>(P, accA, accB, B1, Bp, B0, sm.bias + 256, h, aux, nobits);
-            rbg<E, 0, 16, EPI_SOFTPLUS, true, true, true, 0, false>(P, accA, accB, B0, Bp, B0[14], B0[15], sm.bias + 512, h, aux);
+            fwd_layer<E, 16, EPI_SOFTPLUS, EPI_NONE, 0>(P, accA, accB, B0, Bp, B1, hb, h, aux, nobits);
+            fwd_layer<E, 16, EPI_SOFTPLUS, EPI_SOFTPLUS, 0>(P, accA, accB, B1, Bp, B0, hb + 256, h, aux, nobits);
+            rbg<E, 0, 16, EPI_SOFTPLUS, true, true, true, 0, false>(P, accA, accB, B0, Bp, B0[14], B0[15], hb + 512, h, aux);
 #pragma unroll
             for (int k = 0; k < 3; ++k) o4[k] = io.albedo_slope / (1.f + expf(-accA[k] * SP_INV)) + io.albedo_bias;
             o4[3] = io.rough_slope / (1.f + expf(-accA[3] * SP_INV)) + io.rough_bias;
@@ -727,11 +771,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
 #pragma unroll
                     for (int w = 0; w < 4; ++w) Bp[ks][w] = pack2<E>(v[8 * ks + 2 * w], v[8 * ks + 2 * w + 1]);
             }
-            fwd_layer<E, 20, EPI_RELU, EPI_NONE, 0>(P, accA, accB, B0, Bp, B1, sm.bias, h, aux, nobits);
-            fwd_layer<E, 16, EPI_RELU, EPI_RELU, 0>(P, accA, accB, B1, Bp, B0, sm.bias + 256, h, aux, nobits);
-            fwd_layer<E, 16, EPI_RELU, EPI_RELU, 0>(P, accA, accB, B0, Bp, B1, sm.bias + 512, h, aux, nobits);
-            fwd_layer<E, 16, EPI_RELU, EPI_RELU, 0>(P, accA, accB, B1, Bp, B0, sm.bias + 768, h, aux, nobits);
-            rbg<E, 0, 16, EPI_RELU, true, true, true, 0, false>(P, accA, accB, B0, Bp, B0[14], B0[15], sm.bias + 1024, h, aux);
+            fwd_layer<E, 20, EPI_RELU, EPI_NONE, 0>(P, accA, accB, B0, Bp, B1, hb, h, aux, nobits);
+            fwd_layer<E, 16, EPI_RELU, EPI_RELU, 0>(P, accA, accB, B1, Bp, B0, hb + 256, h, aux, nobits);
+            fwd_layer<E, 16, EPI_RELU, EPI_RELU, 0>(P, accA, accB, B0, Bp, B1, hb + 512, h, aux, nobits);
+            fwd_layer<E, 16, EPI_RELU, EPI_RELU, 0>(P, accA, accB, B1, Bp, B0, hb + 768, h, aux, nobits);
+            rbg<E, 0, 16, EPI_RELU, true, true, true, 0, false>(P, accA, accB, B0, Bp, B0[14], B0[15], hb + 1024, h, aux);
 #pragma unroll
             for (int k = 0; k < 3; ++k) o4[k] = 1.f / (1.f + expf(-accA[k]));
         }
@@ -756,24 +800,31 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
 
 }  // namespace
 
-size_t mlp_full_rev_tape_bytes(int max_slots) { return (size_t)((max_slots + 32 * RA_K4_NW - 1) / (32 * RA_K4_NW)) * RA_K4_NW * TP_WAVE + 4096; }     // whole tiles
+size_t mlp_full_rev_tape_bytes(int max_slots) { return (size_t)((max_slots + 255) / 256) * 8 * TP_WAVE + 4096; }     // whole 256-point tiles
 
 void launch_mlp_fwd_tape(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape,
                          int max_slots, hipStream_t stream) {
     if (max_slots <= 0) return;
-    constexpr int NW = RA_K4_NW;
+    constexpr int NW = RA_K4_NW_F;
     const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
     const int grid = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL((mlp_fwd_tape_kernel<f16, NW>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
+    if (io.dbg_feat || io.dbg_sdf) hipLaunchKernelGGL((mlp_fwd_tape_kernel<f16, NW, true>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
+    else hipLaunchKernelGGL((mlp_fwd_tape_kernel<f16, NW, false>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
 }
 
 void launch_mlp_bwd_heads(const MatNet& mat, const ColNet& col, const void* bwd_arena, int bwd_frags, const float* barena, const float* shead_row,
                           const FrameState& fr, const FullIO& io, const char* tape, int max_slots, hipStream_t stream) {
     if (max_slots <= 0) return;
-    constexpr int NW = RA_K4_NW;
+    constexpr int NW = RA_K4_NW_B;
     const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
     const int grid = tiles < 256 ? tiles : 256;
-    if (io.relight) hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 139, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
-    else hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 157, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+    const bool dbg = io.dbg_grad || io.dbg_gc || io.dbg_pe;
+    if (io.relight) {
+        if (dbg) hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 139, true, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+        else hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 139, true, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+    } else {
+        if (dbg) hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 157, false, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+        else hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 157, false, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+    }
     (void)bwd_frags;
 }
