@@ -1,32 +1,57 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run from the repo root through gpurun):
-#   kernel-trace stats of the default bench command + PMC passes (each its own run, kernel-trace only) -> gpurun_out/prof/
+#   kernel-trace stats of the default bench command and of the other BASELINE shapes, PMC passes of the default command (each
+#   its own run, kernel-trace only), emulated per-rank times of a 2/4/8-rank job -> gpurun_out/prof/  (copy the summaries to
+#   profiles/rNN_* and commit them together with any kernel change: bench.py reads the newest rNN_relight512_pmc.csv)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
+RN=${RA_ROUND:-r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>&1
+python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${RN}_bench.json 2> $OUT/bench.err
+: > $OUT/${RN}_bench_other_shapes.jsonl
+python3 $R/bench.py --mode sphere_tracing --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
+python3 $R/bench.py --mode anisdf --steps 10 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
+python3 $R/bench.py --ground --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
+python3 $R/bench.py --mode novel_light --size 1024 --probes 8 --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
+python3 $R/bench.py --skin-noise 0 --steps 10 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
+: > $OUT/${RN}_emulate_world.jsonl
+for n in 2 4 8; do python3 $R/bench.py --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world.jsonl 2>> $OUT/bench.err; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python3 $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+cp $OUT/kt/r_kernel_stats.csv $OUT/${RN}_relight512_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_s -o r -- python3 $R/bench.py --mode sphere_tracing --steps 7 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+cp $OUT/kt_s/r_kernel_stats.csv $OUT/${RN}_sphere512_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_a -o r -- python3 $R/bench.py --mode anisdf --steps 7 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+cp $OUT/kt_a/r_kernel_stats.csv $OUT/${RN}_anisdf512_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_g -o r -- python3 $R/bench.py --ground --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cp $OUT/kt_g/r_kernel_stats.csv $OUT/${RN}_relight_ground512_kernel_stats.csv
 i=0
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
   rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
+# the same two HBM counters for the volume path (the full query's tape traffic)
+for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+done
 python3 - <<'P'
 import csv, glob, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof'
+rn = os.environ.get('RA_ROUND', 'r02')
+fams = (('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
+        ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'), ('mlp_full', 'mlp_full_kernel'))
 agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
 for f in sorted(glob.glob(out + '/pmc*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
-        k = 'mlp_sdf_stream_kernel' if 'mlp_sdf_stream' in k else ('hdq_coarse_kernel' if 'hdq_coarse' in k else ('mlp_full_kernel' if 'mlp_full' in k else None))
+        k = next((v for s, v in fams if s in r['Kernel_Name']), None)
         if k is None: continue
         agg[(k, r['Counter_Name'])] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
-with open(out + '/pmc_summary.csv', 'w') as f:
+with open(out + f'/{rn}_relight512_pmc.csv', 'w') as f:
     f.write('kernel,counter,value,dispatches\n')
     for (k, c), v in sorted(agg.items()): f.write(f'{k},{c},{v:.0f},{cnt[(k, c)]}\n')
-print(open(out + '/pmc_summary.csv').read())
+print(open(out + f'/{rn}_relight512_pmc.csv').read())
 P
-head -12 $OUT/kt/r_kernel_stats.csv | cut -c1-160
-cat $OUT/bench.json
+head -12 $OUT/${RN}_relight512_kernel_stats.csv | cut -c1-160
+cat $OUT/${RN}_bench.json
