@@ -58,16 +58,19 @@ def cpu_baseline(cfg, H, n_target=768, threads=16):
                        f'torch fp32 CPU restatement of the reference path (oracle/ra_oracle.py)')
 
 
-def hbm_traffic_per_launch(kernel):
+def hbm_traffic_per_launch(kernel, workload='relight512'):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary of this command (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in their own passes, tools/collect_profiles.sh rewrites it whenever kernels change): FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads.  Returns (bytes, file name)."""
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r[0-9][0-9]_relight512_pmc.csv')))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', f'r[0-9][0-9]_{workload}_pmc.csv')))
     for path in reversed(files):
         try:
-            rows = [l.strip().split(',') for l in open(path) if l.startswith(kernel + ',')]
-            v = {r[1]: (float(r[2]), int(r[3])) for r in rows}
-            return (2.0 * v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1] + v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]) * 1024.0, os.path.basename(path)
+            total = 0.0
+            for kn in kernel.split('+'):           # a launch made of two kernels (the full query): the sum of both
+                rows = [l.strip().split(',') for l in open(path) if l.startswith(kn + ',')]
+                v = {r[1]: (float(r[2]), int(r[3])) for r in rows}
+                total += (2.0 * v['FETCH_SIZE'][0] / v['FETCH_SIZE'][1] + v['WRITE_SIZE'][0] / v['WRITE_SIZE'][1]) * 1024.0
+            return total, os.path.basename(path)
         except Exception:
             continue
     return None, None
@@ -235,6 +238,8 @@ def main():
         achieved = (units * f_unit) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel' and not args.ground
         traffic, traffic_src = hbm_traffic_per_launch(kname) if default_cmd else (None, None)
+        if args.mode == 'anisdf' and H == 512 and world == 1 and '+' in kname:
+            traffic, traffic_src = hbm_traffic_per_launch(kname, 'anisdf512')
         line = {
             'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,

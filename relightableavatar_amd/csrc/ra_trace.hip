@@ -655,39 +655,71 @@ __global__ void volume_samples_kernel(const float* __restrict__ ro, const float*
     }
 }
 
-__global__ void volume_composite_kernel(const float* __restrict__ raw, int C, const float* __restrict__ nr, const float* __restrict__ fr,
-                                        int P, int S, float bg, ra_render_out out, const int* __restrict__ perm) {
-    const int r = blockIdx.x * TPB + threadIdx.x;
-    if (r >= P) return;
-    float o[16];
-    const int CC = C - 1;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] = 0.f;
-    float T = 1.f, acc = 0.f, depth = 0.f;
+// One workgroup composites 64 neighbouring rays (one row group of the sample layout): 16 depth segments x 64 rays.  A thread
+// composites its segment with a local transmittance starting at 1, the segments' transmittances are chained through LDS, and
+// thread (g, j) then sums channel g of ray j over the segments in depth order (a fixed order: the image does not depend on how
+// the rays are chunked).  One thread per ray walking all S samples (the first version) left 128 waves per 8192-ray chunk on the
+// chip, each with S dependent strided reads: 326 us for 67 MB.
+constexpr int VC_SEG = 16;
+__global__ __launch_bounds__(64 * VC_SEG) void volume_composite_kernel(const float* __restrict__ raw, const float* __restrict__ nr,
+                                                                          const float* __restrict__ fr, int P, int S, float bg, ra_render_out out,
+                                                                          const int* __restrict__ perm) {
+    __shared__ float part[VC_SEG][17][64];      // [segment][15 channels, acc, depth][ray]
+    __shared__ float tseg[VC_SEG][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r = min(blockIdx.x * 64 + j, P - 1);
+    const int len = (S + VC_SEG - 1) / VC_SEG, s0 = g * len, s1 = min(S, s0 + len);
     const float n_ = nr[r], f_ = fr[r];
-    for (int s = 0; s < S; ++s) {
-        const float* p = raw + vol_slot(r, s, S) * C;
-        const float a = p[CC];
+    float o[15];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) o[c] = 0.f;
+    float T = 1.f, acc = 0.f, depth = 0.f;
+    const float4* base = reinterpret_cast<const float4*>(raw);
+    for (int s = s0; s < s1; ++s) {
+        const float4* p = base + vol_slot(r, s, S) * 4;
+        const float4 q3 = p[3];
+        const float a = q3.w;
         const float w = a * T;
         T *= (1.f - a + 1e-8f);
         acc += w;
         const float tv = linspace01(s, S);
         depth += w * (n_ * (1.f - tv) + f_ * tv);
-        if (a != 0.f)
-            for (int c = 0; c < CC; ++c) o[c] += w * p[c];
+        if (a != 0.f) {
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            o[0] += w * q0.x; o[1] += w * q0.y; o[2] += w * q0.z; o[3] += w * q0.w;
+            o[4] += w * q1.x; o[5] += w * q1.y; o[6] += w * q1.z; o[7] += w * q1.w;
+            o[8] += w * q2.x; o[9] += w * q2.y; o[10] += w * q2.z; o[11] += w * q2.w;
+            o[12] += w * q3.x; o[13] += w * q3.y; o[14] += w * q3.z;
+        }
     }
-    for (int c = 0; c < CC; ++c) o[c] += (1.f - acc) * bg;
-    const int w_ = perm ? perm[r] : r;                          // internal (sorted) ray -> caller's ray index
-    if (out.acc) out.acc[w_] = acc;
-    if (out.depth) out.depth[w_] = depth;
+    tseg[g][j] = T;
+    __syncthreads();
+    float pre = 1.f;
+    for (int k = 0; k < g; ++k) pre *= tseg[k][j];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (out.cpts) out.cpts[3 * w_ + c] = o[c];
-        if (out.bpts) out.bpts[3 * w_ + c] = o[3 + c];
-        if (out.resd) out.resd[3 * w_ + c] = o[6 + c];
-        if (out.norm) out.norm[3 * w_ + c] = o[9 + c];
-        if (out.rgb) out.rgb[3 * w_ + c] = o[12 + c];
+    for (int c = 0; c < 15; ++c) part[g][c][j] = o[c] * pre;
+    part[g][15][j] = acc * pre;
+    part[g][16][j] = depth * pre;
+    __syncthreads();
+    if (blockIdx.x * 64 + j >= P) return;
+    const int w_ = perm ? perm[r] : r;                          // internal (sorted) ray -> caller's ray index
+    float a_ = 0.f;
+#pragma unroll
+    for (int k = 0; k < VC_SEG; ++k) a_ += part[k][15][j];
+    if (g == 15) {
+        float d_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < VC_SEG; ++k) d_ += part[k][16][j];
+        if (out.acc) out.acc[w_] = a_;
+        if (out.depth) out.depth[w_] = d_;
+        return;
     }
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < VC_SEG; ++k) v += part[k][g][j];
+    v += (1.f - a_) * bg;
+    float* dst = g < 3 ? out.cpts : (g < 6 ? out.bpts : (g < 9 ? out.resd : (g < 12 ? out.norm : out.rgb)));
+    if (dst) dst[3 * w_ + g % 3] = v;
 }
 
 inline dim3 grid_for(long long n) { return dim3((unsigned)((n + TPB - 1) / TPB)); }
@@ -1262,5 +1294,6 @@ void launch_volume_samples(const float* ray_o, const float* ray_d, const float* 
 void launch_volume_composite(const float* raw, int C, const float* near_, const float* far_, int P, int S, float bg,
                              const ra_render_out& out, const int* perm, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(volume_composite_kernel, grid_for(P), dim3(TPB), 0, s, raw, C, near_, far_, P, S, bg, out, perm);
+    if (C != 16) { fprintf(stderr, "relightableavatar: volume compositing expects 16 raw channels, got %d\n", C); abort(); }
+    hipLaunchKernelGGL(volume_composite_kernel, dim3((P + 63) / 64), dim3(64 * VC_SEG), 0, s, raw, near_, far_, P, S, bg, out, perm);
 }

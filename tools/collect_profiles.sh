@@ -34,7 +34,7 @@ done
 # the same two HBM counters for the volume path (the full query's tape traffic)
 for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmcv$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 - <<'P'
 import csv, glob, os, collections
@@ -42,16 +42,17 @@ out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof'
 rn = os.environ.get('RA_ROUND', 'r02')
 fams = (('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
         ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'), ('mlp_full', 'mlp_full_kernel'))
-agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
-for f in sorted(glob.glob(out + '/pmc*/*counter_collection.csv')):
-    for r in csv.DictReader(open(f)):
-        k = next((v for s, v in fams if s in r['Kernel_Name']), None)
-        if k is None: continue
-        agg[(k, r['Counter_Name'])] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
-with open(out + f'/{rn}_relight512_pmc.csv', 'w') as f:
-    f.write('kernel,counter,value,dispatches\n')
-    for (k, c), v in sorted(agg.items()): f.write(f'{k},{c},{v:.0f},{cnt[(k, c)]}\n')
-print(open(out + f'/{rn}_relight512_pmc.csv').read())
+for pat, name in (('/pmc[0-9]*/', 'relight512'), ('/pmcv[0-9]*/', 'anisdf512')):      # one summary per workload
+    agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
+    for f in sorted(glob.glob(out + pat + '*counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            k = next((v for s, v in fams if s in r['Kernel_Name']), None)
+            if k is None: continue
+            agg[(k, r['Counter_Name'])] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
+    with open(out + f'/{rn}_{name}_pmc.csv', 'w') as f:
+        f.write('kernel,counter,value,dispatches\n')
+        for (k, c), v in sorted(agg.items()): f.write(f'{k},{c},{v:.0f},{cnt[(k, c)]}\n')
+    print(open(out + f'/{rn}_{name}_pmc.csv').read())
 P
 head -12 $OUT/${RN}_relight512_kernel_stats.csv | cut -c1-160
 cat $OUT/${RN}_bench.json
