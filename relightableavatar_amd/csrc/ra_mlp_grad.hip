@@ -319,8 +319,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         f32x16 accA, accB;
         // ---- residual deformation net (ReLU, sign bits to the tape)
         pe_frags_g<E, 10, false>(Bp, x, h);
-        const float* bias = sm.bias + 4 * h;
-        asm volatile("" : "+v"(bias));
+        // the lane part goes through an empty asm as an INTEGER: the table rows then are one base register + immediates (a
+        // laundered pointer loses its LDS address space: flat loads, each followed by s_waitcnt vmcnt(0) lgkmcnt(0) — which
+        // drains the weight DMA and the tape stores once per row block)
+        unsigned boff = 4 * h;
+        asm volatile("" : "+v"(boff));
+        const float* bias = sm.bias + boff;
         fwd_layer<E, 4, EPI_RELU_BITS, EPI_NONE, 2>(P, accA, accB, B0, Bp, B0, bias, h, aux, bits_out);
         fwd_layer<E, 16, EPI_RELU_BITS, EPI_RELU_BITS, 2>(P, accA, accB, B0, Bp, B1, bias + 256, h, aux, bits_out);
         fwd_layer<E, 16, EPI_RELU_BITS, EPI_RELU_BITS, 2>(P, accA, accB, B1, Bp, B0, bias + 512, h, aux, bits_out);
@@ -339,8 +343,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         }
         // ---- signed distance net (softplus, scaled domain, activations to the tape), head, feature rows
         aux.st = tw + TP_SDF + lane * 16;
-        bias = sm.bias + 9 * 256 + 4 * h;
-        asm volatile("" : "+v"(bias));
+        asm volatile("" : "+v"(boff));
+        bias = sm.bias + 9 * 256 + boff;
         pe_frags_g<E, 8, true>(Bp, cp, h);
         fwd_layer<E, 4, EPI_SOFTPLUS, EPI_NONE, 1>(P, accA, accB, B0, Bp, B0, bias, h, aux, bits_out);
         fwd_layer<E, 16, EPI_SOFTPLUS, EPI_SOFTPLUS, 1>(P, accA, accB, B0, Bp, B1, bias + 256, h, aux, bits_out);
@@ -415,8 +419,12 @@ struct TapeQ {
     template <int S>
     __device__ __forceinline__ void issue() {
         const char* p = base + off(next < 56 ? next : 55);
+#ifdef RA_EXP_NOLOAD
+        q[S][0] = u32x4{(unsigned)next, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; q[S][1] = q[S][0];      // timing experiment: results are garbage
+#else
         q[S][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
         q[S][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 1024));
+#endif
         ++next;
     }
     template <int K01>
@@ -568,9 +576,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         const unsigned nob[4] = {0u, 0u, 0u, 0u};
         // ---- seed of the sdf net: delta_7 = sigma'(z_7) * lin8[0, :] (times GRAD_SCALE), straight into B fragments
         {
-            const char* t7 = tw + TP_SDF + (7 * 8 * 2) * 1024 + lane * 16;
-            const float* w8 = sm.bias + 5 * 256 + 4 * h;
-            asm volatile("" : "+v"(w8), "+v"(t7));
+            unsigned toff = lane * 16, woff = 4 * h;             // laundered as integers: the pointers keep their address spaces
+            asm volatile("" : "+v"(woff), "+v"(toff));
+            const char* t7 = tw + TP_SDF + (7 * 8 * 2) * 1024 + toff;
+            const float* w8 = sm.bias + 5 * 256 + woff;
 #pragma unroll
             for (int rb = 0; rb < 8; ++rb) {
                 const u32x4 a0 = *reinterpret_cast<const u32x4*>(t7 + (rb * 2) * 1024);
@@ -744,8 +753,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         float o4[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned* nobits = nullptr;
         aux.st = nullptr;
-        const float* hb = sm.bias + 4 * h;
-        asm volatile("" : "+v"(hb));
+        unsigned hoff = 4 * h;
+        asm volatile("" : "+v"(hoff));          // integer, not the pointer: see the forward kernel
+        const float* hb = sm.bias + hoff;
         if constexpr (RELIGHT) {
             fwd_layer<E, 16, EPI_SOFTPLUS, EPI_NONE, 0>(P, accA, accB, B0, Bp, B1, hb, h, aux, nobits);
             fwd_layer<E, 16, EPI_SOFTPLUS, EPI_SOFTPLUS, 0>(P, accA, accB, B1, Bp, B0, hb + 256, h, aux, nobits);

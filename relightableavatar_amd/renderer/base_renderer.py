@@ -1,6 +1,6 @@
 """Volume renderer, host-side mirror of lib/networks/renderer/base_renderer.py (eval path):
 uniform samples between near/far, Network.forward per sample, alpha compositing — one
-ra_render_volume_chunk call per chunk of cfg.render_chunk_size rays."""
+ra_render_volume_chunk call per chunk of max(cfg.render_chunk_size, cfg.volume_chunk_rays) rays."""
 import torch
 from torch import nn
 
@@ -28,7 +28,10 @@ class Renderer(nn.Module):
         full = dotdict(rgb=torch.zeros(P, 3, device=dev), acc=torch.zeros(P, device=dev), depth=torch.zeros(P, device=dev),
                        norm=torch.zeros(P, 3, device=dev), cpts=torch.zeros(P, 3, device=dev), bpts=torch.zeros(P, 3, device=dev),
                        resd=torch.zeros(P, 3, device=dev))
-        for a, b in chunks(P, cfg.render_chunk_size):
+        # the reference's render_chunk_size bounds its activation memory on a 24 GB card; rays are independent here (the pixels do
+        # not depend on the chunking: test_full_size_properties_volume_config2), so launches are sized for the device instead:
+        # 428 k full queries per 8192-ray chunk are 6.5 rounds of 256-point tiles over the 256 CUs, i.e. 7 % idle in the last one
+        for a, b in chunks(P, max(cfg.render_chunk_size, cfg.get('volume_chunk_rays', 0))):
             eng.render_volume_chunk(ray_o[a:b], ray_d[a:b], near[a:b], far[a:b], cfg.n_samples, cfg.dist_th,
                                     {k: v[a:b] for k, v in full.items()})
         ret = dotdict()

@@ -835,7 +835,7 @@ def test_full_size_properties_volume_config2():
     image does not depend on how the rays are chunked or dealt to ranks (rays are independent)"""
     from relightableavatar_amd import shard
     from relightableavatar_amd.renderer import make_renderer
-    cfg, net, dev = build('anisdf')
+    cfg, net, dev = build('anisdf', volume_chunk_rays=0)                            # the reference's chunking: 8192 rays
     assert cfg.n_samples == 128 and cfg.render_chunk_size == 8192
     rend = make_renderer(cfg, net)
     base = synthetic.to_device(synthetic.make_batch(512, 512, seed=0, posed=True), dev)
@@ -846,9 +846,11 @@ def test_full_size_properties_volume_config2():
     nn = out.norm_map.norm(dim=-1)                                                   # a weighted sum of unit normals: |sum w n| <= sum w
     assert float((nn - acc).max()) < 2e-3 and float(nn[acc > 0.99].median()) > 0.3
     assert torch.equal(rend.render(base).rgb_map, rgb)                              # deterministic
-    cfg2, net2, _ = build('anisdf', render_chunk_size=3000)                         # other chunking -> same pixels
-    rgb2 = make_renderer(cfg2, net2).render(base).rgb_map
-    assert float((rgb2 - rgb).abs().max()) == 0.0
+    for kw in (dict(render_chunk_size=3000, volume_chunk_rays=0), dict()):          # other chunkings (3000 rays; the device-sized default: one launch sequence) -> same pixels
+        cfg2, net2, _ = build('anisdf', **kw)
+        rgb2 = make_renderer(cfg2, net2).render(base).rgb_map
+        assert float((rgb2 - rgb).abs().max()) == 0.0
+        del net2
     P = rgb.shape[1]
     merged = torch.zeros_like(rgb[0])
     for r in range(2):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Kernel experiments: tools/build_variant.sh NAME FILE.hip "-DFLAG ..." builds gpurun_tmp/variants/NAME.so = the product library with
+# FILE.hip recompiled under the extra flags (the other objects are the in-tree ones).  Use with RA_LIB_PATH=... (see _lib.py).
+set -e
+R=$(cd $(dirname $0)/.. && pwd)
+C=$R/relightableavatar_amd/csrc
+name=$1; src=$2; flags=$3
+mkdir -p $R/gpurun_tmp/variants
+make -s -C $C
+base=$(basename $src .hip)
+nos=""; case $base in ra_hdq|ra_mlp_stream|ra_mlp|ra_mlp_grad) nos=-fno-slp-vectorize;; esac
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value $nos $flags -c $C/$base.hip -o $R/gpurun_tmp/variants/$name.o
+objs=""
+for o in ra_mlp ra_mlp_pipe ra_mlp_stream ra_mlp_grad ra_hdq ra_trace ra_image ra_api ra_pack; do
+  if [ $o = $base ]; then objs="$objs $R/gpurun_tmp/variants/$name.o"; else objs="$objs $C/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $R/gpurun_tmp/variants/$name.so
+echo built gpurun_tmp/variants/$name.so

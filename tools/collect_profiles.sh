@@ -3,6 +3,9 @@
 #   kernel-trace stats of the default bench command and of the other BASELINE shapes, PMC passes of the default command (each
 #   its own run, kernel-trace only), emulated per-rank times of a 2/4/8-rank job -> gpurun_out/prof/  (copy the summaries to
 #   profiles/rNN_* and commit them together with any kernel change: bench.py reads the newest rNN_relight512_pmc.csv)
+# NOTE bench.py takes `roofline.traffic` from the COMMITTED profiles/rNN_*_pmc.csv, i.e. from the previous collection: after a
+#   change of launch granularity (e.g. cfg.volume_chunk_rays) copy the new summaries to profiles/ and collect once more, or the
+#   per-launch traffic in the new bench lines belongs to the old launch size.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
