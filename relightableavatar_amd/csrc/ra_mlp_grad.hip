@@ -143,9 +143,11 @@ struct NoTape { template <int K> __device__ __forceinline__ void take(u32x4&, u3
 // this block's stage turnover (P.fetch<0>: counted wait + barrier + the next weight DMA): the compiler's wait for those loads
 // cannot tell them from the weight DMA it does not see, so it drains the queue — cheap only where the youngest DMA is a whole
 // block old, i.e. exactly there.
-template <typename E, int FM0, int KS, int EPI, bool EARLY, bool TAIL, bool BIAS, int L, bool LO, int PB = 0, int TK = -1, typename PipeT, typename TQ = NoTape>
+// PIN: four prefetched dwords (the ReLU net's sign-bit words of a later layer) are waited for in that same slot instead of at
+// their first use, which would fall a few MFMAs AFTER a turnover — the worst place for a wait that drains the weight DMA.
+template <typename E, int FM0, int KS, int EPI, bool EARLY, bool TAIL, bool BIAS, int L, bool LO, int PB = 0, int TK = -1, bool PIN = false, typename PipeT, typename TQ = NoTape>
 __device__ __forceinline__ void rbg(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4& o0, u32x4& o1,
-                                    const float* bias_rb, int h, EpiAux& aux, TQ* tq = nullptr) {
+                                    const float* bias_rb, int h, EpiAux& aux, TQ* tq = nullptr, unsigned* pin = nullptr) {
     if constexpr (BIAS) init_acc_l(acc, bias_rb);
     else {
 #pragma unroll
@@ -160,6 +162,7 @@ __device__ __forceinline__ void rbg(PipeT& P, f32x16& acc, const f32x16& accPrev
             tq->template take<TK>(aux.n0, aux.n1);
             asm volatile("" : "+v"(aux.n0), "+v"(aux.n1));          // the loads are waited for HERE
         }
+        if constexpr (PIN && (FM0 + ks + ST_PF) % 16 == 0) asm volatile("" : "+v"(pin[0]), "+v"(pin[1]), "+v"(pin[2]), "+v"(pin[3]));
         if constexpr (!(TAIL && ks + ST_PF >= KS)) P.template fetch<(FM0 + ks + ST_PF) % 16>();
         if constexpr (EPI != EPI_NONE) {
             static_for<0, 16>([&](auto e_) {
@@ -437,9 +440,15 @@ struct TapeQ {
 // a transposed 256-row layer (8 row blocks, K = 16 k-steps): Bo = EPI(W^T Bm).  On entry accB holds a pending block:
 //   IN = 0 nothing, 1 the previous transposed layer's last block (same EPI, goes to Bm[14], Bm[15]), 2 an encoding-gradient
 //   block (EPI_PEJAC, block PB_IN).  K01 is the parity of the first tape block this layer consumes (EPI_GRAD_SP).
-template <typename E, int EPI, int IN, int L, bool LO, typename PipeT, typename TQ>
+template <typename E, int EPI, int IN, int L, bool LO, bool PF = false, typename PipeT, typename TQ>
 __device__ __forceinline__ void bwd_layer(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16], int h, EpiAux& aux,
-                                          TQ& tq, const unsigned (&bw_in)[4], const unsigned (&bw)[4]) {
+                                          TQ& tq, const unsigned (&bw_in)[4], const unsigned (&bw)[4], unsigned* bw_next = nullptr,
+                                          const unsigned* bt_next = nullptr) {
+    // PF: the sign-bit words of the layer after next (bt_next, per lane) are requested now and pinned in block 7
+    if constexpr (PF) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bw_next[k] = bt_next[k * 64];
+    }
     // bw_in: sign-bit words of the pending block's layer (EPI_GRAD_RELU, IN == 1); bw: of this layer's output features.
     // EPI_GRAD_SP: on entry aux.t0/t1 hold the tape of the pending block (IN == 1); every row block i takes the tape of block
     // i of THIS layer's output (its epilogue is pending during block i + 1) — on exit aux.t0/t1 = block 7's.
@@ -469,7 +478,7 @@ __device__ __forceinline__ void bwd_layer(PipeT& P, f32x16& accA, f32x16& accB, 
     adv(); bits(std::integral_constant<int, 5>{}, bw);
     rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 0 : -1>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], nullptr, h, aux, &tq);
     adv(); bits(std::integral_constant<int, 6>{}, bw);
-    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 1 : -1>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], nullptr, h, aux, &tq);
+    rbg<E, 0, 16, EPI, false, false, false, L, LO, 0, SP ? 1 : -1, PF>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], nullptr, h, aux, &tq, bw_next);
     adv();
 }
 
@@ -658,9 +667,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
             Bp[0][1] = h ? 0u : pack2<E>(sd[2], 0.f);
         }
         const unsigned* bt = reinterpret_cast<const unsigned*>(tw + TP_BITS) + lane;
-        unsigned bwA[4], bwB[4];
+        unsigned bwA[4], bwB[4], bwC[4];            // three rotating sets: pending block's layer, this layer, prefetch
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bwA[k] = bt[(7 * 4 + k) * 64];                // layer 7's sign bits
+        for (int k = 0; k < 4; ++k) { bwA[k] = bt[(7 * 4 + k) * 64]; bwB[k] = bt[(6 * 4 + k) * 64]; }      // layers 7 and 6
         // head^T: 8 row blocks of 4 k-steps (3 real columns), epilogue = layer 7's ReLU mask -> delta_7
         {
             u32x4 d0, d1;
@@ -678,29 +687,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
             aux.bits = bwA[2];
             rbg<E, 8, 4, EPI_GRAD_RELU, false, false, false, 10, false>(P, accA, accB, B0, Bp, B0[10], B0[11], nullptr, h, aux);
             aux.bits = bwA[3] >> 16;
-            rbg<E, 12, 4, EPI_GRAD_RELU, false, false, false, 10, false>(P, accB, accA, B0, Bp, B0[12], B0[13], nullptr, h, aux);
+            rbg<E, 12, 4, EPI_GRAD_RELU, false, false, false, 10, false, 0, -1, true>(P, accB, accA, B0, Bp, B0[12], B0[13], nullptr, h, aux, (NoTape*)nullptr, bwB);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { aux.g[k] = 0.f; aux.rev[k] = x[k] * INV_2PI; }
-        auto load_bits = [&](unsigned (&dst)[4], int l) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k] = bt[(l * 4 + k) * 64];
-        };
-        load_bits(bwB, 6);
-        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwA, bwB);   // W7^T -> delta_6
-        load_bits(bwA, 5);
-        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B1, Bp, B0, h, aux, tq, bwB, bwA);   // W6^T -> delta_5
-        load_bits(bwB, 4);
-        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwA, bwB);   // W5^T -> delta_4
-        load_bits(bwA, 3);
-        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B1, Bp, B0, h, aux, tq, bwB, bwA);   // W4^T (hidden columns) -> delta_3
-        bwd_pe_blocks<E, EPI_GRAD_RELU, false, 10, false>(P, accA, accB, B1, Bp, B0[14], B0[15], h, aux, tq, bwA);
-        load_bits(bwB, 2);
-        bwd_layer<E, EPI_GRAD_RELU, 0, 10, false>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwA, bwB);   // W3^T -> delta_2
-        load_bits(bwA, 1);
-        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B1, Bp, B0, h, aux, tq, bwB, bwA);   // W2^T -> delta_1
-        load_bits(bwB, 0);
-        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwA, bwB);   // W1^T -> delta_0
+        auto words = [&](int l) { return bt + (l * 4) * 64; };
+        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false, true>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwA, bwB, bwC, words(5));   // W7^T -> delta_6
+        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false, true>(P, accA, accB, B1, Bp, B0, h, aux, tq, bwB, bwC, bwA, words(4));   // W6^T -> delta_5
+        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false, true>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwC, bwA, bwB, words(3));   // W5^T -> delta_4
+        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false, true>(P, accA, accB, B1, Bp, B0, h, aux, tq, bwA, bwB, bwC, words(2));   // W4^T (hidden columns) -> delta_3
+        bwd_pe_blocks<E, EPI_GRAD_RELU, false, 10, false>(P, accA, accB, B1, Bp, B0[14], B0[15], h, aux, tq, bwB);
+        bwd_layer<E, EPI_GRAD_RELU, 0, 10, false, true>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwB, bwC, bwA, words(1));   // W3^T -> delta_2
+        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false, true>(P, accA, accB, B1, Bp, B0, h, aux, tq, bwC, bwA, bwB, words(0));   // W2^T -> delta_1
+        bwd_layer<E, EPI_GRAD_RELU, 1, 10, false>(P, accA, accB, B0, Bp, B1, h, aux, tq, bwA, bwB);                        // W1^T -> delta_0
         bwd_pe_blocks<E, EPI_GRAD_RELU, true, 10, false>(P, accA, accB, B1, Bp, B1[14], B1[15], h, aux, tq, bwB);   // W0^T
         float g[3];         // d sdf / d bpts = g_c + J_resd^T g_c
 #pragma unroll
