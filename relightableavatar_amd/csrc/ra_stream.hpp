@@ -44,10 +44,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <typename E> struct Tr;
 template <> struct Tr<bf16> {
     typedef bf16x8 x8; typedef bf16x2 x2;
+    static constexpr bool is_f16 = false;
     static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct Tr<f16> {
     typedef f16x8 x8; typedef f16x2 x2;
+    static constexpr bool is_f16 = true;
     static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
@@ -180,11 +182,20 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
                     if constexpr (ks == 2) ta[e] = __builtin_amdgcn_logf(ta[e]);
                     if constexpr (ks == 3) ta[e] = ta[e] + tb[e];
                 } else {
-                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e] = (RA_ABL == 3 || RA_ABL == 6) ? accPrev[e] : max0(accPrev[e]);
+                    // f16: ReLU AFTER the pack (v_cvt_pk + v_pk_max_f16: 1.0 instead of 1.5 VALU per element).  Rounding is monotone
+                    // and keeps the sign, so max(round(z), 0) == round(max(z, 0)): bitwise identical distances on 200 k points,
+                    // -6.6 % VALU instructions, -0.5 .. -0.8 % kernel time (same-box A/B) — VALU count is not what bounds K3.
+                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e] = (Tr<E>::is_f16 || RA_ABL == 3 || RA_ABL == 6) ? accPrev[e] : max0(accPrev[e]);
                 }
                 constexpr int sdone = (KS == 4) ? (SP ? 3 : e / 4) : s0 + DEPTH;
                 if constexpr ((e & 1) && sdone == ks) {
-                    const unsigned w = (RA_ABL == 3 || RA_ABL == 6) ? __builtin_bit_cast(unsigned, ta[e]) : pack2<E>(ta[e - 1], ta[e]);
+                    unsigned w = (RA_ABL == 3 || RA_ABL == 6) ? __builtin_bit_cast(unsigned, ta[e]) : pack2<E>(ta[e - 1], ta[e]);
+                    if constexpr (!SP && Tr<E>::is_f16 && RA_ABL != 3 && RA_ABL != 6) {
+                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                        h2_t v = __builtin_bit_cast(h2_t, w);
+                        v = __builtin_elementwise_max(v, h2_t{(_Float16)0, (_Float16)0});
+                        w = __builtin_bit_cast(unsigned, v);
+                    }
                     if constexpr (e < 8) o0[e >> 1] = w; else o1[(e >> 1) & 3] = w;
                 }
             });
