@@ -258,11 +258,13 @@ def get_near_far_aabb(bounds, ray_o, ray_d, epsilon=1e-8):
 def knn3(p1: torch.Tensor, p2: torch.Tensor, K: int = 3, chunk: int = 65536):
     """pytorch3d.ops.knn_points contract: exact squared-L2 K-NN, ascending. p1 (P,3), p2 (N,3).
     Distances are formed as sum((p-v)^2) (not the |p|^2-2pv+|v|^2 expansion) so near-zero values stay exact."""
+    # top-k per block of rows (it is a per-row operation): concatenating the blocks' (rows x N) distance matrices first cost
+    # more than computing them (1.8 GB per 65536 queries against 6890 vertices; 60 % of the ground-pass tests' time)
     d2s, idxs = [], []
-    for i in range(0, max(p1.shape[0], 1), chunk):
-        q = p1[i:i + chunk]
-        d = ((q[:, None, :] - p2[None, :, :]) ** 2).sum(-1) if q.shape[0] <= 8192 else \
-            torch.cat([((q[j:j + 4096, None, :] - p2[None]) ** 2).sum(-1) for j in range(0, q.shape[0], 4096)])
+    step = min(chunk, 4096) if p1.shape[0] > 8192 else max(p1.shape[0], 1)
+    for i in range(0, max(p1.shape[0], 1), step):
+        q = p1[i:i + step]
+        d = ((q[:, None, :] - p2[None, :, :]) ** 2).sum(-1)
         d2, idx = d.topk(K, dim=-1, largest=False, sorted=True)
         d2s.append(d2)
         idxs.append(idx)
