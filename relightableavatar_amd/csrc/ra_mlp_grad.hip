@@ -20,7 +20,8 @@
 //     Jacobian on the fly (d sin(2^f x) = 2^f cos(2^f x), one v_cos per channel).  sdf net first (gradient wrt cpts), then the
 //     residual net seeded with resd_limit (1 - tanh^2) g (cpts = bpts + resd(bpts)), then the material heads or the colour
 //     net on the taped features, then the per-point epilogue (normal transforms, occupancy, raw channels).
-//     Tape reads are inline-asm global loads with counted vmcnt waits beside the LDS-DMA weight stream (two row blocks ahead).
+//     Tape reads are plain (compiler-visible) non-temporal loads requested two row blocks ahead and first used in the MFMA slot
+//     right before a stage turnover (TapeQ below explains why not inline asm with counted waits).
 //   * gradients are carried times GRAD_SCALE (2^4) for f16 headroom; everything acting on them is linear.
 #include "ra_stream.hpp"
 
@@ -36,9 +37,6 @@ constexpr float GRAD_SCALE = 16.f;
 #endif
 #ifndef RA_K4_NW_B
 #define RA_K4_NW_B 8
-#endif
-#ifndef RA_TAPE_N
-#define RA_TAPE_N (2 * FPW + 2)
 #endif
 constexpr int FW_BIAS_ROWS = 19;                       // + feature rows' bias
 // tape of one wave-tile (32 points), bytes
@@ -486,7 +484,7 @@ __device__ __forceinline__ void bwd_layer(PipeT& P, f32x16& accA, f32x16& accB, 
 // on entry accB = the layer's pending block 7 (EPI, into o14, o15; EARLY when those are this block's own inputs).  The two
 // blocks' accumulators are contracted with the encoding's Jacobian right away (8 such blocks per tile: not worth a pending
 // epilogue); on exit nothing is pending.  Bin: the delta fragments to multiply.
-template <typename E, int EPI, bool EARLY, int L, bool LO, bool SWAP = false, typename PipeT, typename TQ>
+template <typename E, int EPI, bool EARLY, int L, bool LO, typename PipeT, typename TQ>
 __device__ __forceinline__ void bwd_pe_blocks(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&Bin)[16], const u32x4 (&Bp)[4], u32x4& o14, u32x4& o15, int h,
                                               EpiAux& aux, TQ& tq, const unsigned (&bw)[4]) {
     if constexpr (EPI == EPI_GRAD_RELU) aux.bits = bw[3];        // EPI_GRAD_SP: aux.t0/t1 already hold block 7's tape
@@ -494,8 +492,8 @@ __device__ __forceinline__ void bwd_pe_blocks(PipeT& P, f32x16& accA, f32x16& ac
     u32x4 d0, d1;
     rbg<E, 0, 16, EPI_NONE, false, false, false, L, LO>(P, accA, accB, Bin, Bp, d0, d1, nullptr, h, aux);
     rbg<E, 0, 16, EPI_NONE, false, false, false, L, LO>(P, accB, accA, Bin, Bp, d0, d1, nullptr, h, aux);
-    flush<E, EPI_PEJAC, L, LO, SWAP ? 1 : 0>(accA, d0, d1, h, aux);
-    flush<E, EPI_PEJAC, L, LO, SWAP ? 0 : 1>(accB, d0, d1, h, aux);
+    flush<E, EPI_PEJAC, L, LO, 0>(accA, d0, d1, h, aux);
+    flush<E, EPI_PEJAC, L, LO, 1>(accB, d0, d1, h, aux);
 }
 
 __device__ __forceinline__ void inv3r(const float R[9], float M[9]) {   // blend_utils.py:125-165
@@ -641,11 +639,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         dumpB(B0, 1);
         bwd_layer<E, EPI_GRAD_SP, 1, 8, true>(P, accA, accB, B0, Bp, B1, h, aux, tq, nob, nob);       // lin1^T -> delta_0
         dumpB(B1, 0);
-#ifdef RA_EXP_SWAP
-        bwd_pe_blocks<E, EPI_GRAD_SP, true, 8, true, true>(P, accA, accB, B1, Bp, B1[14], B1[15], h, aux, tq, nob);    // lin0^T, blocks swapped (experiment)
-#else
         bwd_pe_blocks<E, EPI_GRAD_SP, true, 8, true>(P, accA, accB, B1, Bp, B1[14], B1[15], h, aux, tq, nob);    // lin0^T
-#endif
         float gc[3];        // GRAD_SCALE * d sdf / d cpts
 #pragma unroll
         for (int k = 0; k < 3; ++k) gc[k] = aux.g[k] + __shfl_xor(aux.g[k], 32);

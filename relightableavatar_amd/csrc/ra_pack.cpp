@@ -363,7 +363,6 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
             if (l == 4) { Mat Tp = transpose_pe(Spe4, pe_chan_sdf, sdf_dim); B.add(&Tp, nullptr, pe_chan_sdf, 64, inv_sp); }
         }
         { Mat Tp = transpose_pe(Sm[0], pe_chan_sdf, sdf_dim);
-          if (getenv("RA_EXP_SWAP")) { Mat Sw(64, Tp.cols); for (int r = 0; r < 64; ++r) for (int k = 0; k < Tp.cols; ++k) Sw.at(r, k) = Tp.at((r + 32) % 64, k); Tp = Sw; }
           B.add(&Tp, nullptr, pe_chan_sdf, 64, inv_sp); }
         {   // residual head: 3 seeds -> 256 rows, as a 4-k-step "encoding" layer
             Mat T = transpose(Rhead, 256);                       // [256][3]
