@@ -625,6 +625,43 @@ def test_streamed_k3_tile_boundaries(relight):
     assert eng.hdq_sdf(x_all[:0], 0.125, True).numel() == 0
 
 
+@pytest.mark.parametrize('mode', ['relight', 'anisdf'])
+def test_full_query_tile_boundaries(mode):
+    """the reverse-mode full query (forward with tape + backward, 256-point tiles of 8 x 32 points; the tape is sized by whole
+    tiles) for counts around every tile / wave boundary, both head variants (material heads, colour net): a point's raw channels
+    — normals included — must not depend on the batch it is evaluated in, bit for bit (ragged last tile, dead waves, a single
+    point, an empty set), and must agree with the oracle"""
+    from oracle import ra_oracle as O
+    cfg, net, dev = build(mode)
+    body = synthetic.to_device(synthetic.make_body(0, posed=True), dev)
+    eng = net.set_frame(body)
+    g = torch.Generator().manual_seed(33)
+    N = 2100
+    vid = torch.randint(0, 6890, (N,), generator=g)
+    wv = (body.pverts[0] @ body.R[0].T + body.Th[0])[vid.to(dev)]
+    x_all = (wv + 0.002 * torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(dev)).contiguous()     # all within dist_th
+    v_all = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(dev).contiguous()
+    th = 0.005
+    c0 = eng.counters().n_fine_full
+    whole = eng.forward(x_all, v_all, th).clone()
+    assert eng.counters().n_fine_full - c0 == N and torch.isfinite(whole).all()
+    nrm = whole[:, 13:16] if mode == 'relight' else whole[:, 9:12]
+    assert float((nrm.norm(dim=-1) - 1).abs().max()) < 1e-4                          # unit normals out of the backward pass
+    for n in (1, 31, 32, 33, 63, 65, 255, 256, 257, 511, 512, 513, 1023, 1025, 2047, 2049):
+        part = eng.forward(x_all[:n].contiguous(), v_all[:n].contiguous(), th)
+        assert part.shape == (n, whole.shape[1]) and torch.equal(part, whole[:n]), (mode, n, float((part - whole[:n]).abs().max()))
+    assert eng.forward(x_all[:0], v_all[:0], th).shape[0] == 0
+    # the same 257 points through the fp32 oracle
+    n = 257
+    onet = O.OracleNet(synthetic.make_state_dict(0, relight=mode == 'relight', cfg=cfg), cfg)
+    ref, _ = O.network_forward(onet, x_all[:n].cpu(), v_all[:n].cpu(), O._frame(synthetic.make_body(0, posed=True)), th)
+    e = err(whole[:n], ref)
+    ncol = slice(13, 16) if mode == 'relight' else slice(9, 12)
+    other = [c for c in range(whole.shape[1]) if not (ncol.start <= c < ncol.stop)]
+    assert float(e[:, ncol].max()) < 1.5e-2 and float(e[:, ncol].mean()) < 1e-3, (float(e[:, ncol].max()), float(e[:, ncol].mean()))
+    assert float(e[:, other].max()) < 2e-3, float(e[:, other].max())
+
+
 def test_pose_frame_on_device(golden, relight):
     """N3: ra_pose_frame vs the reference's own functions (golden lbs.npz: bone transforms, T-pose / posed /
     world vertices, bounds) and vs the oracle (vertex normals, full vertex set)."""
