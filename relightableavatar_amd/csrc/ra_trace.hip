@@ -645,12 +645,15 @@ __global__ void volume_samples_kernel(const float* __restrict__ ro, const float*
     const int j = (int)(k & 63);
     const long long gs = k >> 6;
     const int s = (int)(gs % S), rg = (int)(gs / S);
-    const int r = min(rg * 64 + j, P - 1);                      // padding slots repeat the last ray (never composited)
+    const bool pad = rg * 64 + j >= P;                          // padding slots of the last 64-ray group: never composited
+    const int r = min(rg * 64 + j, P - 1);
     const float tv = linspace01(s, S);
     const float z = nr[r] * (1.f - tv) + fr[r] * tv;            // base_renderer.py:17-18
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        x[3 * k + c] = ro[3 * r + c] + rd[3 * r + c] * z;
+        // a padding sample sits far outside every box: the coarse level drops it, so it costs no full query and is not
+        // counted as one (it used to repeat the last ray: up to 63 x S duplicate queries per launch in n_fine_full)
+        x[3 * k + c] = pad ? 1.0e6f : ro[3 * r + c] + rd[3 * r + c] * z;
         v[3 * k + c] = rd[3 * r + c];
     }
 }
