@@ -14,6 +14,7 @@ shard plan, frame all_gather, barrier, MAX reduce, JSON line) on CPU tensors wit
 import argparse
 import glob
 import json
+import math
 import os
 import socket
 import subprocess
@@ -35,27 +36,47 @@ F_FULL_ANISDF = 3_934_208 + 541_184       # volume path: geometry point with nor
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
-def cpu_baseline(cfg, H, n_target=768, threads=16):
-    """oracle (CPU port of the reference path) on a strided sample of the same frame's rays."""
+def sample_batch(H, skin_noise, n_target):
+    """the bounded sample of the benchmarked frame: every stride-th of its in-box rays (rays are independent: one render chunk)."""
+    return synthetic.sample_rays(synthetic.make_batch(H, H, seed=0, posed=True, skin_noise=skin_noise), n_target)
+
+
+def cpu_baseline(cfg, H, skin_noise, n_target=256, threads=16):
+    """oracle (CPU port of the reference path) on a strided sample of the same frame's rays.  Returns the bench line's
+    `cpu_baseline` object and the oracle's maps of the sample (the checker of `psnr_vs_oracle`)."""
     from oracle import ra_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, threads))   # more threads than this only add sync overhead here
-    batch = synthetic.make_batch(H, H, seed=0, posed=True)
-    P = batch.ray_o.shape[1]
-    stride = max(1, P // n_target)
-    for k in shard.RAY_KEYS:
-        batch[k] = batch[k][:, ::stride].contiguous()
+    batch, P, stride = sample_batch(H, skin_noise, n_target)
     n = batch.ray_o.shape[1]
     net = O.OracleNet(synthetic.make_state_dict(0, relight=bool(cfg.relighting), cfg=cfg), cfg)
     t0 = time.perf_counter()
     if cfg.renderer_module.endswith('base_renderer'):
-        O.render_volume(net, batch)
+        ref = O.render_volume(net, batch)
     else:
-        O.render_sphere_tracing(net, batch)
+        ref = O.render_sphere_tracing(net, batch)
     dt = time.perf_counter() - t0
     # rays outside the body's bounding box cost nothing on either side: scale to whole-frame rays
     return dict(value=(n / P) * H * H / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'every {stride}th of the {P} in-box rays of the same {H}x{H} frame ({n} rays, {dt:.1f} s), '
-                       f'torch fp32 CPU restatement of the reference path (oracle/ra_oracle.py)')
+                       f'torch fp32 CPU restatement of the reference path (oracle/ra_oracle.py)'), ref
+
+
+def psnr_vs_oracle(renderer, ref, H, skin_noise, dev, n_target=256):
+    """BASELINE.json's "PSNR vs ref" on the benchmarked frame itself: the HIP path renders the SAME strided sample of the
+    512 x 512 frame the CPU leg rendered with the oracle (lib/evaluators/base_evaluator.py:26-29's PSNR on rgb_map)."""
+    batch, P, stride = sample_batch(H, skin_noise, n_target)
+    out = renderer.render(synthetic.to_device(batch, dev))
+    torch.cuda.synchronize(dev)
+    rgb, rgb_ref = out.rgb_map.float().cpu(), ref.rgb_map.float()
+    e = (rgb - rgb_ref).abs()
+    mse = float((e ** 2).mean())
+    hit, hit_ref = out.acc_map.cpu() > 0, ref.acc_map > 0
+    return {'rgb': (float('inf') if mse == 0 else -10.0 * math.log10(mse)), 'max_abs': float(e.max()), 'n_rays': int(rgb.shape[1]),
+            'hit_rays': int(hit_ref.sum()), 'hit_mask_agreement': float((hit == hit_ref).float().mean()),
+            'sample': f'every {stride}th in-box ray of the benchmarked {H}x{H} frame, skin_noise {skin_noise}',
+            'contract': 'SURVEY.md:409: >= 50 dB and max <= 1e-2 where the reference\'s own trace converges (--skin-noise 0); '
+                        'on the SURVEY 8d body (--skin-noise 2, ~9 % of the reference\'s hit rays end in a limit cycle) the emulated-f16 '
+                        'floor is 50.6 dB (tests/golden/precision_floor.json)'}
 
 
 def hbm_traffic_per_launch(kernel, workload='relight512'):
@@ -103,9 +124,10 @@ def dry_rank(args, rank, world):
     ref = torch.stack([base.ray_d[0, :, 0], base.ray_d[0, :, 1], base.near[0], base.far[0]], -1)[None]       # a per-ray "image"
 
     def step():
-        sb = shard.shard_batch(base, rank, world, 65536)
+        pl = shard.make_plan(P, world, base, mask=base.mask_at_box, render_chunk_size=65536, use_cache=False)      # per frame, as the timed loop does
+        sb = shard.shard_batch(base, rank, world, 65536, pl)
         local = torch.stack([sb.ray_d[0, :, 0], sb.ray_d[0, :, 1], sb.near[0], sb.far[0]], -1)[None]
-        return shard.gather_maps(local, P, rank, world, batch=base)
+        return shard.gather_maps(local, P, rank, world, plan=pl)
     for _ in range(args.warmup):
         step()
     dist.barrier()
@@ -144,6 +166,8 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL on ROCm; gloo only with --dry')
     ap.add_argument('--dry', action='store_true', help='no HIP engine: launcher + process-group plumbing on CPU tensors (CPU test of the N > 1 path)')
     ap.add_argument('--static-frame', action='store_true', help='A/B: do not re-pose the body every step (round-1 behaviour: per-frame set-up outside the timed region)')
+    ap.add_argument('--k4-batch', type=int, default=0, help='cfg.k4_batch_slots: full queries per forward+backward launch pair (0 = library default)')
+    ap.add_argument('--soak', type=float, default=3.0, help='seconds of untimed frames BEFORE the W warm-up steps: the chip is power-limited on this path (DESIGN.md section 4), so the clock of a cold 0.7 s burst is not the sustained one')
     ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 
@@ -174,6 +198,10 @@ def main():
 
     H = args.size
     kw = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0]) if args.ground else {}
+    if args.k4_batch:
+        kw['k4_batch_slots'] = args.k4_batch
+    if args.mode == 'novel_light':
+        kw['novel_light_timing'] = False     # nobody reads `diff` here: no host sync inside the frame
     cfg = make_cfg(args.mode, mlp_dtype=args.dtype, **kw)
     relight = args.mode in ('relight', 'novel_light')
     net = make_network(cfg)
@@ -187,19 +215,28 @@ def main():
     mask0 = base.mask_at_box.clone()
     eng = net.engine()
 
+    mask_host = base.mask_at_box.cpu()          # the loader's copy: the shard plan is host work (shard.make_plan)
+    wbh0 = wb0.cpu()
+    nw = args.emulate_world if args.emulate_world > 1 else world          # --emulate-world N: rank 0's share of an N-rank job, no collective
+    rk = 0 if args.emulate_world > 1 else rank
+
     def step():
-        base.wbounds.copy_(wb0)     # a fresh batch per frame, as the reference's loader delivers
+        # a fresh batch per frame, as the reference's loader delivers: body box (device tensor + the loader's host copy), mask
+        base.wbounds.copy_(wb0)
+        base.wbounds_host, base.wbounds_host_version = wbh0.clone(), base.wbounds._version
         if not args.static_frame:
             eng.set_frame(base, force=True)     # an animation poses a new body every frame: vertex blend, BVH build, bias folds are timed
         if args.ground:
             base.mask_at_box.copy_(mask0)   # the ground pass sets it to all-true in place (sphere_tracing_renderer.py:1103)
+        # a new frame has a new mask: the shard plan (ownership + exchange index vectors) is rebuilt every step, inside the timed region
+        pl = shard.make_plan(P, nw, base, dev, mask=mask_host, ground=args.ground, render_chunk_size=cfg.render_chunk_size, use_cache=False) if nw > 1 else None
         if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
-            out = renderer.render(shard.shard_batch(base, rank, world, cfg.render_chunk_size))
+            out = renderer.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
             rgb = torch.cat([out[n].rgb_map for n in base.novel_lights], dim=-1)
-            return shard.gather_maps(rgb, P, rank, world, batch=base)
+            return rgb if args.emulate_world > 1 else shard.gather_maps(rgb, P, rank, world, plan=pl, ground=args.ground)
         if args.emulate_world > 1:
-            return renderer.render(shard.shard_batch(base, 0, args.emulate_world, cfg.render_chunk_size))
-        return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world)
+            return renderer.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
+        return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world, plan=pl)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -207,6 +244,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # sustained clocks / temperature before anything is measured: rank 0 sizes the soak from two probe frames, every rank runs the
+    # same number of frames (the frame all_gather is a collective)
+    n_soak = 0
+    if args.soak > 0:
+        step(); sync()
+        t_probe = time.perf_counter()
+        step(); sync()
+        ns = torch.tensor([max(0, int(args.soak / max(time.perf_counter() - t_probe, 1e-4)))], device=dev)
+        if use_dist:
+            dist.broadcast(ns, 0)
+        n_soak = int(ns.item())
+        for _ in range(n_soak):
+            step()
+        n_soak += 2
     for _ in range(args.warmup):
         step()
     sync()
@@ -230,11 +281,11 @@ def main():
         dist.all_reduce(cnts)
     if rank == 0:
         ms = dt / args.steps * 1e3
-        kname = {'1': 'mlp_sdf_kernel', '2': 'mlp_sdf_pipe_kernel'}.get(os.environ.get('RA_MLP_GEN', '3'), 'mlp_sdf_stream_kernel')
+        kname = 'mlp_sdf_stream_kernel'
         units, f_unit = cnt.n_fine_sdf, F_SDF
         if args.mode == 'anisdf':           # the volume path has no distance-only queries: its dominant kernel is the full query
-            # second-generation full query = two kernels per launch (forward with tape, reverse-mode backward + colour net); the timer brackets both
-            kname, units, f_unit = ('mlp_full_kernel' if os.environ.get('RA_K4_GEN') == '1' else 'mlp_fwd_tape_kernel+mlp_bwd_heads_kernel'), cnt.n_fine_full, F_FULL_ANISDF
+            # the full query = two kernels per launch (forward with tape, reverse-mode backward + colour net); the timer brackets both
+            kname, units, f_unit = 'mlp_fwd_tape_kernel+mlp_bwd_heads_kernel', cnt.n_fine_full, F_FULL_ANISDF
         achieved = (units * f_unit) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel' and not args.ground
         traffic, traffic_src = hbm_traffic_per_launch(kname) if default_cmd else (None, None)
@@ -259,8 +310,11 @@ def main():
         line['hit_pixels_per_sec'] = cnts[3].item() / dt          # the 84 % of rays that miss the box cost nothing: rays/s flatters
         line['fine_queries_per_sec'] = cnts[0].item() / dt
         line['config']['frame_setup'] = 'static frame (set-up excluded)' if args.static_frame else 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
+        line['config']['soak'] = f'{n_soak} untimed frames in {args.soak:.1f} s before the {args.warmup} warm-up steps'
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(cfg, H)
+            line['cpu_baseline'], ref = cpu_baseline(cfg, H, args.skin_noise)
+            if args.mode in ('relight', 'sphere_tracing', 'anisdf') and not args.ground and args.emulate_world <= 1:
+                line['psnr_vs_oracle'] = psnr_vs_oracle(renderer, ref, H, args.skin_noise, dev)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

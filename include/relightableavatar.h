@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 2
+#define RA_ABI_VERSION 3
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -55,6 +55,11 @@ typedef struct ra_config {
     int   tonemapping;                        /* cfg.tonemapping_rendering                        */
     float bg_brightness;                      /* 0.0                                              */
     int   mlp_f16;                            /* element type of the fused MLP kernels: 1 = IEEE half, 0 = bfloat16 (same MFMA rate) */
+    int   query_skip;                         /* 1 (default): rays that did not move since their last distance query / shadow rays whose
+                                                 visibility reached 0 keep their last distance instead of being queried again — exact
+                                                 (frames are bit-identical with 0), the reference re-queries them (sphere_tracing_renderer.py:144-205) */
+    int   k4_batch_slots;                     /* full queries per forward+backward launch pair (bounds the activation tape: 4.9 KB per slot);
+                                                 0 = default (1 Mi slots = 5 GB) */
 } ra_config;
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 

@@ -57,7 +57,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    DevBuf* bufs[] = {&c->warena, &c->sarena, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
+    DevBuf* bufs[] = {&c->sarena, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
                       &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs,
                       &c->adj_start, &c->adj_list, &c->adj_dfaces};
@@ -96,7 +96,6 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
     std::string err;
     if (ra_pack_weights(c, err)) { ra_set_error("ra_finalize_weights: " + err); return 1; }
     HostNets& H = c->host;
-    if (upload(c->warena, H.warena.data(), H.warena.size() * 2, s)) return 1;
     if (upload(c->sarena, H.sarena.data(), H.sarena.size() * 2, s)) return 1;
     if (upload(c->fwd_arena, H.fwd_arena.data(), H.fwd_arena.size() * 2, s)) return 1;
     if (upload(c->bwd_arena, H.bwd_arena.data(), H.bwd_arena.size() * 2, s)) return 1;
@@ -191,6 +190,11 @@ DevCounters* dcnt(ra_ctx* c) { return c->dcounters.as<DevCounters>(); }
 int* icnt(ra_ctx* c, int k) { return reinterpret_cast<int*>(c->dcounters.as<char>() + 128) + k; }   // small int counters
 enum { CNT_FINE = 0, CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3 };
 
+void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s) {
+    if (c->cfg.mlp_f16) launch_mlp_sdf_stream_f16(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, s);
+    else launch_mlp_sdf_stream_bf16(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, s);
+}
+
 // one hierarchical distance query over the points of rs; writes sdf[n]
 int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s) {
     if (n <= 0) return 0;
@@ -207,27 +211,36 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
-        static const int gen = getenv("RA_MLP_GEN") ? atoi(getenv("RA_MLP_GEN")) : 3;     // 1, 2: earlier generations (A/B)
-        if (gen == 3) launch_mlp_sdf_stream(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
-        else if (gen == 2) launch_mlp_sdf_pipe(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
-        else launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+        k3_launch(c, io, n, s);
     }
     return 0;
 }
 
-// the full query on the compacted fine list: second generation (forward with tape + reverse-mode backward + heads) for f16,
-// the forward-mode first generation for bf16 or RA_K4_GEN=1 (A/B)
-int full_query(ra_ctx* c, const FullIO& io, int n, hipStream_t s) {
-    static const int gen = getenv("RA_K4_GEN") ? atoi(getenv("RA_K4_GEN")) : 2;
+// the full query on the compacted fine list: forward with tape + reverse-mode backward + heads, in sub-batches of
+// cfg.k4_batch_slots fine slots that share ONE tape (4.9 KB per slot).  n is only the upper bound of the device-side
+// count: launch pairs beyond it find no tile and exit at once.
+int full_query(ra_ctx* c, FullIO io, int n, hipStream_t s) {
     Timer t(c, s, 1);
-    if (gen == 2 && c->cfg.mlp_f16) {
-        int err = 0;
-        char* tape = c->buf<char>("k4_tape", mlp_full_rev_tape_bytes(n), &err);
-        if (err) return 1;
-        launch_mlp_fwd_tape(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, n, s);
-        launch_mlp_bwd_heads(c->host.mat, c->host.col, c->bwd_arena.p, c->host.bwd_frags, c->barena.as<float>(), c->shead_row.as<float>(), c->fr, io, tape, n, s);
-    } else {
-        launch_mlp_full(c->host.geo, c->host.mat, c->host.col, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+    const int batch = c->cfg.k4_batch_slots > 0 ? c->cfg.k4_batch_slots : (1 << 20);
+    const int cap = n < batch ? n : batch;
+    int err = 0;
+    char* tape = c->buf<char>("k4_tape", mlp_full_rev_tape_bytes(cap), &err);
+    if (err) {
+        ra_set_error("full query: no device memory for the activation tape (" + std::to_string(mlp_full_rev_tape_bytes(cap) >> 20) +
+                     " MB): lower cfg.k4_batch_slots / cfg.volume_chunk_rays");
+        return 1;
+    }
+    const bool f16w = c->cfg.mlp_f16 != 0;
+    for (int s0 = 0; s0 < n; s0 += cap) {
+        io.slot0 = s0;
+        io.slot_cap = n - s0 < cap ? n - s0 : cap;
+        if (f16w) {
+            launch_mlp_fwd_tape_f16(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, s);
+            launch_mlp_bwd_heads_f16(c->host.mat, c->host.col, c->bwd_arena.p, c->barena.as<float>(), c->shead_row.as<float>(), c->fr, io, tape, s);
+        } else {
+            launch_mlp_fwd_tape_bf16(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, s);
+            launch_mlp_bwd_heads_bf16(c->host.mat, c->host.col, c->bwd_arena.p, c->barena.as<float>(), c->shead_row.as<float>(), c->fr, io, tape, s);
+        }
     }
     return 0;
 }
@@ -316,7 +329,7 @@ int ra_observed_sdf(ra_ctx* c, const float* bpts, int n, float* sdf, void* strea
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
-        launch_mlp_sdf_stream(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+        k3_launch(c, io, n, s);
     }
     RA_HIP(hipGetLastError());
     return 0;
@@ -391,12 +404,6 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
     return 0;
 }
 
-// RA_NO_SKIP=1 re-queries rays that did not move / are already fully shadowed (A/B: the images must be bit-identical)
-static bool skip_enabled() {
-    static const bool on = !(getenv("RA_NO_SKIP") && atoi(getenv("RA_NO_SKIP")));
-    return on;
-}
-
 // light_visibility (sphere_tracing_renderer.py:265-344) for the hit slots of one chunk: per (slot, light) cosine and
 // visibility; rays that face the light and cross the box are sphere traced with the DFSS state machine (HOT LOOP B).
 static int light_visibility_stage(ra_ctx* c, const float* surf, const float* norm_slots, const float* acc, const int* hit_idx,
@@ -435,7 +442,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         RaySet r2{};
         r2.mode = 2; r2.o = surf; r2.t = sh.t; r2.pix = g.ray_pix; r2.light = g.ray_light; r2.ldir = c->light_dir.as<float>();
         r2.n_dev = g.ray_count;
-        r2.skip = skip_enabled() ? sh.stuck : nullptr;
+        r2.skip = c->cfg.query_skip ? sh.stuck : nullptr;
         for (int it = 0; it < shadow.iters; ++it) {
             if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
             launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
@@ -491,7 +498,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     ts.near_ = near_; ts.far_ = far_;
     launch_trace_init(ts, P, nullptr, p->surface, s);
     RaySet rs{};
-    rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t; rs.skip = skip_enabled() ? ts.stuck : nullptr;
+    rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t; rs.skip = c->cfg.query_skip ? ts.stuck : nullptr;
     for (int it = 0; it < p->surface.iters; ++it) {
         if (hdq_pass(c, rs, P, p->surface.dist_th, 1, sdf, s)) return 1;
         launch_trace_update(ts, sdf, P, nullptr, it, p->surface, s);
@@ -1019,19 +1026,21 @@ int ra_get_mlp_time(ra_ctx* c, float* ms, int* n_launches, void* stream) { retur
 
 // ---- test hooks: stage outputs for parity tests (not used by the renderers) -------------------
 int ra_debug_mlp(ra_ctx* c, const float* bpts, int n, float* resd, float* sdf, float* feat, void* stream) {
+    // stage outputs of the geometry networks from the PRODUCTION forward kernel of the full query (K4 forward with tape)
     if (check_ready(c, "ra_debug_mlp")) return 1;
     if (n <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
-    int* cnt = icnt(c, CNT_FINE);
     int* idx = c->buf<int>("fine_idx", n, &err);
+    char* tape = c->buf<char>("k4_tape", mlp_full_rev_tape_bytes(n), &err);
     if (err) return 1;
-    RA_HIP(hipMemcpyAsync(cnt, &n, sizeof(int), hipMemcpyHostToDevice, s));
-    RA_HIP(hipStreamSynchronize(s));
-    MlpIO io{};
-    io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = nullptr; io.dist_th = 1.f; io.smooth = 0; io.resd_limit = c->cfg.resd_limit;
-    io.dbg_resd = resd; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
-    launch_mlp_sdf(c->host.geo, c->warena.p, c->barena.as<float>(), c->fr, io, n, c->cfg.mlp_f16 != 0, s);
+    launch_iota(idx, n, icnt(c, CNT_FINE), s);
+    FullIO io{};
+    io.bpts = bpts; io.idx = idx; io.count = icnt(c, CNT_FINE); io.slot0 = 0; io.slot_cap = n; io.C = c->cfg.relight ? 17 : 16;
+    io.beta = c->host.beta; io.resd_limit = c->cfg.resd_limit; io.relight = c->cfg.relight;
+    io.dbg_resd = resd; io.dbg_sdf = sdf; io.dbg_feat = feat; io.dbg_layer = -1;
+    if (c->cfg.mlp_f16) launch_mlp_fwd_tape_f16(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, s);
+    else launch_mlp_fwd_tape_bf16(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, s);
     RA_HIP(hipGetLastError());
     return 0;
 }
@@ -1059,9 +1068,12 @@ int ra_debug_full(ra_ctx* c, const float* bpts, int n, float* grad, float* sdf, 
     io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
     io.relight = c->cfg.relight;
     io.dbg_grad = grad; io.dbg_sdf = sdf; io.dbg_feat = feat; io.counters = nullptr;
-    if (getenv("RA_DBG_GC")) { io.dbg_gc = grad; io.dbg_grad = nullptr; }       // debugging aid: d sdf / d cpts instead
-    io.dbg_layer = getenv("RA_DBG_LAYER") ? atoi(getenv("RA_DBG_LAYER")) : -1;
+    io.dbg_layer = -1;
+#ifdef RA_TESTING            // debugging aids of tools/dbg_grad.py (test builds only)
+    if (getenv("RA_DBG_GC")) { io.dbg_gc = grad; io.dbg_grad = nullptr; }       // d sdf / d cpts instead
+    if (getenv("RA_DBG_LAYER")) io.dbg_layer = atoi(getenv("RA_DBG_LAYER"));
     if (getenv("RA_DBG_PE")) { io.dbg_pe = feat; io.dbg_feat = nullptr; RA_HIP(hipMemsetAsync(feat, 0, (size_t)n * 256 * 4, s)); }   // encoding-slot gradients in feat[:, :128]
+#endif
     if (full_query(c, io, n, s)) return 1;
     RA_HIP(hipGetLastError());
     return 0;

@@ -16,15 +16,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // ---------------------------------------------------------------------------------------------
-// Packed network (bf16, MFMA fragment order) — built by ra_pack.cpp, consumed by ra_mlp.hip.
-// A "wide" layer has 256 output rows; its weights are stored as
-//   [nb = 8 row blocks of 32][ks = K/16][lane = 64][8 bf16]
-// so that one wave-wide 16-byte load per lane yields the A fragment of
-// v_mfma_f32_32x32x16_bf16 (lane l: row 32*nb + (l&31), k = 16*ks + 8*(l>>5) + 0..7).
-// A "head" layer has <= 32 output rows and the same layout with nb = 1.
-// Offsets are in units of bf16x8 (16 bytes) into the weight arena, biases in floats.
+// Network description — built by ra_pack.cpp.  The 16-bit weights live in the streams the kernels consume in order
+// (ra_pack.cpp StreamBuilder: forward stream of K3 / K4, backward stream of K4); a layer only records where its fp32 bias
+// row starts in the bias arena (256 floats for a wide layer, 32 for a head) and its K depth in 16-wide k-steps.
 // ---------------------------------------------------------------------------------------------
-struct WideLayer { uint32_t w; uint32_t ks; uint32_t bias; };
+struct WideLayer { uint32_t ks; uint32_t bias; };
 
 struct GeoNet {             // residual deformation + signed distance networks
     // residual net (base_network.py:14-42): L0 K=64 (PE10 padded), L1-3, L4 = L4a (K=256) + L4b (K=64, PE skip), L5-7, head 3
@@ -51,11 +47,6 @@ struct ColNet {             // RenderNetwork (base_network.py:132-171)
     WideLayer c1, c2, c3;   // c3's cond slice folded into a per-frame bias
     WideLayer chead;        // 256 -> 3
 };
-
-// tile geometry of the fused MLP kernels
-constexpr int TM = 128;     // columns (points, or point x {primal,tx,ty,tz}) per workgroup tile
-constexpr int XS = 264;     // LDS row stride in bf16 (528 B = 16 * 33: conflict-free ds_read_b128)
-constexpr int MLP_THREADS = 256;
 
 struct FrameState {         // device pointers owned by the ctx
     float* R;        // 9
@@ -88,19 +79,16 @@ struct MlpIO {
     float dist_th;
     int smooth;
     float resd_limit;
-    // debug / stage outputs (nullable)
-    float* dbg_resd;        // n_slots x 3
-    float* dbg_sdf;         // n_slots (raw network sdf)
-    float* dbg_feat;        // n_slots x 256
     DevCounters* counters;  // nullable
 };
 
-struct FullIO {             // geometry + material / colour forward with tangents
+struct FullIO {             // the full query: geometry with normal + material / colour heads
     const float* bpts;      // n_slots x 3
     const float* mats;      // n_slots x 24 (A_bw rows | big_A_bw rows), nullable -> identity
     const float* view;      // n_points x 3 world view dirs (AniSDF), nullable
     const int* idx;
-    const int* count;
+    const int* count;       // device: fine slots of the whole compacted list
+    int slot0, slot_cap;    // this launch pair handles slots [slot0, min(slot0 + slot_cap, *count)) — the tape is sized for slot_cap
     float* raw;             // n_points x C, scattered by idx
     int C;
     float beta;             // clamp(_beta, 1e-9, 1e6)
@@ -111,30 +99,29 @@ struct FullIO {             // geometry + material / colour forward with tangent
     float* dbg_grad;        // n_slots x 3  d sdf / d bpts
     float* dbg_feat;        // n_slots x 256
     float* dbg_sdf;         // n_slots
-    float* dbg_gc;          // n_slots x 3  d sdf / d cpts (second-generation kernel only)
+    float* dbg_resd;        // n_slots x 3
+    float* dbg_gc;          // n_slots x 3  d sdf / d cpts
     float* dbg_pe;          // n_slots x 128 gradients wrt the encoding slots [sdf h0 | sdf h1 | resd h0 | resd h1] (debugging aid, pre-zeroed)
     int dbg_layer;          // debugging aid: which delta (B fragments) of the backward pass goes to dbg_pe (n_slots x 256), -1 = encoding slots
     DevCounters* counters;  // nullable
 };
 
-// f16w: weights/activations are IEEE half (true) or bfloat16 (false); the arena was packed accordingly
-void launch_mlp_sdf(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr,
-                    const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
-// second-generation K3 (ra_mlp_pipe.hip): one 8-wave workgroup per CU, epilogue interleaved with the MFMA stream
-void launch_mlp_sdf_pipe(const GeoNet& net, const void* warena, const float* barena, const FrameState& fr,
-                         const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
-// third-generation K3 (ra_mlp_stream.hip): activations stay in registers, weights stream through LDS (sarena: ra_pack.cpp StreamBuilder)
-void launch_mlp_sdf_stream(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr,
-                           const MlpIO& io, int max_slots, bool f16w, hipStream_t stream);
-void launch_mlp_full(const GeoNet& net, const MatNet& mat, const ColNet& col, const void* warena,
-                     const float* barena, const FrameState& fr, const FullIO& io, int max_slots, bool f16w, hipStream_t stream);
+// K3 (ra_k3.hpp): HDQ fine distance query; activations stay in registers, weights stream through LDS (sarena: ra_pack.cpp StreamBuilder).
+// One translation unit per operand type: IEEE half (production) and bfloat16.
+void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
+                               hipStream_t stream);
+void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
+                                hipStream_t stream);
 
-// second-generation K4 (ra_mlp_grad.hip): forward with tape + reverse-mode backward + heads, f16 only
-size_t mlp_full_rev_tape_bytes(int max_slots);
-void launch_mlp_fwd_tape(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape,
-                         int max_slots, hipStream_t stream);
-void launch_mlp_bwd_heads(const MatNet& mat, const ColNet& col, const void* bwd_arena, int bwd_frags, const float* barena, const float* shead_row,
-                          const FrameState& fr, const FullIO& io, const char* tape, int max_slots, hipStream_t stream);
+// K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list
+size_t mlp_full_rev_tape_bytes(int slots);
+int mlp_full_rev_bwd_stages(int relight);       // 16-fragment stages of the backward stream the kernels are compiled for
+void launch_mlp_fwd_tape_f16(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape, hipStream_t stream);
+void launch_mlp_fwd_tape_bf16(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape, hipStream_t stream);
+void launch_mlp_bwd_heads_f16(const MatNet& mat, const ColNet& col, const void* bwd_arena, const float* barena, const float* shead_row, const FrameState& fr,
+                              const FullIO& io, const char* tape, hipStream_t stream);
+void launch_mlp_bwd_heads_bf16(const MatNet& mat, const ColNet& col, const void* bwd_arena, const float* barena, const float* shead_row, const FrameState& fr,
+                               const FullIO& io, const char* tape, hipStream_t stream);
 
 // --- error plumbing ---------------------------------------------------------------------------
 void ra_set_error(const std::string& msg);

@@ -8,8 +8,7 @@ struct HostNets {
     ColNet col{};
     bool has_color = false;
     float beta = 0.1f;
-    std::vector<uint16_t> warena;
-    std::vector<uint16_t> sarena;      // gen-3 K3 weight stream (consumption order, 1952 fragments of 1 KB)
+    std::vector<uint16_t> sarena;      // K3 weight stream (consumption order, 1952 fragments of 1 KB)
     std::vector<uint16_t> fwd_arena;   // K4 forward stream: sarena + the 256 feature rows (2080 fragments)
     std::vector<uint16_t> bwd_arena;   // K4 backward stream: transposed geometry layers, then the material / colour head
     int bwd_geo_frags = 0, bwd_frags = 0;
@@ -34,7 +33,7 @@ struct ra_ctx {
     std::map<std::string, std::vector<float>> state_dict;
     HostNets host;
     // device copies
-    DevBuf warena, sarena, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
+    DevBuf sarena, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
     int n_lights = 0;
     // frame
     FrameState fr{};

@@ -510,12 +510,16 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     if (n <= 0) return;
     const float inv2r2 = 1.f / (2.f * blend_radius * blend_radius);
     const dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS);
-    static const int dbg = getenv("RA_COARSE_DBG") ? atoi(getenv("RA_COARSE_DBG")) : 0;   // profiling aid: 1 skip the search, 2 skip everything after it
-    // profiling aid: an extra launch in ablation mode `probe` on the SAME inputs before every real launch (the real
-    // launch then overwrites its outputs), so that the ablated time can be read from a kernel trace (odd/even calls)
-    static const int probe = getenv("RA_COARSE_PROBE") ? atoi(getenv("RA_COARSE_PROBE")) : 0;
     // launches below ~1.5 waves per SIMD are latency-bound: spread each group of 64 queries over the 4 waves of a workgroup
-    static const int split_max = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 98304;
+    int dbg = 0, probe = 0, split_max = 98304;
+#ifdef RA_TESTING            // profiling aids (test builds only, tools/build_variant.sh)
+    // RA_COARSE_DBG: 1 skip the search, 2 skip everything after it.  RA_COARSE_PROBE: an extra launch in ablation mode `probe` on the
+    // SAME inputs before every real launch (which then overwrites its outputs): the ablated time is read from a kernel trace
+    static const int e_dbg = getenv("RA_COARSE_DBG") ? atoi(getenv("RA_COARSE_DBG")) : 0;
+    static const int e_probe = getenv("RA_COARSE_PROBE") ? atoi(getenv("RA_COARSE_PROBE")) : 0;
+    static const int e_split = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 98304;
+    dbg = e_dbg; probe = e_probe; split_max = e_split;
+#endif
     for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
         const int d = pass == 0 ? probe : dbg;
         if (fr.bvh_leaves > 0 && n <= split_max)

@@ -1,5 +1,5 @@
-// K3, third generation: HDQ fine query (resd + sdf MLPs) with register-resident activations and the
-// weights streamed through LDS.
+// K3: HDQ fine query (resd + sdf MLPs) with register-resident activations and the weights streamed through LDS.
+// Implementation header: ra_k3_f16.hip / ra_k3_bf16.hip instantiate it for one operand type each (parallel builds).
 //
 // The first two generations keep the 128-point activation tile in LDS: every layer stores 64 KB of
 // activations with 8-byte ds_writes (~80 B/clk/CU on gfx950, and the store transfer is not hidden by
@@ -23,6 +23,17 @@
 //     5 VALU ops per element; the scale lives in the weights fed by the unscaled encoding and in the biases.
 //   reference: lib/networks/deform/base_network.py:34-42,78-87,374-382; lib/utils/net_utils.py:1263-1273,1337-1352
 #include "ra_stream.hpp"
+
+#ifdef RA_TIMESTAMPS
+// Instrumented variant (tools/build_variant.sh ... "-DRA_TIMESTAMPS", tools/k3_timestamps.py): wave 0 of every workgroup records
+// s_memtime at the layer boundaries of its first tile.  48 slots per workgroup: [0] tile start, [1..9] after resd L0..L7 + head,
+// [10..18] after sdf L0..L7 + head, [19] tile end, [20] last tile end, [21] tiles done, [22] XCC id.  Costs a few % (MI355X_MICROARCH.md).
+__device__ long long ra_k3_ts[256 * 48];
+extern "C" int ra_k3_read_timestamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ra_k3_ts), sizeof(ra_k3_ts)); }
+#define RA_STAMP(p, k) do { if (p) { __builtin_amdgcn_sched_barrier(0); (p)[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define RA_STAMP(p, k) do { } while (0)
+#endif
 
 namespace {
 
@@ -62,25 +73,34 @@ __device__ __forceinline__ void pe_frags(u32x4 (&Bp)[4], const float (&x)[3], in
 
 // one network: L0 (encoding) .. L7, then the <= 32-row head; returns the head accumulator (bias included)
 template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO>
-__device__ __forceinline__ f32x16 run_net(Pipe<E, NW>& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h) {
+__device__ __forceinline__ f32x16 run_net(Pipe<E, NW>& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h, long long* ts) {
     u32x4 B0[16], B1[16], Bp[4];
     f32x16 accA, accB;
     pe_frags<E, PEL, LO>(Bp, x, h);
     // every layer starts on a stage boundary (32, 128, 160 and 16 fragments are multiples of 16)
     layer<E, NW, 4, ACT, ACT, false>(P, accA, accB, B0 /* unused */, Bp, B0, bias, h);
+    RA_STAMP(ts, 0);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 256, h);
+    RA_STAMP(ts, 1);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 512, h);
+    RA_STAMP(ts, 2);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 768, h);
+    RA_STAMP(ts, 3);
     layer<E, NW, 20, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1024, h);
+    RA_STAMP(ts, 4);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1280, h);
+    RA_STAMP(ts, 5);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1536, h);
+    RA_STAMP(ts, 6);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1792, h);
+    RA_STAMP(ts, 7);
     row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accA, accB, B1, Bp, B1[14], B1[15], bias + 2048, h);
+    RA_STAMP(ts, 8);
     return accA;
 }
 
 template <typename E, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba,
                                                                       FrameState fr, MlpIO io) {
     __shared__ __attribute__((aligned(16))) StSmem<E> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,7 +135,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, 
 #pragma unroll
     for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
 
+    long long* ts = nullptr;
+#ifdef RA_TIMESTAMPS
+    int tiles_done = 0;
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef RA_TIMESTAMPS
+        ts = (wave == 0 && lane == 0 && tile == (int)blockIdx.x) ? ra_k3_ts + blockIdx.x * 48 : nullptr;
+        RA_STAMP(ts, 0);
+        if (ts) ts += 1;
+#endif
         const int s = tile * ST_TM + wave * 32 + c;
         float x[3] = {0.f, 0.f, 0.f};
         int pidx = 0;
@@ -128,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, 
         // the first ST_PF fragments of the tile (stage 0 of the stream)
         P.template fetch<0>(); P.template fetch<1>(); P.template fetch<2>(); P.template fetch<3>();
         // ---- residual deformation net (ReLU); head: resd = tanh(z) * resd_limit, cpts = bpts + resd
-        const f32x16 hr = run_net<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h);
+        const f32x16 hr = run_net<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h, ts);
         float cp[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -136,7 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, 
             cp[k] = x[k] + __shfl(r, c);
         }
         // ---- signed distance net (softplus, scaled domain); head row 0 = sdf
-        const f32x16 hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h);
+        const f32x16 hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr);
         if (h == 0 && s < count) {
             float d = hs[0] * SP_INV;                                 // head accumulates beta*log2(e) * sdf
             if (io.smooth) {                                          // HDQ blend (base_network.py:374-382)
@@ -146,6 +175,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, 
             io.sdf[pidx] = d;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RA_TIMESTAMPS
+        RA_STAMP(ts, 18);
+        ++tiles_done;
+        if (wave == 0 && lane == 0) {
+            long long* t0 = ra_k3_ts + blockIdx.x * 48;
+            t0[20] = __builtin_readcyclecounter(); t0[21] = tiles_done;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            t0[22] = xcc & 0xf;
+        }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -153,27 +193,26 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_sdf_stream_kernel(GeoNet net, 
 
 }  // namespace
 
-template <int NW>
-static void launch_nw(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io,
-                      int max_slots, bool f16w, hipStream_t stream) {
+template <typename E, int NW>
+static void launch_nw(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
     const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
     const int grid = tiles < 256 ? tiles : 256;     // one workgroup per CU (the weight ring fills its LDS), persistent over tiles
-    if (f16w) hipLaunchKernelGGL((mlp_sdf_stream_kernel<f16, NW>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena, barena, fr, io);
-    else if (NW == 8) hipLaunchKernelGGL((mlp_sdf_stream_kernel<bf16, 8>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena, barena, fr, io);
+    hipLaunchKernelGGL((mlp_sdf_stream_kernel<E, NW>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena, barena, fr, io);
 }
 
-void launch_mlp_sdf_stream(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io,
-                           int max_slots, bool f16w, hipStream_t stream) {
+// A launch that cannot fill the 256 CUs with 256-point tiles is bound by the latency of ONE tile (1952 MFMAs per
+// wave): narrower workgroups put one wave on a SIMD instead of two (86 -> 67 -> 58 us per tile for 8 / 4 / 2 waves).
+// max_slots is only an upper bound of the device-side count: up to 65536 the 4-wave variant needs at most the two
+// rounds that equal one 8-wave round, and one when the real count is below half.  All widths are bit-identical.
+template <typename E>
+static void launch_k3(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
     if (max_slots <= 0) return;
-    // A launch that cannot fill the 256 CUs with 256-point tiles is bound by the latency of ONE tile (1952 MFMAs per
-    // wave): narrower workgroups put one wave on a SIMD instead of two (86 -> 67 -> 58 us per tile for 8 / 4 / 2 waves).
-    // max_slots is only an upper bound of the device-side count: up to 65536 the 4-wave variant needs at most the two
-    // rounds that equal one 8-wave round, and one when the real count is below half.
+    int nw = max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8);
+#ifdef RA_TESTING            // test / experiment builds only (tools/build_variant.sh): force the workgroup width
     static const int force = getenv("RA_STREAM_NW") ? atoi(getenv("RA_STREAM_NW")) : 0;
-    const int nw = !f16w ? 8 : (force ? force : (max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8)));   // bf16 (A/B only): wide variant
-#ifndef RA_STREAM_WIDE_ONLY
-    if (nw == 2) { launch_nw<2>(net, sarena, barena, fr, io, max_slots, f16w, stream); return; }
-    if (nw == 4) { launch_nw<4>(net, sarena, barena, fr, io, max_slots, f16w, stream); return; }
+    if (force) nw = force;
 #endif
-    launch_nw<8>(net, sarena, barena, fr, io, max_slots, f16w, stream);
+    if (nw == 2) launch_nw<E, 2>(net, sarena, barena, fr, io, max_slots, stream);
+    else if (nw == 4) launch_nw<E, 4>(net, sarena, barena, fr, io, max_slots, stream);
+    else launch_nw<E, 8>(net, sarena, barena, fr, io, max_slots, stream);
 }

@@ -1,13 +1,13 @@
-// K4, second generation: the full query (geometry with normal + material / colour heads) in REVERSE mode on the
-// streamed-weight machinery of K3 (ra_stream.hpp).
+// K4: the full query (geometry with normal + material / colour heads) in REVERSE mode on the streamed-weight machinery of
+// K3 (ra_stream.hpp).  Implementation header: ra_k4_{fwd,bwd}_{f16,bf16}.hip instantiate one kernel family each (parallel builds).
 //
 //   reference: forward_geometry + take_gradient   lib/networks/deform/base_network.py:456-494, lib/utils/net_utils.py:1215-1239
 //              material heads                      lib/networks/relight/relight_network.py:45-47,91-104
 //              RenderNetwork                       lib/networks/deform/base_network.py:152-171,496-515
 //
-// The first generation (ra_mlp.hip, mlp_full_kernel) carries three forward-mode tangent columns next to every point: 4x the
-// forward FLOPs on a tile that keeps its activations in LDS.  d sdf / d bpts is a gradient of ONE output, i.e. what reverse
-// mode is for: one forward pass that remembers the activations, one backward pass through the transposed layers.
+// Forward-mode tangents (three columns next to every point, the round-1 kernel) cost 4x the forward FLOPs.  d sdf / d bpts is a
+// gradient of ONE output, i.e. what reverse mode is for: one forward pass that remembers the activations, one backward pass
+// through the transposed layers.
 //
 //   * forward kernel (mlp_fwd_tape_kernel) = K3 + a tape: every hidden row block's packed f16 B fragments (softplus net: the
 //     activations y', from which sigma' = 1 - 2^-y' in the scaled domain; ReLU net: sign bits only, 16 per row block via
@@ -64,6 +64,12 @@ struct EpiAux {
     float* dbg;          // debugging aid: this lane half's 32 encoding-slot gradients are accumulated here (nullable)
 };
 
+// number of fine slots of the sub-batch [slot0, slot0 + slot_cap) of the compacted list (device-side total *io.count)
+__device__ __forceinline__ int batch_count(const FullIO& io) {
+    const int left = *io.count - io.slot0;
+    return left < 0 ? 0 : (left < io.slot_cap ? left : io.slot_cap);
+}
+
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 
 template <typename E>
@@ -81,11 +87,11 @@ struct Epi {
     template <int ks, int e>
     static __device__ __forceinline__ void step(const f32x16& a, float (&ta)[16], float (&tb)[16], u32x4& o0, u32x4& o1, EpiAux& x, int h) {
         constexpr int s0 = (KS == 4) ? (DEPTH ? 0 : e / 4) : (e * (LAST - DEPTH + 1)) / 16;
-        if constexpr (SP) {
-            if constexpr (s0 == ks) { ta[e] = __builtin_amdgcn_exp2f(-__builtin_fabsf(a[e])); tb[e] = max0(a[e]); }
+        if constexpr (SP) {          // ra_stream.hpp, sp_finish
+            if constexpr (s0 == ks) ta[e] = __builtin_amdgcn_exp2f(a[e]);
             if constexpr (s0 + 1 == ks) ta[e] = 1.f + ta[e];
             if constexpr (s0 + 2 == ks) ta[e] = __builtin_amdgcn_logf(ta[e]);
-            if constexpr (s0 + 3 == ks) ta[e] = ta[e] + tb[e];
+            if constexpr (s0 + 3 == ks) ta[e] = sp_finish(ta[e], a[e]);
         } else if constexpr (EPI == EPI_GRAD_SP) {
             if constexpr (s0 == ks) ta[e] = __builtin_amdgcn_exp2f(-half_of<E>(e < 8 ? x.t0[e >> 1] : x.t1[(e >> 1) & 3], e & 1));
             if constexpr (s0 + 1 == ks) ta[e] = __builtin_fmaf(-ta[e], a[e], a[e]);          // a * (1 - 2^-y') = a * sigma'(z)
@@ -297,9 +303,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         else v = ba[net.sfeat.bias + r] * SP_SCALE;
         sm.bias[i] = v;
     }
-    if (tid == 0) sm.count = *io.count;
+    if (tid == 0) sm.count = batch_count(io);
     __syncthreads();
-    const int count = sm.count;
+    const int count = sm.count;             // slots of THIS sub-batch (slot0 .. slot0 + count)
     if (blockIdx.x == 0 && tid == 0 && io.counters) atomicAdd(&io.counters->n_fine_full, (unsigned long long)count);
     const int ntiles = (count + TM - 1) / TM;
     if ((int)blockIdx.x >= ntiles) return;
@@ -308,9 +314,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
     pipe_init(P, stream, sm, wave, lane, NW, FW_STAGES);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int s = tile * TM + wave * 32 + c;
+        const int sl = tile * TM + wave * 32 + c;       // slot inside the sub-batch (the tape's index)
+        const bool live = sl < count;
+        const int s = io.slot0 + sl;                     // slot of the compacted fine list
         float x[3] = {0.f, 0.f, 0.f};
-        if (s < count) { x[0] = io.bpts[3 * s]; x[1] = io.bpts[3 * s + 1]; x[2] = io.bpts[3 * s + 2]; }
+        if (live) { x[0] = io.bpts[3 * s]; x[1] = io.bpts[3 * s + 1]; x[2] = io.bpts[3 * s + 2]; }
         char* tw = tape + ((size_t)tile * NW + wave) * TP_WAVE;
         EpiAux aux;
         aux.bits = 0u; aux.scale = SP_INV; aux.st = nullptr; aux.dbg = nullptr;
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
             flush<E, EPI_LINEAR, 0, false>(accA, B0[14], B0[15], h, aux);
             tape_store2(aux, B0[14], B0[15]);
         }
-        if (DBG && io.dbg_feat && s < count) {          // test hook: features as the heads will see them (f16 values)
+        if (DBG && io.dbg_feat && live) {          // test hook: features as the heads will see them (f16 values)
 #pragma unroll
             for (int k = 0; k < 16; ++k)
 #pragma unroll
@@ -392,7 +400,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_tape_kernel(GeoNet net, co
         if (h == 0) {
             float4 gv = make_float4(cp[0], cp[1], cp[2], sdf);
             *reinterpret_cast<float4*>(tw + TP_GEO + c * 16) = gv;
-            if (DBG && io.dbg_sdf && s < count) io.dbg_sdf[s] = sdf;
+            if (DBG && io.dbg_sdf && live) io.dbg_sdf[s] = sdf;
+            if (DBG && io.dbg_resd && live) { io.dbg_resd[3 * s] = cp[0] - x[0]; io.dbg_resd[3 * s + 1] = cp[1] - x[1]; io.dbg_resd[3 * s + 2] = cp[2] - x[2]; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
         }
         sm.bias[i] = v;
     }
-    if (tid == 0) sm.count = *io.count;
+    if (tid == 0) sm.count = batch_count(io);
     __syncthreads();
     const int count = sm.count;
     const int ntiles = (count + TM - 1) / TM;
@@ -564,10 +573,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
     Pipe<E, NW, STAGES> P;
     pipe_init(P, stream, sm, wave, lane, NW, STAGES);
 
-
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int s = tile * TM + wave * 32 + c;
-        const bool live = s < count;
+        const int sl = tile * TM + wave * 32 + c;
+        const bool live = sl < count;
+        const int s = io.slot0 + sl;
         const char* tw = tape + ((size_t)tile * NW + wave) * TP_WAVE;
         float x[3] = {0.f, 0.f, 0.f};
         if (live) { x[0] = io.bpts[3 * s]; x[1] = io.bpts[3 * s + 1]; x[2] = io.bpts[3 * s + 2]; }
@@ -803,31 +812,34 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_heads_kernel(MatNet mat, C
 
 }  // namespace
 
-size_t mlp_full_rev_tape_bytes(int max_slots) { return (size_t)((max_slots + 255) / 256) * 8 * TP_WAVE + 4096; }     // whole 256-point tiles
+// tape of a sub-batch of `slots` fine slots (whole 256-point tiles)
+static size_t k4_tape_bytes(int slots) { return (size_t)((slots + 255) / 256) * 8 * TP_WAVE + 4096; }
 
-void launch_mlp_fwd_tape(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape,
-                         int max_slots, hipStream_t stream) {
-    if (max_slots <= 0) return;
+template <typename E>
+static void launch_k4_fwd(const GeoNet& net, const void* fwd_arena, const float* barena, const FrameState& fr, const FullIO& io, char* tape, hipStream_t stream) {
+    if (io.slot_cap <= 0) return;
     constexpr int NW = RA_K4_NW_F;
-    const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
+    const int tiles = (io.slot_cap + 32 * NW - 1) / (32 * NW);
     const int grid = tiles < 256 ? tiles : 256;
-    if (io.dbg_feat || io.dbg_sdf) hipLaunchKernelGGL((mlp_fwd_tape_kernel<f16, NW, true>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
-    else hipLaunchKernelGGL((mlp_fwd_tape_kernel<f16, NW, false>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
+    if (io.dbg_feat || io.dbg_sdf || io.dbg_resd) hipLaunchKernelGGL((mlp_fwd_tape_kernel<E, NW, true>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
+    else hipLaunchKernelGGL((mlp_fwd_tape_kernel<E, NW, false>), dim3(grid), dim3(64 * NW), 0, stream, net, fwd_arena, barena, fr, io, tape);
 }
 
-void launch_mlp_bwd_heads(const MatNet& mat, const ColNet& col, const void* bwd_arena, int bwd_frags, const float* barena, const float* shead_row,
-                          const FrameState& fr, const FullIO& io, const char* tape, int max_slots, hipStream_t stream) {
-    if (max_slots <= 0) return;
+constexpr int BW_STAGES_RELIGHT = 139, BW_STAGES_ANISDF = 157;      // backward stream: geometry (transposed) + material heads / colour net
+
+template <typename E>
+static void launch_k4_bwd(const MatNet& mat, const ColNet& col, const void* bwd_arena, const float* barena, const float* shead_row, const FrameState& fr,
+                          const FullIO& io, const char* tape, hipStream_t stream) {
+    if (io.slot_cap <= 0) return;
     constexpr int NW = RA_K4_NW_B;
-    const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
+    const int tiles = (io.slot_cap + 32 * NW - 1) / (32 * NW);
     const int grid = tiles < 256 ? tiles : 256;
     const bool dbg = io.dbg_grad || io.dbg_gc || io.dbg_pe;
     if (io.relight) {
-        if (dbg) hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 139, true, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
-        else hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 139, true, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+        if (dbg) hipLaunchKernelGGL((mlp_bwd_heads_kernel<E, NW, BW_STAGES_RELIGHT, true, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+        else hipLaunchKernelGGL((mlp_bwd_heads_kernel<E, NW, BW_STAGES_RELIGHT, true, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
     } else {
-        if (dbg) hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 157, false, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
-        else hipLaunchKernelGGL((mlp_bwd_heads_kernel<f16, NW, 157, false, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+        if (dbg) hipLaunchKernelGGL((mlp_bwd_heads_kernel<E, NW, BW_STAGES_ANISDF, false, true>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
+        else hipLaunchKernelGGL((mlp_bwd_heads_kernel<E, NW, BW_STAGES_ANISDF, false, false>), dim3(grid), dim3(64 * NW), 0, stream, mat, col, bwd_arena, barena, shead_row, fr, io, tape);
     }
-    (void)bwd_frags;
 }

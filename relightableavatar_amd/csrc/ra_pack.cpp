@@ -1,4 +1,4 @@
-// Host-side weight packer: reference state_dict (fp32) -> f16/bf16 MFMA fragment order.
+// Host-side weight packer: reference state_dict (fp32) -> f16/bf16 weight streams in MFMA fragment order.
 //   weight_norm fold  W = g * v / |v|_row          lib/utils/net_utils.py:1326-1327, base_network.py:145-149
 //   SDF skip          cat([x, inputs]) / sqrt(2)   lib/utils/net_utils.py:1345-1346 (folded into lin4)
 //   resd skip         cat([x, input])              lib/utils/net_utils.py:1266-1267 (x first)
@@ -36,38 +36,24 @@ uint16_t f2h(float f) {    // IEEE half, round to nearest even (clang's _Float16
     return u;
 }
 
-struct Packer {
-    std::vector<uint16_t> w;    // 16-bit element arena (multiple of 8 elements)
-    std::vector<float> b;       // bias arena
+struct Packer {                 // layer table + fp32 bias arena (the 16-bit weights go to the streams below)
+    std::vector<float> b;
     bool half = false;          // f16 (true) or bf16 (false)
 
-    // M: [rows<=256 or <=32][K], K multiple of 16 after padding
+    // M: [rows<=256 or <=32][K]; records the layer's K depth and appends its bias row (padded to n_rows_pad)
     WideLayer add(const Mat& M, const std::vector<float>& bias, int n_rows_pad, int k_min = 0) {
         int K = (M.cols + 15) / 16 * 16;
         if (K < k_min) K = k_min;
-        const int KS = K / 16, NB = n_rows_pad / 32;
         WideLayer L;
-        L.w = (uint32_t)(w.size() / 8);
-        L.ks = (uint32_t)KS;
+        L.ks = (uint32_t)(K / 16);
         L.bias = (uint32_t)b.size();
-        w.resize(w.size() + (size_t)NB * KS * 64 * 8, 0);
-        uint16_t* o = w.data() + (size_t)L.w * 8;
-        for (int nb = 0; nb < NB; ++nb)
-            for (int ks = 0; ks < KS; ++ks)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 8; ++e) {
-                        const int row = nb * 32 + (lane & 31), col = ks * 16 + (lane >> 5) * 8 + e;
-                        float val = 0.f;
-                        if (row < M.rows && col < M.cols) val = M.at(row, col);
-                        o[(((size_t)nb * KS + ks) * 64 + lane) * 8 + e] = half ? f2h(val) : f2bf(val);
-                    }
         for (int r = 0; r < n_rows_pad; ++r) b.push_back(r < (int)bias.size() ? bias[r] : 0.f);
         while (b.size() % 4) b.push_back(0.f);
         return L;
     }
 };
 
-// ---- gen-3 K3 weight stream (ra_mlp_stream.hip): fragments in the exact order the kernel consumes them,
+// ---- K3 weight stream (ra_k3.hpp): fragments in the exact order the kernel consumes them,
 // [layer][row block rb][k-step][lane][8], K indices permuted so that the packed D fragment of one layer IS the
 // B fragment of the next (no LDS round trip for activations):
 //   hidden k-step ks, lane half h, slot j  <->  feature 32*(ks>>1) + 16*(ks&1) + 8*(j>>2) + 4*h + (j&3)
@@ -332,7 +318,7 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         if (!get(sd, "light_xyz_", H.light_xyz) || !get(sd, "light_area", H.light_area) || !get(sd, "light_sharp", H.light_sharp)) { err = "missing light_xyz_/light_area/light_sharp"; return 1; }
         if (H.light_xyz.size() != H.light_area.size() * 3 || H.light_area.size() != H.light_sharp.size() || H.light_area.size() > RA_N_LIGHTS_MAX) { err = "bad light buffer shapes"; return 1; }
     }
-    {   // gen-3 stream: resd L0..L7, head, sdf L0..L7, head.  The softplus layers work in the scaled domain
+    {   // K3 stream: resd L0..L7, head, sdf L0..L7, head.  The softplus layers work in the scaled domain
         // y' = y * beta*log2(e) (beta = 100): only the layers fed by the unscaled encoding carry the factor.
         StreamBuilder S;
         S.half = P.half;
@@ -344,8 +330,8 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         if (S.w.size() != (size_t)1952 * 512) { err = "internal: weight stream has " + std::to_string(S.w.size() / 512) + " fragments, expected 1952"; return 1; }
         H.sarena = S.w;
     }
-    {   // K4 (reverse mode) streams, same fragment order / K permutation as the gen-3 stream.
-        // forward: the gen-3 stream + the 256 feature rows of lin8 (head output, no activation; unscaled weights on scaled inputs)
+    {   // K4 (reverse mode) streams, same fragment order / K permutation as the K3 stream.
+        // forward: the K3 stream + the 256 feature rows of lin8 (head output, no activation; unscaled weights on scaled inputs)
         StreamBuilder F;
         F.half = P.half;
         F.w = H.sarena;
@@ -392,13 +378,17 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
             B.add(&C3, nullptr, pe_chan_col, 256, 1.f);
             B.add(&Chead, nullptr, pe_chan_col, 32, 1.f);
         }
-        if ((B.w.size() / 512) % 16) { err = "internal: backward stream is not a whole number of stages"; return 1; }
         H.bwd_arena = B.w;
         H.bwd_frags = (int)(B.w.size() / 512);
+        // the backward kernels walk a stream of compile-time length: a state_dict / cfg that changes it must fail here, not read a misaligned stream
+        if ((c.relight || H.has_color) && H.bwd_frags != 16 * mlp_full_rev_bwd_stages(c.relight)) {
+            err = "backward stream of the full query has " + std::to_string(H.bwd_frags) + " fragments, the kernels are built for " +
+                  std::to_string(16 * mlp_full_rev_bwd_stages(c.relight)) + " (cond / view / xyz dimensions differ from the compiled variant)";
+            return 1;
+        }
         H.shead_row.assign(256, 0.f);
         for (int k = 0; k < 256; ++k) H.shead_row[k] = Shead.at(0, k);
     }
-    H.warena = P.w;
     H.barena = P.b;
     return 0;
 }

@@ -65,12 +65,17 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // wrong values as soon as the scheduler places it right behind the producing MFMA)
 __device__ __forceinline__ float max0(float z) { return __builtin_amdgcn_fmed3f(z, 0.f, 3.0e38f); }     // finite bound: with +inf LLVM folds it back to two v_max
 
+// scaled-domain softplus y' = log2(1 + 2^z'), z' = beta*log2(e) * pre-activation, in FOUR VALU ops per element:
+// v_exp, v_add, v_log and ONE v_med3 that also handles the overflow of 2^z' (z' >= 128: log2(1 + inf) = inf):
+// c = log2(1 + 2^z) lies in [z, 64] for z <= 64, so med3(c, z, 64) = c there, and c >= z > 64 beyond, where med3 = z =
+// softplus to fp32 precision (the next term is 2^-64).  The earlier form max(z, 0) + log2(1 + 2^-|z|) took five; the kernel is
+// power-limited, so every VALU op per element costs about 1 ns per MFMA slot whether or not it "fits".
+__device__ __forceinline__ float sp_finish(float c, float z) { return __builtin_amdgcn_fmed3f(c, z, 64.f); }
+
 template <int ACT>
 __device__ __forceinline__ float act(float z) {
     if (ACT == ACT_RELU || RA_ABL == 1) return max0(z);
-    // scaled-domain softplus: z = beta*log2(e) * pre-activation, result = beta*log2(e) * softplus
-    const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(z));
-    return max0(z) + __builtin_amdgcn_logf(1.f + e);
+    return sp_finish(__builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(z)), z);
 }
 
 template <typename E> struct StSmem {
@@ -155,7 +160,7 @@ template <typename E, int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool 
 __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4],
                                           u32x4& o0, u32x4& o1, const float* bias_rb, int h) {
     init_acc(acc, bias_rb, h);
-    float ta[16], tb[16];
+    float ta[16];
     static_for<0, KS>([&](auto ks_) {
         constexpr int ks = decltype(ks_)::value;
         const u32x4 bw = (KS == 4) ? Bp[ks & 3] : (ks < 16 ? Bm[ks & 15] : Bp[ks & 3]);
@@ -172,15 +177,15 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
                 constexpr int LAST = (KS == 4) ? 3 : (EARLY ? 13 : KS - 1);
                 constexpr int s0 = (KS == 4) ? 0 : (e * (LAST - DEPTH + 1)) / 16;
                 if constexpr (SP && KS != 4) {
-                    if constexpr (s0 == ks) { ta[e] = __builtin_amdgcn_exp2f(-__builtin_fabsf(accPrev[e])); tb[e] = max0(accPrev[e]); }
+                    if constexpr (s0 == ks) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
                     if constexpr (s0 + 1 == ks) ta[e] = 1.f + ta[e];
                     if constexpr (s0 + 2 == ks) ta[e] = __builtin_amdgcn_logf(ta[e]);
-                    if constexpr (s0 + 3 == ks) ta[e] = ta[e] + tb[e];
+                    if constexpr (s0 + 3 == ks) ta[e] = sp_finish(ta[e], accPrev[e]);
                 } else if constexpr (SP) {          // 4-MFMA row blocks (first layer): one stage of all 16 elements per slot
-                    if constexpr (ks == 0) { ta[e] = __builtin_amdgcn_exp2f(-__builtin_fabsf(accPrev[e])); tb[e] = max0(accPrev[e]); }
+                    if constexpr (ks == 0) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
                     if constexpr (ks == 1) ta[e] = 1.f + ta[e];
                     if constexpr (ks == 2) ta[e] = __builtin_amdgcn_logf(ta[e]);
-                    if constexpr (ks == 3) ta[e] = ta[e] + tb[e];
+                    if constexpr (ks == 3) ta[e] = sp_finish(ta[e], accPrev[e]);
                 } else {
                     // f16: ReLU AFTER the pack (v_cvt_pk + v_pk_max_f16: 1.0 instead of 1.5 VALU per element).  Rounding is monotone
                     // and keeps the sign, so max(round(z), 0) == round(max(z, 0)): bitwise identical distances on 200 k points,

@@ -20,6 +20,28 @@ class Renderer(nn.Module):
         # order the mask means.  Tests set this to reproduce the order of the platform a golden frame was made on.
         self.ground_inds = None
 
+    def _grow_bounds(self, batch):
+        """batch.wbounds -= / += cfg.env_lvis.bbox_margin in place (once per render chunk, :1020-1022 / :1054-1056) and the grown box
+        as six host floats for the chunk's launch.  A batch whose loader kept the host copy it made the box from
+        (`wbounds_host`, e.g. synthetic.to_device) is grown on both sides and costs no device round trip; otherwise the box is
+        read back (one stream sync per chunk, what the reference's own .item() calls cost)."""
+        m = self.cfg.env_lvis.bbox_margin
+        wb = batch.wbounds
+        host = batch.get('wbounds_host', None)
+        if host is not None and wb.is_cuda and batch.get('wbounds_host_version', None) != wb._version:
+            host = None                      # somebody else wrote to the device tensor since the mirror was made: read it back
+        wb[:, 0] -= m
+        wb[:, 1] += m
+        if not wb.is_cuda:
+            return wb[0].reshape(-1).tolist()
+        if host is None:
+            host = wb.detach().cpu()         # one stream sync; the mirror is valid from here on
+        else:
+            host[:, 0] -= m
+            host[:, 1] += m
+        batch['wbounds_host'], batch['wbounds_host_version'] = host, wb._version
+        return host[0].reshape(-1).tolist()
+
     def _envmap(self, batch):
         cfg = self.cfg
         if not self.net.training and cfg.replace_light:
@@ -64,10 +86,9 @@ class Renderer(nn.Module):
             full[k] = torch.zeros((P, w) if w else (P,), device=dev)
         for a, b in (batch.get('render_chunks', None) or chunks(P, cfg.render_chunk_size)):      # render_chunks: a shard's view of the frame's chunks (shard.py)
             # quirk (sphere_tracing_renderer.py:1020-1022): the box grows IN PLACE on the batch every chunk
-            wb = batch.wbounds
-            wb[:, 0] -= cfg.env_lvis.bbox_margin
-            wb[:, 1] += cfg.env_lvis.bbox_margin
-            bbox6 = wb[0].reshape(-1).tolist()
+            bbox6 = self._grow_bounds(batch)
+            if b <= a:
+                continue
             eng.render_sphere_chunk(ray_o[a:b], ray_d[a:b], near[a:b], far[a:b], bbox6, probe, params,
                                     {k: v[a:b] for k, v in full.items()})
         ret = dotdict()
@@ -115,12 +136,20 @@ class Renderer(nn.Module):
         cfg = self.cfg
         dev = eng.device
         H, W = int(batch.meta.H.item()), int(batch.meta.W.item())
-        F = H * W
-        inds = batch.mask_at_box.reshape(-1).to(dev).nonzero()[:, 0] if self.ground_inds is None else self.ground_inds.to(dev)
         big = torch.tensor([[-1e9] * 3, [1e9] * 3])
         rays = eng.gen_rays(H, W, batch.cam_K[0].cpu().numpy(), batch.cam_R[0].cpu().numpy(), batch.cam_T[0].cpu().numpy(), big)
         g_o, g_d = rays.ray_o.contiguous(), rays.ray_d.contiguous()
-        assert g_o.shape[0] == F
+        assert g_o.shape[0] == H * W
+        pix = batch.get('ground_pix', None)
+        if pix is not None:
+            # one rank of a sharded frame (shard.py): its full-frame tiles only; its human rays are a subset of them, so the blend
+            # stays local.  ground_chunks = its pixels per chunk of the WHOLE frame (every chunk grows the box, also an empty one)
+            g_o, g_d = g_o[pix].contiguous(), g_d[pix].contiguous()
+            inds, ranges = batch.ground_inds.to(dev), batch.ground_chunks
+        else:
+            inds = batch.mask_at_box.reshape(-1).to(dev).nonzero()[:, 0] if self.ground_inds is None else self.ground_inds.to(dev)
+            ranges = chunks(H * W, cfg.render_chunk_size)
+        F = g_o.shape[0]
         acc_h = ret.acc_map[0]
         acc_g = torch.ones(F, device=dev)
         acc_g[inds] = 1 - acc_h
@@ -130,11 +159,11 @@ class Renderer(nn.Module):
         if cfg.vis_novel_light:              # cached for the per-probe re-shade (render_ground :541-543; 4 KB per frame pixel)
             L = cfg.env_h * cfg.env_w
             out.lvis, out.ldot = torch.zeros(F, L, device=dev), torch.zeros(F, L, device=dev)
-        for a, b in chunks(F, cfg.render_chunk_size):
-            wb = batch.wbounds
-            wb[:, 0] -= cfg.env_lvis.bbox_margin
-            wb[:, 1] += cfg.env_lvis.bbox_margin
-            eng.render_ground_chunk(g_o[a:b], g_d[a:b], acc_g[a:b], wb[0].reshape(-1).tolist(), probe, gp,
+        for a, b in ranges:
+            bbox6 = self._grow_bounds(batch)
+            if b <= a:
+                continue
+            eng.render_ground_chunk(g_o[a:b], g_d[a:b], acc_g[a:b], bbox6, probe, gp,
                                     {k: v[a:b] for k, v in out.items()})
         n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, device=dev, dtype=torch.float32), dim=0)
         grd = dotdict(rgb_map=out.rgb[None], surf_map=out.surf[None], albedo_map=out.albedo[None], roughness_map=torch.ones(1, F, device=dev),

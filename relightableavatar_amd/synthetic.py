@@ -317,6 +317,16 @@ def make_batch(H: int, W: int, seed: int = 0, posed: bool = True, n_novel_lights
     return b
 
 
+def sample_rays(batch: dotdict, n_target: int):
+    """every stride-th in-box ray of `batch` (in place; rays are independent units, so the sample renders as one chunk and every
+    ray gets the pixel it has in the whole frame up to the per-chunk box growth of the shadow rays).  Returns (batch, P, stride)."""
+    P = batch.ray_o.shape[1]
+    stride = max(1, P // max(1, n_target))
+    for k in ('ray_o', 'ray_d', 'near', 'far'):
+        batch[k] = batch[k][:, ::stride].contiguous()
+    return batch, P, stride
+
+
 def make_novel_lights(n: int, seed: int = 0, env_h: int = 16, env_w: int = 32) -> dotdict:
     lights = dotdict()
     for k in range(n):
@@ -332,10 +342,14 @@ def make_novel_lights(n: int, seed: int = 0, env_h: int = 16, env_w: int = 32) -
 
 
 def to_device(batch, device):
+    """the loader's hand-over (the reference's to_cuda(batch)); small per-frame constants the host needs again (the body's
+    bounding box the renderer grows per chunk) keep a host mirror, so the render loop never reads them back from the device"""
     out = dotdict()
+    if isinstance(batch.get('wbounds', None), torch.Tensor) and not batch['wbounds'].is_cuda:
+        out['wbounds_host'] = batch['wbounds'].clone()
     for k, v in batch.items():
-        if k == 'meta':
-            out[k] = v
+        if k == 'meta' or k.startswith('wbounds_host'):
+            out.setdefault(k, v)
         elif isinstance(v, torch.Tensor):
             out[k] = v.to(device)
         elif isinstance(v, dict):

@@ -194,26 +194,57 @@ def test_shards_carry_the_frames_chunk_boundaries():
     assert 'render_chunks' not in shard.shard_batch(b, 0, 1, chunk)                  # world 1: the batch itself
 
 
-def test_sharded_ground_pass_is_rejected():
-    from relightableavatar_amd.base_utils import dotdict
+def test_ground_pass_is_dealt_by_the_same_tiles():
+    """the full-frame ground pass of a sharded frame: every rank's in-box (human) pixels are a subset of its ground pixels (so the
+    alpha blend of the two layers is rank-local), the ground shards partition the frame, carry the frame's chunk boundaries, and
+    the exchange's index vectors invert the deal"""
+    b = synthetic.make_batch(96, 96, seed=0)
+    P, F = b.ray_o.shape[1], 96 * 96
+    pix = b.mask_at_box.reshape(-1).nonzero()[:, 0]
+    for world in (2, 3, 8):
+        pl = shard.make_plan(P, world, b, ground=True, render_chunk_size=2000)
+        g = pl.ground
+        assert sorted(torch.cat(g.idx).tolist()) == list(range(F))
+        full_chunks = chunks(F, 2000)
+        for r in range(world):
+            sb = shard.shard_batch(b, r, world, 2000, pl, ground=True)
+            assert torch.equal(sb.ground_pix[sb.ground_inds], pix[pl.idx[r]])        # its human rays, found among its ground pixels
+            assert len(sb.ground_chunks) == len(full_chunks) and sb.ground_chunks[-1][1] == sb.ground_pix.numel()
+            for (a, e), (fa, fe) in zip(sb.ground_chunks, full_chunks):
+                assert bool(((sb.ground_pix[a:e] >= fa) & (sb.ground_pix[a:e] < fe)).all())
+            assert sb.mask_at_box is not b.mask_at_box                                # the ground pass overwrites the shard's copy only
+        x = torch.rand(F, 2)
+        stacked = torch.zeros(world * g.n_max, 2)
+        for r in range(world):
+            stacked[r * g.n_max:r * g.n_max + g.idx[r].numel()] = x[g.idx[r]]
+        full = torch.empty(F, 2)
+        full[g.order] = stacked[g.src]
+        assert torch.equal(full, x)
 
-    class R:
-        cfg = make_cfg('relight', vis_ground_shading=True)
-    with pytest.raises(ValueError, match='ground'):
-        shard.render_sharded(R(), synthetic.make_batch(32, 32, seed=0), ('rgb_map',), 0, 2)
 
-
-def test_plan_cache_keys_on_the_live_mask_object():
-    """a new frame's mask at a recycled address must not hit the previous frame's plan"""
+def test_plan_is_keyed_on_the_mask_content():
+    """a new frame's mask at a recycled address, or an in-place edit of the live mask, must not hit another frame's
+    plan — and the same content does, whatever tensor carries it.  use_cache=False always rebuilds (bench.py: a new frame per step)."""
     b1 = synthetic.make_batch(64, 64, seed=0)
     P = b1.ray_o.shape[1]
-    p1 = shard.plan(P, 2, b1)
-    assert shard.plan(P, 2, b1) is p1                                                # same live mask, same version: cached
+    p1 = shard.make_plan(P, 2, b1)
+    assert shard.make_plan(P, 2, b1) is p1
     b2 = synthetic.make_batch(64, 64, seed=0)
     b2.mask_at_box = b1.mask_at_box.clone()
-    assert shard.plan(P, 2, b2) is not p1                                            # another tensor object: recomputed
-    b1.mask_at_box[:] = b1.mask_at_box                                               # in-place write bumps the version
-    assert shard.plan(P, 2, b1) is not p1
+    assert shard.make_plan(P, 2, b2) is p1                                           # same content: same plan
+    assert shard.make_plan(P, 2, b1, use_cache=False) is not p1
+    m = b1.mask_at_box.reshape(-1)
+    on = m.nonzero()[:, 0]
+    m[on[0]] = False                                                                 # in-place edit: one in-box pixel less
+    p3 = shard.make_plan(P - 1, 2, b1)
+    assert p3 is not p1 and sum(p3.counts) == P - 1
+    # a renderer that overwrites the mask between shard and gather (the ground pass does) cannot change the ownership: the plan is explicit
+    pl = shard.make_plan(P, 2, b2)
+    own = pl.idx[0].clone()
+    sb = shard.shard_batch(b2, 0, 2, None, pl)
+    b2.mask_at_box[:] = True
+    assert sb.ray_o.shape[1] == pl.counts[0] and torch.equal(pl.idx[0], own)         # the plan in hand still describes the shard
+    assert not sb.mask_at_box.all()                                                  # and the shard carries its own copy of the mask
 
 
 def test_fixed_material_source_rule():

@@ -1,4 +1,4 @@
-"""A/B: frame with and without the repeated-query skip must be bit-identical (run twice with RA_NO_SKIP=0/1, then compare)."""
+"""A/B: frame with and without the repeated-query skip (cfg.query_skip) must be bit-identical: ab_skip.py OUT.pt [ground] [noskip]; ab_skip.py cmp A.pt B.pt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,8 @@ if sys.argv[1] == 'cmp':
     for k in a: print(k, 'max |diff|', float((a[k] - b[k]).abs().max()), 'equal', bool(torch.equal(a[k], b[k])))
     sys.exit(0)
 dev = torch.device('cuda:0')
-kw = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0]) if len(sys.argv) > 2 else {}
+kw = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0]) if 'ground' in sys.argv[2:] else {}
+kw['query_skip'] = 'noskip' not in sys.argv[2:]
 cfg = make_cfg('relight', **kw)
 net = make_network(cfg); net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg)); net = net.to(dev).eval()
 batch = synthetic.to_device(synthetic.make_batch(256, 256, seed=0, posed=True), dev)

@@ -65,9 +65,90 @@ def novel_ground_floor(emu):
     return {f'{n}.rgb_map': stats(out[n].rgb_map[0], torch.from_numpy(ref[f'{n}.rgb_map'])[0]) for n in ('main', 'probe00', 'probe01')}
 
 
+def novel_floor(emu):
+    """frame_novel.npz (vis_novel_light, three probes, no ground): per-probe rgb of the emulated oracle vs the reference's"""
+    ref = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'frame_novel.npz')))
+    cfg = make_cfg('novel_light')
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg, emulate=emu, kernel_like=True)
+    H = int(ref['H'])
+    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']), n_novel_lights=3)
+    out = O.render_novel_light(net, batch)
+    return {f'{n}.rgb_map': stats(out[n].rgb_map[0], torch.from_numpy(ref[f'{n}.rgb_map'])[0]) for n in ('main', 'probe00', 'probe01', 'probe02')}
+
+
+def ground_floor(emu):
+    """frame_ground.npz (relight + ground-plane pass, blended layers)"""
+    ref = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'frame_ground.npz')))
+    kw = dict(vis_ground_shading=True, ground_normal=[float(v) for v in ref['ground_normal']], ground_origin=[float(v) for v in ref['ground_origin']],
+              render_chunk_size=int(ref['render_chunk_size']))
+    cfg = make_cfg('relight', **kw)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg, emulate=emu, kernel_like=True)
+    H = int(ref['H'])
+    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['crop']))
+    m = batch.mask_at_box.reshape(1, -1)
+    inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]
+    out = O.render_sphere_tracing(net, batch, ground_inds=inds)
+    return {k: stats(out[k][0], torch.from_numpy(ref[k])[0]) for k in ('rgb_map', 'shade_map')}
+
+
+def multi_chunk_floor(emu):
+    """the multi-chunk case of tests/test_gpu_parity.py (128 x 128, crop 8, three render chunks of 24 rays): no golden from the
+    reference exists for it, so the floor is emulated oracle vs fp32 oracle (the same comparand the GPU test uses)"""
+    cfg = make_cfg('relight', render_chunk_size=24)
+    sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+    mk = lambda: synthetic.make_batch(128, 128, seed=0, posed=True, crop=8)
+    ref = O.render_sphere_tracing(O.OracleNet(sd, cfg), mk())
+    out = O.render_sphere_tracing(O.OracleNet(sd, cfg, emulate=emu, kernel_like=True), mk())
+    return {k: stats(out[k][0], ref[k][0]) for k in ('rgb_map', 'shade_map')}
+
+
+def other_pose_floor(emu):
+    """tests/test_gpu_parity.py::test_anisdf_sphere_tracing_vs_oracle_other_pose (identity pose, seed 3, AniSDF colour net through the
+    sphere-tracing renderer): emulated oracle vs fp32 oracle, the comparand of that test"""
+    cfg = make_cfg('sphere_tracing')
+    sd = synthetic.make_state_dict(0, relight=False, cfg=cfg)
+    mk = lambda: synthetic.make_batch(96, 96, seed=3, posed=False, crop=16)
+    ref = O.render_sphere_tracing(O.OracleNet(sd, cfg), mk())
+    out = O.render_sphere_tracing(O.OracleNet(sd, cfg, emulate=emu, kernel_like=True), mk())
+    return {k: stats(out[k][0], ref[k][0]) for k in ('rgb_map', 'norm_map')}
+
+
+def full_size_sample_floor(emu):
+    """tests/test_gpu_parity.py::test_full_size_sample_meets_the_contract: every ~40th in-box ray of BASELINE's 512 x 512 relit frame on
+    the smooth-skinning body; emulated oracle vs fp32 oracle (the comparand of that test).  Also which rays carry the error."""
+    cfg = make_cfg('relight')
+    sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+    mk = lambda: synthetic.sample_rays(synthetic.make_batch(512, 512, seed=0, posed=True, skin_noise=0.0), 1024)[0]
+    ref = O.render_sphere_tracing(O.OracleNet(sd, cfg), mk())
+    out = O.render_sphere_tracing(O.OracleNet(sd, cfg, emulate=emu, kernel_like=True), mk())
+    res = {k: stats(out[k][0], ref[k][0]) for k in ('rgb_map', 'shade_map', 'norm_map', 'surf_map')}
+    e = (out.rgb_map[0] - ref.rgb_map[0]).abs().amax(-1)
+    res['rgb_map']['n_rays'] = int(e.numel())
+    res['rgb_map']['n_rays_over_1e2'] = int((e > 1e-2).sum())
+    res['rgb_map']['psnr_trim1pct'] = round(O.psnr(out.rgb_map[0][e <= e.kthvalue(int(round(0.99 * e.numel()))).values],
+                                                   ref.rgb_map[0][e <= e.kthvalue(int(round(0.99 * e.numel()))).values]), 2)
+    return res
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     res = {'_about': 'emulated 16-bit-operand oracle vs the reference fp32 goldens; written by tools/precision_floor.py'}
+    only = sys.argv[1:]
+    path = os.path.join(ROOT, 'tests', 'golden', 'precision_floor.json')
+    if only and os.path.exists(path):
+        res = json.load(open(path))           # partial update: python tools/precision_floor.py novel ground multi_chunk
+    for name, fn in (('frame_novel.npz', novel_floor), ('frame_ground.npz', ground_floor), ('multi_chunk', multi_chunk_floor),
+                     ('other_pose', other_pose_floor), ('full_size_sample', full_size_sample_floor)):
+        if only and name.replace('frame_', '').replace('.npz', '') not in only:
+            continue
+        for emu in ('f16', 'bf16'):
+            t0 = time.time()
+            res[f'{name}:{emu}'] = fn(emu)
+            print(name, emu, f'{time.time() - t0:.0f} s', json.dumps(res[f'{name}:{emu}']), flush=True)
+    if only:
+        with open(path, 'w') as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+        return
     for emu in ('f16', 'bf16'):
         res[f'frame_novel_ground.npz:{emu}'] = novel_ground_floor(emu)
         print('frame_novel_ground.npz', emu, json.dumps(res[f'frame_novel_ground.npz:{emu}']['main.rgb_map']), flush=True)
