@@ -311,6 +311,7 @@ def main():
         line['fine_queries_per_sec'] = cnts[0].item() / dt
         line['config']['frame_setup'] = 'static frame (set-up excluded)' if args.static_frame else 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
         line['config']['soak'] = f'{n_soak} untimed frames in {args.soak:.1f} s before the {args.warmup} warm-up steps'
+        line['config']['soak_frames'] = n_soak
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ref = cpu_baseline(cfg, H, args.skin_noise)
             if args.mode in ('relight', 'sphere_tracing', 'anisdf') and not args.ground and args.emulate_world <= 1:

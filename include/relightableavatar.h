@@ -74,7 +74,9 @@ int ra_finalize_weights(ra_ctx* ctx, void* stream);
 
 /* ---- per-frame SMPL state: the batch keys world_to_bigpose consumes
  * (lib/networks/deform/base_network.py:238-336; schema lib/datasets/base_dataset.py:337-397).
- * All dev pointers, copied into the ctx (async on stream).  cond_fix = train_motion.poses[:,
+ * All dev pointers.  pverts, weights, A, big_A, poses and cond_fix are consumed by ra_set_frame (async on stream: vertex blend,
+ * BVH build, bias folds); R, Th, pnorm and tverts are read IN PLACE by every later query of the frame, so the caller keeps them
+ * alive and unchanged until the next ra_set_frame (the Python binding holds references).  cond_fix = train_motion.poses[:,
  * fix_material] (base_network.py:501-503), may be NULL for the relight network. */
 typedef struct ra_frame {
     const float* R;        /* 3x3   */
@@ -153,6 +155,11 @@ typedef struct ra_render_out { /* all dev, all optional (NULL = not wanted); P r
     float* ray_o;      /* P x 3   origins of hit rays, zeros elsewhere                  */
     float* lvis;       /* P x 512 (cfg.vis_novel_light)                                 */
     float* ldot;       /* P x 512 (cfg.vis_novel_light)                                 */
+    /* render_human's per-hit leftovers (sphere_tracing_renderer.py:616-650), as full-ray maps (zeros on misses, NOT premultiplied);
+     * the caller compacts them to the hit rays */
+    float* raw;               /* P x (n_samples * C): the network's raw channels of the n_samples surface samples (C = ra_raw_channels) */
+    float* volume_albedo;     /* P x 3   composited albedo, clipped, before cfg.albedo_multiplier (relight)                 */
+    float* volume_roughness;  /* P       composited roughness, clipped (relight)                                            */
 } ra_render_out;
 
 typedef struct ra_sphere_params {
@@ -306,7 +313,8 @@ int ra_add_light_probe(ra_ctx* ctx, float* rgb, int H, int W, const float* probe
  *   SURFACE   a = cpts_map | surf_map (P,3): (a - tbounds[0]) / (tbounds[1] - tbounds[0]) * acc
  *   RESIDUAL  a = cpts_map, b = bpts_map:     acc * (a - b) / (the int(0.005 * 3P)-th largest value of a - b)
  *   DEPTH     a = depth_map (P):              clip((a - lo) / (hi - lo), 0, 1), lo / hi = the int(0.01 * P)-th smallest / largest
- *                                             depth among rays with acc != 0, lo clipped to min_clip
+ *                                             depth among rays with acc != 0, lo clipped to min_clip (fewer such rays than the
+ *                                             rank: the rank is clamped to their count, where the reference's topk raises)
  *   ALPHA     acc;   ROUGHNESS a (P);   RENDERING a (P,3);   ALBEDO a (P,3), linear2srgb if tonemap
  *   NORMAL    a = norm_map (P,3):             (normalize(a) @ cam_R^T, y and z flipped) * 0.5 + 0.5, times acc
  *   SHADING / SPECULAR a (P,3):               if normalize: a / (the int(0.005 * 3P)-th largest value)

@@ -710,11 +710,12 @@ def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
     net_view = view[:, None, :].expand(-1, S, -1)
     net_surf = surf[:, None, :] + net_zval[None, :, None] * net_view
     raw, _ = network_forward(net, net_surf.reshape(-1, 3), net_view.reshape(-1, 3), fr, c.dist_th)
+    raw_samples = raw                                                 # ret.raw of net_decoder, (hits * S, C): returned as is (:616)
     raw = raw.view(surf.shape[0], S, -1)
     raw, o = raw[..., :-1], raw[..., -1]
     _, raw, o = volume_rendering(raw, o, bg_brightness=c.bg_brightness)
     raw = raw / (o[..., None] + 1e-8)
-    ret = odict(acc_map=acc, ray_o=ro, surf_map=surf, depth_map=depth)
+    ret = odict(acc_map=acc, ray_o=ro, surf_map=surf, depth_map=depth, raw=raw_samples)
     if net.relight:
         cpts, bpts, resd, albedo, rough, norm = raw.split([3, 3, 3, 3, 1, 3], dim=-1)
     else:
@@ -742,7 +743,7 @@ def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
         ret.rgb_map = rgb
     full = odict()
     for k, vv in ret.items():
-        if k in ('volume_albedo', 'volume_roughness'):
+        if k in ('volume_albedo', 'volume_roughness', 'raw'):          # per-hit arrays: not scattered (not in expanding_keys, :662-677)
             full[k] = vv
             continue
         z = vv.new_zeros(P, *vv.shape[1:])

@@ -38,7 +38,7 @@ class ra_trace_params(C.Structure):
 
 
 RENDER_OUT_KEYS = ('rgb', 'acc', 'depth', 'surf', 'norm', 'albedo', 'roughness', 'shade', 'spec', 'cpts', 'bpts', 'resd',
-                   'ray_o', 'lvis', 'ldot')
+                   'ray_o', 'lvis', 'ldot', 'raw', 'volume_albedo', 'volume_roughness')
 
 
 class ra_render_out(C.Structure):

@@ -23,3 +23,40 @@ class dotdict(dict):
 
     def copy(self):
         return dotdict(super().copy())
+
+
+class lazydict(dotdict):
+    """dotdict whose entries may be thunks, evaluated (once) when first read.  The renderers use it for outputs whose SHAPE is
+    data dependent (the per-hit arrays `raw`, `volume_albedo`, `volume_roughness` of render_human): producing them needs the hit
+    count on the host, i.e. a device synchronisation that the frame loop must not pay unless somebody reads them."""
+
+    class _Thunk:
+        __slots__ = ('fn',)
+
+        def __init__(self, fn):
+            self.fn = fn
+
+    def lazy(self, key, fn):
+        dict.__setitem__(self, key, lazydict._Thunk(fn))
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if isinstance(v, lazydict._Thunk):
+            v = v.fn()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+    def copy(self):
+        c = lazydict()
+        for k in dict.keys(self):
+            dict.__setitem__(c, k, dict.__getitem__(self, k))
+        return c

@@ -115,6 +115,7 @@ def default_cfg() -> dotdict:
     c.tonemapping_albedo = True
     # build-side knobs (not in the reference)
     c.mlp_dtype = 'f16'          # element type of the fused MLP kernels: 'f16' or 'bf16' (fp32 accumulate either way)
+    c.ret_raw = True             # sphere-tracing renderer: also return render_human's per-hit raw / volume_albedo / volume_roughness (lazily)
     c.novel_light_timing = True  # novel-light renderer: bracket the main pass with device syncs to fill `diff` like the reference (:107-112)
     c.query_skip = True          # rays that did not move since their last distance query are not queried again (exact; False = the reference's schedule)
     c.k4_batch_slots = 0         # full queries per forward+backward launch pair (bounds the 4.9 KB/slot activation tape); 0 = 1 Mi

@@ -47,8 +47,8 @@ int ra_ctx_create(ra_ctx** out, int device) {
     RA_HIP(hipSetDevice(device));
     ra_ctx* c = new ra_ctx();
     c->device = device;
-    if (c->dcounters.ensure(256)) { delete c; return 1; }
-    RA_HIP(hipMemset(c->dcounters.p, 0, 256));
+    if (c->dcounters.ensure(1024)) { delete c; return 1; }
+    RA_HIP(hipMemset(c->dcounters.p, 0, 1024));
     *out = c;
     return 0;
 }
@@ -57,7 +57,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    DevBuf* bufs[] = {&c->sarena, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
+    DevBuf* bufs[] = {&c->sarena, &c->sarena_pairs, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
                       &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs,
                       &c->adj_start, &c->adj_list, &c->adj_dfaces};
@@ -97,6 +97,7 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
     if (ra_pack_weights(c, err)) { ra_set_error("ra_finalize_weights: " + err); return 1; }
     HostNets& H = c->host;
     if (upload(c->sarena, H.sarena.data(), H.sarena.size() * 2, s)) return 1;
+    if (upload(c->sarena_pairs, H.sarena_pairs.data(), H.sarena_pairs.size() * 2, s)) return 1;
     if (upload(c->fwd_arena, H.fwd_arena.data(), H.fwd_arena.size() * 2, s)) return 1;
     if (upload(c->bwd_arena, H.bwd_arena.data(), H.bwd_arena.size() * 2, s)) return 1;
     if (upload(c->shead_row, H.shead_row.data(), H.shead_row.size() * 4, s)) return 1;
@@ -130,14 +131,11 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RA_HIP(hipSetDevice(c->device));
     const int nv = f->n_verts, nb = c->cfg.n_bones, cond = nb * 3;
-    if (c->fR.ensure(9 * 4) || c->fTh.ensure(3 * 4) || c->fvertA.ensure((size_t)nv * 24 * 4) || c->fpverts4.ensure((size_t)nv * 16) ||
-        c->fpnorm.ensure((size_t)nv * 12) || c->ftverts.ensure((size_t)nv * 12) || c->fbias_r0.ensure(1024) || c->fbias_r4.ensure(1024) ||
+    if (c->fvertA.ensure((size_t)nv * 24 * 4) || c->fpverts4.ensure((size_t)nv * 16) || c->fbias_r0.ensure(1024) || c->fbias_r4.ensure(1024) ||
         c->fbias_c3.ensure(1024) || c->fcond.ensure((size_t)cond * 4))
         return 1;
-    RA_HIP(hipMemcpyAsync(c->fR.p, f->R, 36, hipMemcpyDeviceToDevice, s));
-    RA_HIP(hipMemcpyAsync(c->fTh.p, f->Th, 12, hipMemcpyDeviceToDevice, s));
-    RA_HIP(hipMemcpyAsync(c->fpnorm.p, f->pnorm, (size_t)nv * 12, hipMemcpyDeviceToDevice, s));
-    RA_HIP(hipMemcpyAsync(c->ftverts.p, f->tverts, (size_t)nv * 12, hipMemcpyDeviceToDevice, s));
+    // R, Th, pnorm, tverts are read in place: the caller keeps the frame's arrays alive and unchanged until the next ra_set_frame
+    // (include/relightableavatar.h) — four copy launches less per frame
     launch_pack_verts(f->pverts, nv, c->fpverts4.as<float4>(), s);
     launch_vert_blend(f->weights, f->A, f->big_A, nv, nb, c->fvertA.as<float>(), s);
     const int nleaf = c->use_bvh ? bvh_leaf_count(nv) : 0;
@@ -153,8 +151,8 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     if (c->host.has_color && f->cond_fix)
         launch_fold_bias(c->cond_c3.as<float>(), cond, 0, cond, f->cond_fix, c->b_c3.as<float>(), c->fbias_c3.as<float>(), s);
     FrameState& fr = c->fr;
-    fr.R = c->fR.as<float>(); fr.Th = c->fTh.as<float>(); fr.vertA = c->fvertA.as<float>(); fr.pverts4 = c->fpverts4.as<float4>();
-    fr.pnorm = c->fpnorm.as<float>(); fr.tverts = c->ftverts.as<float>(); fr.bias_r0 = c->fbias_r0.as<float>();
+    fr.R = (float*)f->R; fr.Th = (float*)f->Th; fr.vertA = c->fvertA.as<float>(); fr.pverts4 = c->fpverts4.as<float4>();
+    fr.pnorm = (float*)f->pnorm; fr.tverts = (float*)f->tverts; fr.bias_r0 = c->fbias_r0.as<float>();
     fr.bias_r4 = c->fbias_r4.as<float>(); fr.bias_c3 = c->fbias_c3.as<float>(); fr.n_verts = nv;
     fr.bvh_pts = c->fbvh_pts.as<float4>(); fr.bvh_lbox = c->fbvh_pairs.as<float4>();
     fr.bvh_sbox = c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf; fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
@@ -188,11 +186,27 @@ struct Timer {
 
 DevCounters* dcnt(ra_ctx* c) { return c->dcounters.as<DevCounters>(); }
 int* icnt(ra_ctx* c, int k) { return reinterpret_cast<int*>(c->dcounters.as<char>() + 128) + k; }   // small int counters
-enum { CNT_FINE = 0, CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3 };
+enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
+
+// Every hierarchical-distance pass compacts its fine points through a device counter that must start at zero.  Instead of one
+// 4-byte memset launch per pass (21 per relit chunk), the counters are a set that ONE memset zeroes per chunk; each pass takes
+// the next unused slot.  Stream order makes the refill safe: the memset runs after every earlier user.
+void zero_chunk_counters(ra_ctx* c, hipStream_t s) {
+    hipMemsetAsync(icnt(c, 0), 0, CNT_ALL * sizeof(int), s);
+    c->fc_next = 0;
+    c->cnt_zero = true;
+}
+int* next_fine_counter(ra_ctx* c, hipStream_t s) {
+    if (c->fc_next >= CNT_FC_SLOTS) {
+        hipMemsetAsync(icnt(c, CNT_FC0), 0, CNT_FC_SLOTS * sizeof(int), s);
+        c->fc_next = 0;
+    }
+    return icnt(c, CNT_FC0 + c->fc_next++);
+}
 
 void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s) {
-    if (c->cfg.mlp_f16) launch_mlp_sdf_stream_f16(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, s);
-    else launch_mlp_sdf_stream_bf16(c->host.geo, c->sarena.p, c->barena.as<float>(), c->fr, io, n, s);
+    if (c->cfg.mlp_f16) launch_mlp_sdf_stream_f16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s);
+    else launch_mlp_sdf_stream_bf16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s);
 }
 
 // one hierarchical distance query over the points of rs; writes sdf[n]
@@ -203,11 +217,11 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     float* bpts = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
     if (err) return 1;
     HdqOut out{};
-    out.sdf = sdf; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = bpts;
+    out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     MlpIO io{};
-    io.bpts = bpts; io.idx = fine_idx; io.count = icnt(c, CNT_FINE); io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
+    io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
@@ -255,15 +269,15 @@ int forward_pass(ra_ctx* c, const float* x, const float* v, int n, const int* n_
     float* mats = c->buf<float>("fine_mats", (size_t)n * 24, &err);
     float* sdf = c->buf<float>("fwd_sdf", n, &err);
     if (err) return 1;
-    hipMemsetAsync(raw, 0, (size_t)n * C * sizeof(float), s);
     RaySet rs{};
     rs.mode = 0; rs.x = x; rs.n_dev = n_dev;
     HdqOut out{};
-    out.sdf = sdf; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = bpts; out.mats = mats;
+    out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts; out.mats = mats;
+    out.raw_zero = raw; out.raw_C = C;          // points outside dist_th: zero rows, written by the coarse level itself
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     FullIO io{};
-    io.bpts = bpts; io.mats = mats; io.view = v; io.idx = fine_idx; io.count = icnt(c, CNT_FINE); io.raw = raw; io.C = C;
+    io.bpts = bpts; io.mats = mats; io.view = v; io.idx = fine_idx; io.count = out.fine_count; io.raw = raw; io.C = C;
     io.beta = c->host.beta; io.resd_limit = c->cfg.resd_limit;
     io.albedo_slope = c->cfg.albedo_slope; io.albedo_bias = c->cfg.albedo_bias;
     io.rough_slope = c->cfg.roughness_slope; io.rough_bias = c->cfg.roughness_bias;
@@ -323,9 +337,10 @@ int ra_observed_sdf(ra_ctx* c, const float* bpts, int n, float* sdf, void* strea
     int err = 0;
     int* idx = c->buf<int>("fine_idx", n, &err);
     if (err) return 1;
-    launch_iota(idx, n, icnt(c, CNT_FINE), s);
+    int* cnt = next_fine_counter(c, s);
+    launch_iota(idx, n, cnt, s);
     MlpIO io{};
-    io.bpts = bpts; io.idx = idx; io.count = icnt(c, CNT_FINE); io.sdf = sdf; io.dist_th = 1.f; io.smooth = 0;
+    io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = sdf; io.dist_th = 1.f; io.smooth = 0;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
         Timer t(c, s, 0);
@@ -354,7 +369,7 @@ int ra_bigpose_transform(ra_ctx* c, const float* x, int n, const float* R, const
     RaySet rs{};
     rs.mode = 0; rs.x = x;
     HdqOut o{};
-    o.sdf = sdfc; o.fine_count = icnt(c, CNT_FINE); o.fine_idx = fine_idx; o.bpts = fb;
+    o.sdf = sdfc; o.fine_count = next_fine_counter(c, s); o.fine_idx = fine_idx; o.bpts = fb;
     o.dbg_sdf_batch = sb; o.dbg_nn_batch = nb; o.dbg_d2 = d2; o.dbg_bpts = bp; o.dbg_tpts = tp; o.dbg_mats = mats;
     o.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, 1e9f, c->cfg.blend_radius, o, s);      // transform=False -> filtering off: dist = 1e9 (:253-259)
@@ -435,7 +450,8 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         ssdf = c->buf<float>("sh_sdf", NR, &err);
     }
     if (err) return 1;
-    launch_shadow_gen(g, P, s);
+    launch_shadow_gen(g, P, s, c->cnt_zero);     // the chunk's bulk memset covers the first shadow stage; a second one zeroes its counter itself
+    c->cnt_zero = false;
     if (traced) {
         sh.near_ = g.near_; sh.far_ = g.far_; sh.tan_i = c->light_sharp.as<float>(); sh.light = g.ray_light;
         launch_trace_init(sh, (int)NR, g.ray_count, shadow, s);
@@ -469,6 +485,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     const int S = p->n_samples, C = c->cfg.relight ? 17 : 16, L = c->n_lights;
+    zero_chunk_counters(c, s);                // ONE memset for every device counter this chunk uses
     // ---- spatially coherent ray order (per-ray results are order-free; outputs go back through perm)
     const int* perm = nullptr;
     if (bbox) {
@@ -494,6 +511,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     float* depth = c->buf<float>("sf_depth", P, &err);
     float* acc = c->buf<float>("sf_acc", P, &err);
     int* hit_idx = c->buf<int>("sf_hit", P, &err);
+    int* slot_of_ray = c->buf<int>("sf_slot", P, &err);
     if (err) return 1;
     ts.near_ = near_; ts.far_ = far_;
     launch_trace_init(ts, P, nullptr, p->surface, s);
@@ -504,7 +522,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
         launch_trace_update(ts, sdf, P, nullptr, it, p->surface, s);
     }
     int* hit_count = icnt(c, CNT_HIT);
-    launch_surface_finish(ray_o, ray_d, ts.st, ts.occ, P, surf, depth, acc, hit_idx, hit_count, s);
+    launch_surface_finish(ray_o, ray_d, ts.st, ts.occ, P, surf, depth, acc, hit_idx, hit_count, s, slot_of_ray, true);
     launch_accumulate(hit_count, &dcnt(c)->n_hit_pixels, s);
     if (relit) {   // spatially coherent hit order for the shadow trace (results are scattered back, so order-free)
         const size_t tb = sort_hits_temp_bytes(P);
@@ -516,6 +534,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
         const float bmin[3] = {bbox[0], bbox[1], bbox[2]};
         if (launch_sort_hits(surf, acc, P, bmin, k0, k1, v0, hit_idx, tmp, tb, s)) { ra_set_error("ra_render_sphere_chunk: radix sort failed"); return 1; }
     }
+    launch_slot_index(hit_idx, hit_count, P, slot_of_ray, s);          // ray -> hit slot in the final hit order (-1: miss)
     // ---- material query on S samples around each hit (render_human :602-620)
     float* xs = c->buf<float>("mt_x", (size_t)P * S * 3, &err);
     float* vs = c->buf<float>("mt_v", (size_t)P * S * 3, &err);
@@ -528,6 +547,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     m.albedo = c->buf<float>("mp_albedo", (size_t)P * 3, &err);
     m.rough = c->buf<float>("mp_rough", P, &err);
     m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
+    m.valbedo = (out->volume_albedo && c->cfg.relight) ? c->buf<float>("mp_valbedo", (size_t)P * 3, &err) : nullptr;
     if (err) return 1;
     launch_surface_samples(surf, ray_d, hit_idx, hit_count, P, S, p->surf_sample_range, xs, vs, icnt(c, CNT_SAMP), s);
     if (forward_pass(c, xs, vs, P * S, icnt(c, CNT_SAMP), p->dist_th, raw, s)) return 1;
@@ -550,12 +570,17 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
         launch_shade(in, c->cfg, s);
         c->n_shaded += 0;   // counted on device via hit pixels
     }
-    // ---- scatter to the full ray set (zeros elsewhere), premultiplied by acc (alpha_output_)
+    // ---- every requested map to the full ray set (zeros elsewhere), premultiplied by acc (alpha_output_): one launch
     const int pm = p->premultiply;
+    EmitMaps em{};
+    em.slot_of_ray = slot_of_ray; em.acc = acc; em.perm = perm; em.P = P;
+    long long total = 0;
     auto scat = [&](float* dst, const float* src, int Cc, bool premul, bool src_full) {
         if (!dst) return;
-        hipMemsetAsync(dst, 0, (size_t)P * Cc * sizeof(float), s);
-        launch_scatter_maps(hit_idx, hit_count, P, premul ? 1 : 0, acc, src, Cc, dst, src_full ? 1 : 0, perm, s);
+        if (em.n_jobs == RA_MAX_MAP_JOBS) { launch_emit_maps(em, s); em.n_jobs = 0; total = 0; }
+        total += (long long)P * Cc;
+        em.job[em.n_jobs] = MapJob{src, dst, Cc, premul ? 1 : 0, src_full ? 1 : 0};
+        em.end[em.n_jobs++] = total;
     };
     scat(out->acc, acc, 1, false, true);
     scat(out->depth, depth, 1, pm, true);
@@ -569,13 +594,17 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     if (c->cfg.relight) {
         scat(out->albedo, m.albedo, 3, pm, false);
         scat(out->roughness, m.rough, 1, pm, false);
+        scat(out->volume_albedo, m.valbedo, 3, false, false);
+        scat(out->volume_roughness, m.rough, 1, false, false);
     }
+    scat(out->raw, raw, S * C, false, false);
     if (relit) {
         scat(out->shade, shade, 3, pm, false);
         scat(out->spec, spec, 3, pm, false);
         scat(out->lvis, lvis, L, pm, false);
         scat(out->ldot, ldot, L, pm, false);
     }
+    launch_emit_maps(em, s);
     RA_HIP(hipGetLastError());
     return 0;
 }
@@ -590,6 +619,8 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     RA_CHECK((long long)P * c->n_lights < (1ll << 31), "ra_render_ground_chunk: chunk too large (P x lights must fit an int)");
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
+    zero_chunk_counters(c, s);
+    c->cnt_zero = false;                      // launch_ground_hit zeroes its hit counter itself
     GroundIn g{};
     g.ray_o = ray_o; g.ray_d = ray_d; g.acc = acc; g.P = P;
     const float nn = std::sqrt(p->normal[0] * p->normal[0] + p->normal[1] * p->normal[1] + p->normal[2] * p->normal[2]) + 1e-8f;   // normalize(): x / (|x| + eps)
@@ -651,6 +682,7 @@ int ra_render_volume_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     RA_CHECK(!c->cfg.relight, "ra_render_volume_chunk: volume rendering is wired for the AniSDF network (base_renderer)");
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
+    zero_chunk_counters(c, s);
     const int S = n_samples, C = 16;
     const size_t N = (size_t)((P + 63) & ~63) * S;          // samples are laid out per group of 64 rays (padded)
     RA_CHECK(N < (1u << 30), "ra_render_volume_chunk: chunk too large");
@@ -1034,9 +1066,10 @@ int ra_debug_mlp(ra_ctx* c, const float* bpts, int n, float* resd, float* sdf, f
     int* idx = c->buf<int>("fine_idx", n, &err);
     char* tape = c->buf<char>("k4_tape", mlp_full_rev_tape_bytes(n), &err);
     if (err) return 1;
-    launch_iota(idx, n, icnt(c, CNT_FINE), s);
+    int* cnt = next_fine_counter(c, s);
+    launch_iota(idx, n, cnt, s);
     FullIO io{};
-    io.bpts = bpts; io.idx = idx; io.count = icnt(c, CNT_FINE); io.slot0 = 0; io.slot_cap = n; io.C = c->cfg.relight ? 17 : 16;
+    io.bpts = bpts; io.idx = idx; io.count = cnt; io.slot0 = 0; io.slot_cap = n; io.C = c->cfg.relight ? 17 : 16;
     io.beta = c->host.beta; io.resd_limit = c->cfg.resd_limit; io.relight = c->cfg.relight;
     io.dbg_resd = resd; io.dbg_sdf = sdf; io.dbg_feat = feat; io.dbg_layer = -1;
     if (c->cfg.mlp_f16) launch_mlp_fwd_tape_f16(c->host.geo, c->fwd_arena.p, c->barena.as<float>(), c->fr, io, tape, s);
@@ -1051,7 +1084,7 @@ int ra_debug_full(ra_ctx* c, const float* bpts, int n, float* grad, float* sdf, 
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     const int C = c->cfg.relight ? 17 : 16;
-    int* cnt = icnt(c, CNT_FINE);
+    int* cnt = next_fine_counter(c, s);
     int* idx = c->buf<int>("fine_idx", n, &err);
     float* view = c->buf<float>("dbg_view", (size_t)n * 3, &err);
     if (err) return 1;
@@ -1128,7 +1161,7 @@ int ra_debug_hdq(ra_ctx* c, const float* x, int n, float th, float* sdf_coarse, 
     RaySet rs{};
     rs.mode = 0; rs.x = x;
     HdqOut out{};
-    out.sdf = sdf_coarse; out.fine_count = icnt(c, CNT_FINE); out.fine_idx = fine_idx; out.bpts = fb;
+    out.sdf = sdf_coarse; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = fb;
     out.dbg_sdf_batch = sdf_batch; out.dbg_nn_batch = nn_batch; out.dbg_d2 = d2; out.dbg_bpts = bpts; out.dbg_tpts = tpts; out.dbg_mats = mats;
     out.counters = dcnt(c);
     RA_HIP(hipMemsetAsync(bpts, 0, (size_t)n * 12, s));
@@ -1136,7 +1169,7 @@ int ra_debug_hdq(ra_ctx* c, const float* x, int n, float th, float* sdf_coarse, 
     RA_HIP(hipMemsetAsync(mats, 0, (size_t)n * 96, s));
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     RA_HIP(hipStreamSynchronize(s));
-    RA_HIP(hipMemcpy(fine_count_host, icnt(c, CNT_FINE), sizeof(int), hipMemcpyDeviceToHost));
+    RA_HIP(hipMemcpy(fine_count_host, out.fine_count, sizeof(int), hipMemcpyDeviceToHost));
     RA_HIP(hipGetLastError());
     return 0;
 }

@@ -108,10 +108,11 @@ struct FullIO {             // the full query: geometry with normal + material /
 
 // K3 (ra_k3.hpp): HDQ fine distance query; activations stay in registers, weights stream through LDS (sarena: ra_pack.cpp StreamBuilder).
 // One translation unit per operand type: IEEE half (production) and bfloat16.
-void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
-                               hipStream_t stream);
-void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
-                                hipStream_t stream);
+// sarena_pairs: the same fragments with the row blocks of a layer interleaved in pairs (the 2- / 4-wave latency variants)
+void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
+                               int max_slots, hipStream_t stream);
+void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
+                                int max_slots, hipStream_t stream);
 
 // K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list
 size_t mlp_full_rev_tape_bytes(int slots);

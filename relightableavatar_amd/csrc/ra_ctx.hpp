@@ -9,6 +9,7 @@ struct HostNets {
     bool has_color = false;
     float beta = 0.1f;
     std::vector<uint16_t> sarena;      // K3 weight stream (consumption order, 1952 fragments of 1 KB)
+    std::vector<uint16_t> sarena_pairs;  // the same with the row blocks of every layer interleaved in pairs (K3 latency variants)
     std::vector<uint16_t> fwd_arena;   // K4 forward stream: sarena + the 256 feature rows (2080 fragments)
     std::vector<uint16_t> bwd_arena;   // K4 backward stream: transposed geometry layers, then the material / colour head
     int bwd_geo_frags = 0, bwd_frags = 0;
@@ -33,7 +34,7 @@ struct ra_ctx {
     std::map<std::string, std::vector<float>> state_dict;
     HostNets host;
     // device copies
-    DevBuf sarena, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
+    DevBuf sarena, sarena_pairs, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
     int n_lights = 0;
     // frame
     FrameState fr{};
@@ -45,7 +46,9 @@ struct ra_ctx {
     int adj_n_faces = 0, adj_n_verts = 0;
     // scratch (grow-only)
     std::map<std::string, DevBuf> scratch;
-    DevBuf dcounters;       // DevCounters + small int counters
+    DevBuf dcounters;       // DevCounters (64 B) + at byte 128: the int counters of a chunk (ra_api.cpp: CNT_*, fine-count slots)
+    int fc_next = 0;        // next unused fine-count slot (each hdq pass takes a fresh, still-zero one)
+    bool cnt_zero = false;  // the named counters (hit / ray / sample counts) were zeroed by the chunk's bulk memset
     // host-side counters
     uint64_t n_coarse = 0, n_shaded = 0;
     // timing of the fused MLP launches

@@ -414,6 +414,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
     const bool fine = live && (d0 < th2);
     if (live) {
         out.sdf[i] = smpl;
+        if (out.raw_zero && !fine) {                // Network.forward: zero raw channels outside dist_th (the full query writes the fine rows)
+            float* rz = out.raw_zero + (size_t)i * out.raw_C;
+            for (int c = 0; c < out.raw_C; ++c) rz[c] = 0.f;
+        }
         if (out.dbg_sdf_batch) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) { out.dbg_sdf_batch[3 * i + k] = sk[k]; out.dbg_nn_batch[3 * i + k] = ik[k]; out.dbg_d2[3 * i + k] = dk[k]; }
@@ -506,7 +510,7 @@ void launch_bvh_build(const float4* pverts4, int n_verts, float4* bvh_pts, float
 
 void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
                        hipStream_t s) {
-    hipMemsetAsync(out.fine_count, 0, sizeof(int), s);
+    // out.fine_count must be zero on entry (ra_api.cpp hands every pass a fresh counter of the chunk's pre-zeroed set)
     if (n <= 0) return;
     const float inv2r2 = 1.f / (2.f * blend_radius * blend_radius);
     const dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS);

@@ -35,7 +35,11 @@ __global__ void pad_tail_kernel(float* __restrict__ p, const int* __restrict__ c
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i < n && i >= *cnt) p[i] = __uint_as_float(0x7FFFFFFFu);
 }
-// "a simple version of percentile" (:108-109): lo = the k-th smallest, hi = the k-th largest of the n sorted values
+// "a simple version of percentile" (:108-109): lo = the k-th smallest, hi = the k-th largest of the n sorted values.
+// Deviation, on purpose: the Depth type selects among the rays with acc != 0, whose count is only known on the device.  Where
+// fewer than k = int(0.01 * P) rays hit, the reference's topk(k) raises; checking that here would cost a read-back per image,
+// so k is clamped to the count instead (a nearly empty frame is stretched between its own extremes; documented in
+// include/relightableavatar.h and visualizers/base_visualizer.py)
 __global__ void pick_kernel(const float* __restrict__ sorted, const int* __restrict__ n_dev, int n_host, int k, float* __restrict__ stats) {
     const int n = n_dev ? *n_dev : n_host;
     const int kk = k < 1 ? 1 : (k > n ? n : k);

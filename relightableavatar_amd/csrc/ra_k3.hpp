@@ -72,8 +72,8 @@ __device__ __forceinline__ void pe_frags(u32x4 (&Bp)[4], const float (&x)[3], in
 }
 
 // one network: L0 (encoding) .. L7, then the <= 32-row head; returns the head accumulator (bias included)
-template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO>
-__device__ __forceinline__ f32x16 run_net(Pipe<E, NW>& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h, long long* ts) {
+template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO, typename PipeT>
+__device__ __forceinline__ f32x16 run_net(PipeT& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h, long long* ts) {
     u32x4 B0[16], B1[16], Bp[4];
     f32x16 accA, accB;
     pe_frags<E, PEL, LO>(Bp, x, h);
@@ -97,6 +97,33 @@ __device__ __forceinline__ f32x16 run_net(Pipe<E, NW>& P, const float (&x)[3], c
     row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accA, accB, B1, Bp, B1[14], B1[15], bias + 2048, h);
     RA_STAMP(ts, 8);
     return accA;
+}
+
+// the same network as pairs of row blocks (ra_stream.hpp, row_blocks): the latency variant of the 2- and 4-wave workgroups
+template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO, typename PipeT>
+__device__ __forceinline__ f32x16 run_net_pairs(PipeT& P, const float (&x)[3], const float* bias, int h, long long* ts) {
+    u32x4 B0[16], B1[16], Bp[4];
+    f32x16 a0, a1, b0, b1;
+    pe_frags<E, PEL, LO>(Bp, x, h);
+    layer_pairs<E, NW, 4, ACT, ACT, false>(P, a0, a1, b0, b1, B0 /* unused */, Bp, B0, bias, h);
+    RA_STAMP(ts, 0);
+    layer_pairs<E, NW, 16, ACT, ACT, true>(P, a0, a1, b0, b1, B0, Bp, B1, bias + 256, h);
+    RA_STAMP(ts, 1);
+    layer_pairs<E, NW, 16, ACT, ACT, true>(P, a0, a1, b0, b1, B1, Bp, B0, bias + 512, h);
+    RA_STAMP(ts, 2);
+    layer_pairs<E, NW, 16, ACT, ACT, true>(P, a0, a1, b0, b1, B0, Bp, B1, bias + 768, h);
+    RA_STAMP(ts, 3);
+    layer_pairs<E, NW, 20, ACT, ACT, true>(P, a0, a1, b0, b1, B1, Bp, B0, bias + 1024, h);
+    RA_STAMP(ts, 4);
+    layer_pairs<E, NW, 16, ACT, ACT, true>(P, a0, a1, b0, b1, B0, Bp, B1, bias + 1280, h);
+    RA_STAMP(ts, 5);
+    layer_pairs<E, NW, 16, ACT, ACT, true>(P, a0, a1, b0, b1, B1, Bp, B0, bias + 1536, h);
+    RA_STAMP(ts, 6);
+    layer_pairs<E, NW, 16, ACT, ACT, true>(P, a0, a1, b0, b1, B0, Bp, B1, bias + 1792, h);
+    RA_STAMP(ts, 7);
+    row_blocks<E, NW, 1, 0, 16, ACT, true, true, LAST>(P, a0, a1, b0, b1, B1, Bp, B1[12], B1[13], B1[14], B1[15], bias + 2048, h);
+    RA_STAMP(ts, 8);
+    return a0;
 }
 
 template <typename E, int NW>
@@ -123,7 +150,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     const int ntiles = (count + ST_TM - 1) / ST_TM;
     if ((int)blockIdx.x >= ntiles) return;
 
-    Pipe<E, NW> P;
+    constexpr bool PAIRS = NW < 8;          // one wave per SIMD: two row blocks in flight (pair-ordered stream), A fragments read 8 ahead
+    Pipe<E, NW, ST_STAGES, PAIRS ? 8 : ST_PF> P;
     P.g = reinterpret_cast<const char*>(stream);
     P.voff = wave * (16 / NW) * 1024 + lane * 16;
     P.ring = reinterpret_cast<const char*>(sm.ring) + lane * 16;
@@ -155,9 +183,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
             if (io.smooth) smpl = io.sdf[pidx];
         }
         // the first ST_PF fragments of the tile (stage 0 of the stream)
-        P.template fetch<0>(); P.template fetch<1>(); P.template fetch<2>(); P.template fetch<3>();
+        static_for<0, decltype(P)::PF>([&](auto f_) { P.template fetch<decltype(f_)::value>(); });
         // ---- residual deformation net (ReLU); head: resd = tanh(z) * resd_limit, cpts = bpts + resd
-        const f32x16 hr = run_net<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h, ts);
+        f32x16 hr;
+        if constexpr (PAIRS) hr = run_net_pairs<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h, ts);
+        else hr = run_net<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h, ts);
         float cp[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -165,7 +195,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
             cp[k] = x[k] + __shfl(r, c);
         }
         // ---- signed distance net (softplus, scaled domain); head row 0 = sdf
-        const f32x16 hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr);
+        f32x16 hs;
+        if constexpr (PAIRS) hs = run_net_pairs<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr);
+        else hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr);
         if (h == 0 && s < count) {
             float d = hs[0] * SP_INV;                                 // head accumulates beta*log2(e) * sdf
             if (io.smooth) {                                          // HDQ blend (base_network.py:374-382)
@@ -205,14 +237,15 @@ static void launch_nw(const GeoNet& net, const void* sarena, const float* barena
 // max_slots is only an upper bound of the device-side count: up to 65536 the 4-wave variant needs at most the two
 // rounds that equal one 8-wave round, and one when the real count is below half.  All widths are bit-identical.
 template <typename E>
-static void launch_k3(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
+static void launch_k3(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
+                      hipStream_t stream) {
     if (max_slots <= 0) return;
     int nw = max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8);
 #ifdef RA_TESTING            // test / experiment builds only (tools/build_variant.sh): force the workgroup width
     static const int force = getenv("RA_STREAM_NW") ? atoi(getenv("RA_STREAM_NW")) : 0;
     if (force) nw = force;
 #endif
-    if (nw == 2) launch_nw<E, 2>(net, sarena, barena, fr, io, max_slots, stream);
-    else if (nw == 4) launch_nw<E, 4>(net, sarena, barena, fr, io, max_slots, stream);
+    if (nw == 2) launch_nw<E, 2>(net, sarena_pairs, barena, fr, io, max_slots, stream);
+    else if (nw == 4) launch_nw<E, 4>(net, sarena_pairs, barena, fr, io, max_slots, stream);
     else launch_nw<E, 8>(net, sarena, barena, fr, io, max_slots, stream);
 }

@@ -18,10 +18,12 @@ struct RaySet {
 
 struct HdqOut {
     float* sdf;           // n: coarse signed distance (smpl_sdf after the abs rule)
-    int* fine_count;      // device counter, zeroed by the launcher
+    int* fine_count;      // device counter, ZERO on entry (a fresh one per pass: ra_api.cpp next_fine_counter)
     int* fine_idx;        // slot -> point
     float* bpts;          // slot x 3
     float* mats;          // slot x 24 or nullptr
+    float* raw_zero;      // nullable: n x raw_C rows that non-fine points zero (Network.forward's zeros outside dist_th)
+    int raw_C;
     // debug (nullable): per point
     float* dbg_sdf_batch; // n x 3
     int* dbg_nn_batch;    // n x 3
@@ -56,15 +58,24 @@ void launch_trace_init(const TraceState& ts, int n, const int* n_dev, const ra_t
 void launch_trace_update(const TraceState& ts, const float* sdf, int n, const int* n_dev, int iter,
                          const ra_trace_params& p, hipStream_t s);
 
-// surface pass epilogue: surf/depth/acc, hit compaction
+// surface pass epilogue: surf/depth/acc, hit compaction (hit_count: zeroed here unless counter_is_zero), slot_of_ray[r] = -1 for every ray
 void launch_surface_finish(const float* ray_o, const float* ray_d, const float* st, const float* occ, int P, float* surf,
-                           float* depth, float* acc, int* hit_idx, int* hit_count, hipStream_t s);
+                           float* depth, float* acc, int* hit_idx, int* hit_count, hipStream_t s, int* slot_of_ray = nullptr,
+                           bool counter_is_zero = false);
+// slot_of_ray[hit_idx[k]] = k for the (possibly re-ordered) hit list
+void launch_slot_index(const int* hit_idx, const int* hit_count, int P, int* slot_of_ray, hipStream_t s);
+// every requested output map of a chunk in ONE launch: per ray either its hit slot's values (optionally times acc) or zeros
+struct MapJob { const float* src; float* dst; int C; int premul; int src_full; };
+constexpr int RA_MAX_MAP_JOBS = 16;
+struct EmitMaps { MapJob job[RA_MAX_MAP_JOBS]; long long end[RA_MAX_MAP_JOBS]; int n_jobs; const int* slot_of_ray; const float* acc; const int* perm; int P; };
+void launch_emit_maps(const EmitMaps& m, hipStream_t s);
 // 3 (S) samples per hit pixel: x = surf + z * view
 void launch_surface_samples(const float* surf, const float* ray_d, const int* hit_idx, const int* hit_count, int P, int S,
                             float range, float* x, float* v, int* n_out, hipStream_t s);
 // per hit pixel: composite S samples of raw (C channels, last = occ), normalise, split
 struct SurfaceMaps {      // per hit slot
     float *cpts, *bpts, *resd, *norm, *albedo, *rough, *rgb;
+    float* valbedo;       // nullable: clipped albedo before cfg.albedo_multiplier (ret.volume_albedo, :646)
 };
 void launch_surface_composite(const float* raw, int C, int S, const int* hit_count, int P, int relight, const ra_config& cfg,
                               const SurfaceMaps& m, hipStream_t s);
@@ -90,7 +101,7 @@ struct ShadowGen {
     float *near_, *far_;
     int* ray_count;
 };
-void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s);
+void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s, bool counter_is_zero = false);
 void launch_debug_aabb(const float* o, const float* d, int n, const float* bbox6, float* nr, float* fr, hipStream_t s);
 void launch_debug_brdf(const float* p2l, const float* p2c, const float* nrm, const float* alb, const float* rough, int L, int N, const ra_config& cfg,
                        float* out, hipStream_t s);

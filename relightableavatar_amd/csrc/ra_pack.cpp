@@ -64,24 +64,27 @@ struct StreamBuilder {
     uint16_t cv(float v) const { return half ? f2h(v) : f2bf(v); }
     static int hidden_feature(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
     // rows_pad/32 row blocks; per row block: 16 hidden k-steps of Mh (may be null) then 4 PE k-steps of Mp (may be null)
+    bool pairs = false;         // interleave the fragments of row blocks (2p, 2p + 1) k-step by k-step (K3's latency variants, ra_stream.hpp row_blocks)
+    template <typename ChanFn>
+    void frag(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale) {       // ks < 16: hidden k-step, else encoding k-step ks - 16
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int row = rb * 32 + (lane & 31);
+                if (ks < 16) {
+                    const int col = hidden_feature(ks, lane >> 5, j);
+                    w.push_back(cv(row < Mh->rows && col < Mh->cols ? Mh->at(row, col) : 0.f));
+                } else {
+                    const int col = chan(8 * (ks - 16) + j, lane >> 5);
+                    w.push_back(cv(row < Mp->rows && col >= 0 && col < Mp->cols ? Mp->at(row, col) * pe_scale : 0.f));
+                }
+            }
+    }
     template <typename ChanFn>
     void add(const Mat* Mh, const Mat* Mp, ChanFn chan, int rows_pad, float pe_scale) {
-        for (int rb = 0; rb < rows_pad / 32; ++rb) {
-            if (Mh)
-                for (int ks = 0; ks < 16; ++ks)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int row = rb * 32 + (lane & 31), col = hidden_feature(ks, lane >> 5, j);
-                            w.push_back(cv(row < Mh->rows && col < Mh->cols ? Mh->at(row, col) : 0.f));
-                        }
-            if (Mp)
-                for (int ks = 0; ks < 4; ++ks)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int row = rb * 32 + (lane & 31), col = chan(8 * ks + j, lane >> 5);
-                            w.push_back(cv(row < Mp->rows && col >= 0 && col < Mp->cols ? Mp->at(row, col) * pe_scale : 0.f));
-                        }
-        }
+        const int nb = rows_pad / 32, group = (pairs && nb % 2 == 0) ? 2 : 1;
+        for (int rb0 = 0; rb0 < nb; rb0 += group)
+            for (int ks = Mh ? 0 : 16; ks < (Mp ? 20 : 16); ++ks)
+                for (int g = 0; g < group; ++g) frag(Mh, Mp, chan, rb0 + g, ks, pe_scale);
     }
 };
 
@@ -329,6 +332,14 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         S.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
         if (S.w.size() != (size_t)1952 * 512) { err = "internal: weight stream has " + std::to_string(S.w.size() / 512) + " fragments, expected 1952"; return 1; }
         H.sarena = S.w;
+        StreamBuilder Sp;           // the same stream in pair order
+        Sp.half = P.half;
+        Sp.pairs = true;
+        for (int i = 0; i < 8; ++i) Sp.add(i == 0 ? nullptr : &Rm[i], i == 0 ? &Rm[0] : (i == 4 ? &Rpe4 : nullptr), pe_chan_resd, 256, 1.f);
+        Sp.add(&Rhead, nullptr, pe_chan_resd, 32, 1.f);
+        for (int l = 0; l < 8; ++l) Sp.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
+        Sp.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
+        H.sarena_pairs = Sp.w;
     }
     {   // K4 (reverse mode) streams, same fragment order / K permutation as the K3 stream.
         // forward: the K3 stream + the 256 feature rows of lin8 (head output, no activation; unscaled weights on scaled inputs)

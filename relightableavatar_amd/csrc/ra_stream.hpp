@@ -94,9 +94,11 @@ __device__ __forceinline__ void glds16x2(const char* sbase, unsigned voff, unsig
 }
 
 // the weight stream as seen by one wave of an NW-wave workgroup (each wave moves 16 / NW fragments of every stage)
-template <typename E, int NW, int STAGES = ST_STAGES>
+// PF: A fragments read ahead of their MFMA (4 with two waves per SIMD; a lone wave per SIMD needs 8 to cover the LDS latency)
+template <typename E, int NW, int STAGES = ST_STAGES, int PF_ = ST_PF>
 struct Pipe {
     static constexpr int FPW = 16 / NW;
+    static constexpr int PF = PF_;
     const char* g;          // weight stream (uniform)
     unsigned voff;          // per lane: wave * FPW * 1024 + lane * 16
     const char* ring;       // LDS ring (generic pointer), + lane * 16
@@ -104,7 +106,7 @@ struct Pipe {
     unsigned slot;          // ring slot of the stage being read (wave-uniform)
     int sstage;             // its position in the tile's stream, 0 .. ST_STAGES-1 (wave-uniform)
     const char* rd;         // ring + slot * 16 KB + lane * 16
-    typename Tr<E>::x8 af[ST_PF];
+    typename Tr<E>::x8 af[PF];
 
     __device__ __forceinline__ void issue(int stream_stage, unsigned ring_slot) {
         const char* sb = g;
@@ -137,7 +139,7 @@ struct Pipe {
     template <int FM>
     __device__ __forceinline__ void fetch() {
         if (FM == 0) sync_stage();
-        af[FM % ST_PF] = *reinterpret_cast<const typename Tr<E>::x8*>(rd + FM * 1024);
+        af[FM % PF] = *reinterpret_cast<const typename Tr<E>::x8*>(rd + FM * 1024);
     }
 };
 
@@ -224,5 +226,76 @@ __device__ __forceinline__ void layer(PipeT& P, f32x16& accA, f32x16& accB, u32x
     row_block<E, NW, (7 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], bias + 224, h);
 }
 
+// ---- paired row blocks: the latency variant for launches that cannot fill the chip -------------------------------------------
+// With ONE wave per SIMD the 16 MFMAs of a row block are a dependent chain on one accumulator and issue every ~64 cycles
+// (measured: tools/k3_timestamps.py, 2-wave launch).  Two row blocks in flight — fragments interleaved k-step by k-step in the
+// stream (ra_pack.cpp, `pair` order) — give the pipe an independent MFMA every slot.  Each accumulator still sums its k-steps
+// in the same order, so the results are bit-identical to the unpaired kernel.
+// NB = 2: blocks a, b (accumulators acc0, acc1); NB = 1: a lone block (the heads).  The pending epilogue is the previous PAIR
+// (prev0 -> o00, o01; prev1 -> o10, o11: 32 elements over the NB * KS slots; EARLY: they are this block's own k-steps 12..15).
+template <typename E, int NW, int NB, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT>
+__device__ __forceinline__ void row_blocks(PipeT& P, f32x16& acc0, f32x16& acc1, const f32x16& prev0, const f32x16& prev1, u32x4 (&Bm)[16],
+                                           const u32x4 (&Bp)[4], u32x4& o00, u32x4& o01, u32x4& o10, u32x4& o11, const float* bias_rb, int h) {
+    init_acc(acc0, bias_rb, h);
+    if constexpr (NB == 2) init_acc(acc1, bias_rb + 32, h);
+    float ta[32];
+    constexpr int NS = NB * KS;
+    static_for<0, NS>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int ks = i / NB;
+        const u32x4 bw = (KS == 4) ? Bp[ks & 3] : (ks < 16 ? Bm[ks & 15] : Bp[ks & 3]);
+        constexpr int PF = PipeT::PF;
+        if constexpr (NB == 1 || (i & 1) == 0) acc0 = Tr<E>::mfma(P.af[(FM0 + i) % PF], __builtin_bit_cast(X8<E>, bw), acc0);
+        else acc1 = Tr<E>::mfma(P.af[(FM0 + i) % PF], __builtin_bit_cast(X8<E>, bw), acc1);
+        if constexpr (!(TAIL && i + PF >= NS)) P.template fetch<(FM0 + i + PF) % 16>();
+        if constexpr (PENDING) {
+            static_for<0, 32>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
+                constexpr int DEPTH = SP ? 3 : 0;
+                constexpr int LAST = (KS == 4) ? NS - 1 : (EARLY ? NB * 12 - 1 : NS - 1);
+                // 4-k-step blocks (first layers): the 16 elements of a block move through the chain together, one stage per slot
+                constexpr int s0 = (KS == 4) ? (NB == 2 ? 4 * (e >> 4) + (SP ? 0 : (e & 15) / 4) : (SP ? 0 : e / 8)) : (e * (LAST - DEPTH + 1)) / 32;
+                const float z = e < 16 ? prev0[e & 15] : prev1[e & 15];
+                if constexpr (SP) {
+                    if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(z);
+                    if constexpr (s0 + 1 == i) ta[e] = 1.f + ta[e];
+                    if constexpr (s0 + 2 == i) ta[e] = __builtin_amdgcn_logf(ta[e]);
+                    if constexpr (s0 + 3 == i) ta[e] = sp_finish(ta[e], z);
+                } else {
+                    if constexpr (s0 == i) ta[e] = Tr<E>::is_f16 ? z : max0(z);        // f16: ReLU after the pack (see row_block)
+                }
+                constexpr int sdone = s0 + DEPTH;
+                if constexpr ((e & 1) && sdone == i) {
+                    unsigned w = pack2<E>(ta[e - 1], ta[e]);
+                    if constexpr (!SP && Tr<E>::is_f16) {
+                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                        h2_t v = __builtin_bit_cast(h2_t, w);
+                        v = __builtin_elementwise_max(v, h2_t{(_Float16)0, (_Float16)0});
+                        w = __builtin_bit_cast(unsigned, v);
+                    }
+                    constexpr int q = e & 15;
+                    if constexpr (e < 16) { if constexpr (q < 8) o00[q >> 1] = w; else o01[(q >> 1) & 3] = w; }
+                    else { if constexpr (q < 8) o10[q >> 1] = w; else o11[(q >> 1) & 3] = w; }
+                }
+            });
+        }
+        // a lone wave has nobody to hide its LDS latency: keep the slot's instructions in source order, so that the fragment of
+        // slot i + PF really is requested PF slots ahead (left alone the scheduler sinks the reads to two slots before their use:
+        // 61 instead of ~40 cycles per MFMA)
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// a 256-row layer as four pairs of row blocks.  On entry (b0, b1) hold the pending last pair of the previous layer (if PEND_IN:
+// activation ACT_IN, destination Bm[12..15]); on exit they hold this layer's pending blocks 6, 7.
+template <typename E, int NW, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
+__device__ __forceinline__ void layer_pairs(PipeT& P, f32x16& a0, f32x16& a1, f32x16& b0, f32x16& b1, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16],
+                                            const float* bias, int h) {
+    row_blocks<E, NW, 2, 0, KS, ACT_IN, PEND_IN, true, false>(P, a0, a1, b0, b1, Bm, Bp, Bm[12], Bm[13], Bm[14], Bm[15], bias, h);
+    row_blocks<E, NW, 2, (2 * KS) % 16, KS, ACT, true, false, false>(P, b0, b1, a0, a1, Bm, Bp, Bo[0], Bo[1], Bo[2], Bo[3], bias + 64, h);
+    row_blocks<E, NW, 2, (4 * KS) % 16, KS, ACT, true, false, false>(P, a0, a1, b0, b1, Bm, Bp, Bo[4], Bo[5], Bo[6], Bo[7], bias + 128, h);
+    row_blocks<E, NW, 2, (6 * KS) % 16, KS, ACT, true, false, false>(P, b0, b1, a0, a1, Bm, Bp, Bo[8], Bo[9], Bo[10], Bo[11], bias + 192, h);
+}
 
 }  // namespace

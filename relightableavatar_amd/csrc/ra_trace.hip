@@ -111,10 +111,11 @@ __global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf
 // ------------------------------------------------------------------------------------------ surface
 __global__ void surface_finish_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ st,
                                       const float* __restrict__ occ, int P, float* __restrict__ surf, float* __restrict__ depth,
-                                      float* __restrict__ acc, int* __restrict__ hit_idx, int* __restrict__ hit_count) {
+                                      float* __restrict__ acc, int* __restrict__ hit_idx, int* __restrict__ hit_count, int* __restrict__ slot_of_ray) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     bool hit = false;
     if (i < P) {
+        if (slot_of_ray) slot_of_ray[i] = -1;
         const float s = st[i];
         const float sx = ro[3 * i] + s * rd[3 * i], sy = ro[3 * i + 1] + s * rd[3 * i + 1], sz = ro[3 * i + 2] + s * rd[3 * i + 2];
         surf[3 * i] = sx; surf[3 * i + 1] = sy; surf[3 * i + 2] = sz;
@@ -264,6 +265,7 @@ __global__ void surface_composite_kernel(const float* __restrict__ raw, int C, i
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float a = fminf(fmaxf(out[9 + c], cfg.albedo_bias), cfg.albedo_bias + cfg.albedo_slope);
+            if (m.valbedo) m.valbedo[3 * h + c] = a;
             if (cfg.albedo_multiplier > 0.f) a *= cfg.albedo_multiplier;
             m.albedo[3 * h + c] = a;
         }
@@ -601,6 +603,32 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
 }
 
 // ------------------------------------------------------------------------------------------ scatter
+__global__ void slot_index_kernel(const int* __restrict__ hit_idx, const int* __restrict__ hit_count, int* __restrict__ slot_of_ray) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k < *hit_count) slot_of_ray[hit_idx[k]] = k;
+}
+
+// all output maps of a chunk in one launch (replaces one memset + one scatter per map): element k of the concatenated
+// (ray, channel) spaces of the jobs; a ray without a hit slot writes zeros (multi_scatter_zeros, :680-688), a hit ray its slot's
+// values, times acc where the map is premultiplied (alpha_output_)
+__global__ void emit_maps_kernel(EmitMaps m) {
+    long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    int j = 0;
+    long long start = 0;
+    while (j < m.n_jobs && k >= m.end[j]) { start = m.end[j]; ++j; }
+    if (j >= m.n_jobs) return;
+    const MapJob& J = m.job[j];
+    k -= start;
+    const int r = (int)(k / J.C), c = (int)(k - (long long)r * J.C);
+    const int slot = m.slot_of_ray[r];
+    float v = 0.f;
+    if (slot >= 0) {
+        v = J.src_full ? J.src[(size_t)r * J.C + c] : J.src[(size_t)slot * J.C + c];
+        if (J.premul) v *= m.acc[r];
+    }
+    J.dst[(size_t)(m.perm ? m.perm[r] : r) * J.C + c] = v;      // perm: internal (sorted) ray -> caller's ray index
+}
+
 __global__ void scatter_maps_kernel(const int* __restrict__ hit_idx, const int* __restrict__ hit_count, int premultiply,
                                     const float* __restrict__ acc_full, const float* __restrict__ src, int C, float* __restrict__ dst,
                                     int src_full, const int* __restrict__ perm) {
@@ -754,10 +782,20 @@ void launch_trace_update(const TraceState& ts, const float* sdf, int n, const in
 }
 
 void launch_surface_finish(const float* ray_o, const float* ray_d, const float* st, const float* occ, int P, float* surf,
-                           float* depth, float* acc, int* hit_idx, int* hit_count, hipStream_t s) {
-    hipMemsetAsync(hit_count, 0, sizeof(int), s);
+                           float* depth, float* acc, int* hit_idx, int* hit_count, hipStream_t s, int* slot_of_ray, bool counter_is_zero) {
+    if (!counter_is_zero) hipMemsetAsync(hit_count, 0, sizeof(int), s);
     if (P <= 0) return;
-    hipLaunchKernelGGL(surface_finish_kernel, grid_for(P), dim3(TPB), 0, s, ray_o, ray_d, st, occ, P, surf, depth, acc, hit_idx, hit_count);
+    hipLaunchKernelGGL(surface_finish_kernel, grid_for(P), dim3(TPB), 0, s, ray_o, ray_d, st, occ, P, surf, depth, acc, hit_idx, hit_count, slot_of_ray);
+}
+
+void launch_slot_index(const int* hit_idx, const int* hit_count, int P, int* slot_of_ray, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(slot_index_kernel, grid_for(P), dim3(TPB), 0, s, hit_idx, hit_count, slot_of_ray);
+}
+
+void launch_emit_maps(const EmitMaps& m, hipStream_t s) {
+    if (m.n_jobs <= 0 || m.P <= 0) return;
+    hipLaunchKernelGGL(emit_maps_kernel, grid_for(m.end[m.n_jobs - 1]), dim3(TPB), 0, s, m);
 }
 
 void launch_surface_samples(const float* surf, const float* ray_d, const int* hit_idx, const int* hit_count, int P, int S,
@@ -776,8 +814,8 @@ void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s) {
     hipLaunchKernelGGL(light_dirs_kernel, grid_for(L), dim3(TPB), 0, s, xyz, L, ldir);
 }
 
-void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s) {
-    hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
+void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s, bool counter_is_zero) {
+    if (!counter_is_zero) hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
     if (P <= 0) return;
     const long long groups = ((long long)P + 63) / 64;
     const int lchunks = (g.L + SG_LIGHTS - 1) / SG_LIGHTS;

@@ -58,7 +58,8 @@ class Renderer(sphere_tracing_renderer.Renderer):
                 g_rgb, g_alb, g_shade, g_spec = eng.reshade_ground(grd.ray_d, grd.albedo_map, grd.lvis_map, grd.ldot_map, probes, images,
                                                                    cfg.ground_attach_envmap)
             for i, n in enumerate(names):
-                human = dotdict({k: main[k] for k in main if k != 'ground'})      # references, not copies (:183)
+                human = main.copy()                                               # references, not copies (:183); lazily evaluated entries stay lazy
+                human.pop('ground', None)
                 human.rgb_map, human.shade_map, human.spec_map = rgb[i][None], shade[i][None], spec[i][None]
                 if grd is not None:
                     ground = dotdict({k: grd[k] for k in visual if k in grd})

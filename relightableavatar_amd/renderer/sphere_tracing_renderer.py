@@ -6,7 +6,7 @@ import torch
 from torch import nn
 
 from .. import config
-from ..base_utils import dotdict
+from ..base_utils import dotdict, lazydict
 from .chunking import chunks
 
 
@@ -79,11 +79,16 @@ class Renderer(nn.Module):
                 names += ['spec']
             if cfg.vis_novel_light:
                 names += ['lvis', 'ldot']
-        width = dict(acc=0, depth=0, roughness=0, lvis=cfg.env_h * cfg.env_w, ldot=cfg.env_h * cfg.env_w)
+        raw_c = 17 if eng.relight else 16
+        want_raw = bool(cfg.get('ret_raw', True))          # render_human's per-hit leftovers raw / volume_albedo / volume_roughness (:616-650)
+        if want_raw:
+            names += ['raw'] + (['volume_albedo', 'volume_roughness'] if eng.relight else [])
+        width = dict(acc=0, depth=0, roughness=0, volume_roughness=0, lvis=cfg.env_h * cfg.env_w, ldot=cfg.env_h * cfg.env_w,
+                     raw=cfg.n_samples * raw_c)
         full = dotdict()
         for k in names:
             w = width.get(k, 3)
-            full[k] = torch.zeros((P, w) if w else (P,), device=dev)
+            full[k] = torch.empty((P, w) if w else (P,), device=dev)      # every ray of every map is written by the chunks (zeros for misses)
         for a, b in (batch.get('render_chunks', None) or chunks(P, cfg.render_chunk_size)):      # render_chunks: a shard's view of the frame's chunks (shard.py)
             # quirk (sphere_tracing_renderer.py:1020-1022): the box grows IN PLACE on the batch every chunk
             bbox6 = self._grow_bounds(batch)
@@ -91,7 +96,15 @@ class Renderer(nn.Module):
                 continue
             eng.render_sphere_chunk(ray_o[a:b], ray_d[a:b], near[a:b], far[a:b], bbox6, probe, params,
                                     {k: v[a:b] for k, v in full.items()})
-        ret = dotdict()
+        ret = lazydict()
+        if want_raw:
+            # per-hit arrays in ascending ray order (the reference's order is topk(sorted=False)'s, implementation-defined).  Their
+            # shape needs the hit count on the host: evaluated only when read (the trainers' losses, relight_trainer.py:78-79)
+            hits = lambda: (full.acc > 0).nonzero()[:, 0]
+            ret.lazy('raw', lambda: full.raw[hits()].reshape(1, -1, raw_c))                     # B, P_hit * S, C
+            if eng.relight:
+                ret.lazy('volume_albedo', lambda: full.volume_albedo[hits()][None])              # B, P_hit, 3
+                ret.lazy('volume_roughness', lambda: full.volume_roughness[hits()][None, :, None])   # B, P_hit, 1
         ret.acc_map = full.acc[None]
         ret.ray_o = full.ray_o[None]
         ret.surf_map, ret.depth_map = full.surf[None], full.depth[None]

@@ -7,6 +7,8 @@ Same name, arguments and return value (an H x W x 3|4 numpy image) as the refere
 normalisation, the scatter of the in-box rays into the frame and the alpha plane run in the HIP library
 (ra_map_to_image), the light-probe inset in ra_add_light_probe.  Writing images to disk, ground-truth images and the
 deprecated Semantic / Feature types stay out of scope (no GPU work in them).  There is no CPU fallback.
+One deviation: Output.Depth stretches between the 1 % quantiles of the HIT rays' depths; with fewer hit rays than 1 % of the rays the
+reference's topk raises, the build clamps the rank to the hit count (the count lives on the device; no read-back per image).
 """
 import ctypes as C
 from enum import Enum, auto
@@ -88,4 +90,17 @@ class Visualizer:
             img = add_light_probe(img.reshape(1, H * W, 3), output.envmap.probe, batch, cfg, eng)[0].view(H, W, 3)
         if store_alpha:                                                            # :201-208
             img = torch.cat([img, alpha.view(H, W, 1)], dim=-1)
+        if 'orig_H' in batch and 'orig_W' in batch:                                # :214-215: a cropped batch is pasted into the full-size frame
+            img = Visualizer.fill_image(img, int(batch.orig_H.item()), int(batch.orig_W.item()), batch.crop_bbox[0], cfg)
         return img.detach().cpu().numpy()
+
+    @staticmethod
+    def fill_image(img, orig_H, orig_W, bbox, cfg=None):
+        """Visualizer.fill_image (base_visualizer.py:233-239): the crop goes back to its place in an orig_H x orig_W frame of
+        cfg.bg_brightness.  Like the reference's, the frame has 3 channels: a 4-channel image (cfg.store_alpha_channel) does not
+        fit and raises, as the reference's slice assignment does."""
+        cfg = cfg or config.active_cfg()
+        full = img.new_ones(orig_H, orig_W, 3) * cfg.bg_brightness
+        x0, y0, x1, y1 = int(bbox[0, 0]), int(bbox[0, 1]), int(bbox[1, 0]), int(bbox[1, 1])
+        full[y0:y1, x0:x1] = img[:y1 - y0, :x1 - x0]
+        return full

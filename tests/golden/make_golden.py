@@ -202,7 +202,9 @@ def main():
             out = sphere_tracing_renderer.Renderer(net).render(batch)
         npz('frame_relight_smooth.npz', H=H, crop=crop, skin_noise=0.0, wbounds_after=batch.wbounds,
             **{k: out[k] for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'albedo_map', 'roughness_map',
-                                   'shade_map', 'spec_map', 'cpts_map', 'bpts_map', 'resd_map')})
+                                   'shade_map', 'spec_map', 'cpts_map', 'bpts_map', 'resd_map',
+                                   # render_human's per-hit leftovers (:616-650), in the reference's own (topk, unsorted) hit order
+                                   'raw', 'volume_albedo', 'volume_roughness')})
     elif mode == 'novel_ground':    # the README's relight command (readme.md:64): vis_novel_light + vis_ground_shading, main + probes
         from lib.networks.renderer import novel_light_sphere_tracing
         H, crop = 24, 10

@@ -299,6 +299,18 @@ def test_frame_relight_smooth_meets_the_contract(golden):
     assert p >= fl['psnr'] - 3.0
     assert float(err(out.albedo_map, ref['albedo_map']).max()) < 1e-3 and float(err(out.surf_map, ref['surf_map']).max()) < 2e-3
     assert psnr(out.shade_map, ref['shade_map']) >= 50.0
+    # row H's full key set: render_human's per-hit leftovers (sphere_tracing_renderer.py:616-650) are in the output (lazily: reading
+    # them costs the hit count's read-back) and match the reference's as sets of rows (its hit order is topk's, ours ascending)
+    assert {'raw', 'volume_albedo', 'volume_roughness'} <= set(out.keys())
+    for k, tol in (('volume_albedo', 1e-3), ('volume_roughness', 1e-3), ('raw', 3e-2)):      # raw carries the f16 normals
+        a, b = out[k][0].double().cpu(), T(ref[k])[0].double()
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        d = torch.cdist(a, b, p=float('inf'))
+        if k == 'raw':      # the samples' f16 normals: single samples off a crease reach 0.09 (the composited norm_map is what is shaded)
+            m1, m0 = d.min(1).values, d.min(0).values
+            assert float((m1 < tol).float().mean()) > 0.99 and float((m0 < tol).float().mean()) > 0.99 and float(m1.median()) < 3e-3, (k, float(m1.max()))
+        else:
+            assert float(d.min(1).values.max()) < tol and float(d.min(0).values.max()) < tol, (k, float(d.min(1).values.max()))
 
 
 def test_frame_relight(golden):
@@ -611,7 +623,7 @@ def test_frame_ground(golden):
     near = T(ref['surf_map'])[0].abs().amax(-1) < 1e3        # rays parallel to the plane: t = x / (0 + eps * |random edge|^2) in the reference
     assert float((err(out.surf_map, ref['surf_map'])[0][near] < 1e-3).float().mean()) > 0.99
     assert float((err(out.shade_map, ref['shade_map']) < 5e-3).float().mean()) > 0.99
-    assert float(err(out.acc_map, ref['acc_map']).max()) < 2e-2
+    assert float(err(out.acc_map, ref['acc_map']).max()) < 3e-2          # acc = 1 - min_i 500 d_i / t_i: a 1e-4 distance error is 2.5e-2 of alpha at t = 2
     # the shadow on the ground exists: some ground pixels near the body are darker than the unshadowed ground
     acc_h = out.acc_map[0]
     g = out.shade_map[0][acc_h == 0].sum(-1)
@@ -695,6 +707,11 @@ def test_streamed_k3_tile_boundaries(relight):
         e = (sdf3 - sdf1).abs()
         assert torch.isfinite(sdf3).all() and float(e.max()) < 6e-4 and float(e.mean()) < 6e-5, (n, float(e.max()), float(e.mean()))
     assert eng.hdq_sdf(x_all[:0], 0.125, True).numel() == 0
+    # the three launch geometries (2 / 4 / 8 waves; the narrow ones run two row blocks at a time on a pair-ordered weight stream)
+    # sum every accumulator's k-steps in the same order: a point's distance does not depend on the launch it is in, bit for bit
+    big = eng.hdq_sdf(x_all, 0.125, False)                       # 70 000 points: 8 waves
+    for n in (1000, 16384, 30000, 65536):                         # 2 waves up to 16 384, 4 waves up to 65 536
+        assert torch.equal(eng.hdq_sdf(x_all[:n].contiguous(), 0.125, False), big[:n]), n
 
 
 @pytest.mark.parametrize('mode', ['relight', 'anisdf'])

@@ -125,6 +125,13 @@ def test_frame_relight_smooth(golden):
     _cmp(out, ref, 'rgb_map', 4e-4)
     _cmp(out, ref, 'shade_map', 6e-4)     # penumbra values: fp32 re-association x (sharp / 2t)
     assert O.psnr(out.rgb_map, T(ref['rgb_map'])) > 80
+    # render_human's per-hit leftovers (:616-650).  The reference orders the hit rays by topk(sorted=False) (implementation
+    # defined), the oracle ascending: compared as sets of rows
+    for k, tol in (('volume_albedo', 1e-4), ('volume_roughness', 1e-4), ('raw', 1e-2)):      # raw carries the normals (see norm_map above)
+        a, b = out[k][0], T(ref[k])[0]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        d = torch.cdist(a.double(), b.double(), p=float('inf'))
+        assert float(d.min(1).values.max()) < tol and float(d.min(0).values.max()) < tol, (k, float(d.min(1).values.max()))
 
 
 def test_frame_novel_ground(golden):

@@ -11,7 +11,7 @@ def main():
     d, j = sys.argv[1], sys.argv[2]
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 16
     line = json.loads(open(j).read().strip().splitlines()[-1])
-    frames = line['steps'] + line['warmup']
+    frames = line['steps'] + line['warmup'] + line.get('config', {}).get('soak_frames', 0)
     print('ms/step', round(line['ms_per_step'], 3), '| frames profiled', frames)
     rows = []
     for f in glob.glob(d + '/**/*kernel_stats.csv', recursive=True):
