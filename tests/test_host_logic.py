@@ -146,6 +146,47 @@ print('rank', rank, 'ok')
 '''
 
 
+WORKER_GROUND = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from relightableavatar_amd import shard, synthetic
+from relightableavatar_amd.base_utils import dotdict
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+batch = synthetic.make_batch(96, 96, seed=0)
+P, F = batch.ray_o.shape[1], 96 * 96
+class FakeGroundRenderer:                 # stands in for the sphere-tracing renderer with cfg.vis_ground_shading: full-frame maps of the
+    cfg = dotdict(vis_ground_shading=True, render_chunk_size=2000)          # rank's ground pixels, its human rays blended in at their pixels
+    def render(self, b):
+        pix = b.get('ground_pix', None)
+        inds = b.ground_inds if pix is not None else b.mask_at_box.reshape(-1).nonzero()[:, 0]
+        pix = torch.arange(F) if pix is None else pix
+        g = pix.float()[:, None] * torch.tensor([1.0, 2.0, 3.0])
+        g[inds] += b.ray_o[0] * 7 + b.far[0][:, None]
+        b.mask_at_box[:] = True                                             # the real ground pass does (:1103)
+        return dotdict(rgb_map=g[None], acc_map=(pix.float() * 0.5)[None])
+ref = FakeGroundRenderer().render(dotdict(batch, mask_at_box=batch.mask_at_box.clone()))
+out = shard.render_sharded(FakeGroundRenderer(), batch, ('rgb_map', 'acc_map'), rank, world)
+assert out.rgb_map.shape == (1, F, 3) and out.acc_map.shape == (1, F)
+assert torch.equal(out.rgb_map, ref.rgb_map) and torch.equal(out.acc_map, ref.acc_map)
+assert not batch.mask_at_box.all()                                          # the caller's mask is untouched
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_sharded_ground_pass_gloo_world2(tmp_path):
+    """the N > 1 path of the README command (ground-plane pass): every rank renders its full-frame tiles with its human rays
+    blended in locally, ONE all_gather assembles the frame"""
+    script = tmp_path / 'worker_ground.py'
+    script.write_text(WORKER_GROUND)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29613', str(script), REPO], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('ok') == 2
+
+
 def test_sharded_render_gloo_world2(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
