@@ -9,7 +9,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
-RN=${RA_ROUND:-r02}
+RN=${RA_ROUND:-r03}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${RN}_bench.json 2> $OUT/bench.err
@@ -18,33 +18,39 @@ python3 $R/bench.py --mode sphere_tracing --steps 20 --warmup 3 --no-cpu-baselin
 python3 $R/bench.py --mode anisdf --steps 10 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
 python3 $R/bench.py --ground --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
 python3 $R/bench.py --mode novel_light --size 1024 --probes 8 --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
-python3 $R/bench.py --skin-noise 0 --steps 10 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
+python3 $R/bench.py --skin-noise 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_skin_noise0.json 2>> $OUT/bench.err        # the body the contract is asserted on, with its PSNR
 : > $OUT/${RN}_emulate_world.jsonl
 for n in 2 4 8; do python3 $R/bench.py --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world.jsonl 2>> $OUT/bench.err; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python3 $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+# config 5 (1024 x 1024, 8 probes) and the README command (novel light + ground) as one rank of an N-rank job
+: > $OUT/${RN}_emulate_world_config5.jsonl
+for n in 1 2 4 8; do python3 $R/bench.py --emulate-world $n --size 1024 --mode novel_light --probes 8 --steps 10 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world_config5.jsonl 2>> $OUT/bench.err; done
+for n in 1 2 4 8; do python3 $R/bench.py --emulate-world $n --size 512 --mode novel_light --ground --probes 2 --steps 10 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world_config5.jsonl 2>> $OUT/bench.err; done
+$R/tools/frame_anatomy.sh w8 44 -- --emulate-world 8 --steps 10 --warmup 3 > $OUT/${RN}_emulate_world8_kernels.txt 2>> $OUT/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python3 $R/bench.py --steps 7 --warmup 2 --no-cpu-baseline --soak 0 > /dev/null 2>&1
 cp $OUT/kt/r_kernel_stats.csv $OUT/${RN}_relight512_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_s -o r -- python3 $R/bench.py --mode sphere_tracing --steps 7 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_s -o r -- python3 $R/bench.py --mode sphere_tracing --steps 7 --warmup 2 --no-cpu-baseline --soak 0 > /dev/null 2>&1
 cp $OUT/kt_s/r_kernel_stats.csv $OUT/${RN}_sphere512_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_a -o r -- python3 $R/bench.py --mode anisdf --steps 7 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_a -o r -- python3 $R/bench.py --mode anisdf --steps 7 --warmup 2 --no-cpu-baseline --soak 0 > /dev/null 2>&1
 cp $OUT/kt_a/r_kernel_stats.csv $OUT/${RN}_anisdf512_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_g -o r -- python3 $R/bench.py --ground --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_g -o r -- python3 $R/bench.py --ground --steps 3 --warmup 1 --no-cpu-baseline --soak 0 > /dev/null 2>&1
 cp $OUT/kt_g/r_kernel_stats.csv $OUT/${RN}_relight_ground512_kernel_stats.csv
 i=0
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --soak 0 > /dev/null 2>&1
 done
 # the same two HBM counters for the volume path (the full query's tape traffic)
 for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmcv$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmcv$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline --soak 0 > /dev/null 2>&1
 done
 python3 - <<'P'
 import csv, glob, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof'
-rn = os.environ.get('RA_ROUND', 'r02')
+rn = os.environ.get('RA_ROUND', 'r03')
 fams = (('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
-        ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'), ('mlp_full', 'mlp_full_kernel'))
+        ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'))
 for pat, name in (('/pmc[0-9]*/', 'relight512'), ('/pmcv[0-9]*/', 'anisdf512')):      # one summary per workload
     agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
     for f in sorted(glob.glob(out + pat + '*counter_collection.csv')):
