@@ -96,7 +96,7 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
     std::string err;
     if (ra_pack_weights(c, err)) { ra_set_error("ra_finalize_weights: " + err); return 1; }
     HostNets& H = c->host;
-    if (upload(c->sarena, H.sarena.data(), H.sarena.size() * 2, s)) return 1;
+    if (upload(c->sarena, H.sarena_trim.data(), H.sarena_trim.size() * 2, s)) return 1;        // device copy: the trimmed stream (8-wave K3)
     if (upload(c->sarena_pairs, H.sarena_pairs.data(), H.sarena_pairs.size() * 2, s)) return 1;
     if (upload(c->fwd_arena, H.fwd_arena.data(), H.fwd_arena.size() * 2, s)) return 1;
     if (upload(c->bwd_arena, H.bwd_arena.data(), H.bwd_arena.size() * 2, s)) return 1;

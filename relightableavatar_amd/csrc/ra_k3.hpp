@@ -77,26 +77,44 @@ __device__ __forceinline__ f32x16 run_net(PipeT& P, const float (&x)[3], const f
     u32x4 B0[16], B1[16], Bp[4];
     f32x16 accA, accB;
     pe_frags<E, PEL, LO>(Bp, x, h);
-    // every layer starts on a stage boundary (32, 128, 160 and 16 fragments are multiples of 16)
+    // every layer starts on a stage boundary (32, 128, 160 / 144, 112 and 16 fragments are multiples of 16)
     layer<E, NW, 4, ACT, ACT, false>(P, accA, accB, B0 /* unused */, Bp, B0, bias, h);
     RA_STAMP(ts, 0);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 256, h);
     RA_STAMP(ts, 1);
     layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 512, h);
     RA_STAMP(ts, 2);
-    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 768, h);
-    RA_STAMP(ts, 3);
-    layer<E, NW, 20, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1024, h);
-    RA_STAMP(ts, 4);
-    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1280, h);
-    RA_STAMP(ts, 5);
-    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1536, h);
-    RA_STAMP(ts, 6);
-    layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1792, h);
-    RA_STAMP(ts, 7);
-    row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accA, accB, B1, Bp, B1[14], B1[15], bias + 2048, h);
-    RA_STAMP(ts, 8);
-    return accA;
+    if constexpr (LO) {
+        // SDF net on the trimmed stream: lin3 has 205 outputs = 7 row blocks (its last one stays pending in accA: the accumulators
+        // swap roles from here on), lin4 reads them in 14 hidden k-steps + 4 encoding k-steps
+        layer<E, NW, 16, ACT, ACT, true, PipeT, 7>(P, accA, accB, B0, Bp, B1, bias + 768, h);
+        RA_STAMP(ts, 3);
+        layer<E, NW, 18, ACT, ACT, true, PipeT, 8, 14, 7>(P, accB, accA, B1, Bp, B0, bias + 1024, h);
+        RA_STAMP(ts, 4);
+        layer<E, NW, 16, ACT, ACT, true>(P, accB, accA, B0, Bp, B1, bias + 1280, h);
+        RA_STAMP(ts, 5);
+        layer<E, NW, 16, ACT, ACT, true>(P, accB, accA, B1, Bp, B0, bias + 1536, h);
+        RA_STAMP(ts, 6);
+        layer<E, NW, 16, ACT, ACT, true>(P, accB, accA, B0, Bp, B1, bias + 1792, h);
+        RA_STAMP(ts, 7);
+        row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accB, accA, B1, Bp, B1[14], B1[15], bias + 2048, h);
+        RA_STAMP(ts, 8);
+        return accB;
+    } else {
+        layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 768, h);
+        RA_STAMP(ts, 3);
+        layer<E, NW, 20, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1024, h);
+        RA_STAMP(ts, 4);
+        layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1280, h);
+        RA_STAMP(ts, 5);
+        layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B1, Bp, B0, bias + 1536, h);
+        RA_STAMP(ts, 6);
+        layer<E, NW, 16, ACT, ACT, true>(P, accA, accB, B0, Bp, B1, bias + 1792, h);
+        RA_STAMP(ts, 7);
+        row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accA, accB, B1, Bp, B1[14], B1[15], bias + 2048, h);
+        RA_STAMP(ts, 8);
+        return accA;
+    }
 }
 
 // the same network as pairs of row blocks (ra_stream.hpp, row_blocks): the latency variant of the 2- and 4-wave workgroups
@@ -151,13 +169,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     if ((int)blockIdx.x >= ntiles) return;
 
     constexpr bool PAIRS = NW < 8;          // one wave per SIMD: two row blocks in flight (pair-ordered stream), A fragments read 8 ahead
-    Pipe<E, NW, ST_STAGES, PAIRS ? 8 : ST_PF> P;
+    constexpr int STAGES = PAIRS ? ST_STAGES : ST_STAGES_TRIM;          // the 8-wave kernel walks the trimmed stream
+    Pipe<E, NW, STAGES, PAIRS ? 8 : ST_PF> P;
     P.g = reinterpret_cast<const char*>(stream);
     P.voff = wave * (16 / NW) * 1024 + lane * 16;
     P.ring = reinterpret_cast<const char*>(sm.ring) + lane * 16;
     P.ring_addr = (unsigned)(size_t)sm.ring + wave * (16 / NW) * 1024;
     P.slot = ST_RING - 1;            // the first sync_stage() advances to slot 0 / stream stage 0
-    P.sstage = ST_STAGES - 1;
+    P.sstage = STAGES - 1;
     P.rd = P.ring;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll

@@ -80,11 +80,14 @@ struct StreamBuilder {
             }
     }
     template <typename ChanFn>
-    void add(const Mat* Mh, const Mat* Mp, ChanFn chan, int rows_pad, float pe_scale) {
+    // hks: hidden k-steps emitted (16 = all 256 inputs; the trimmed stream drops the k-steps of inputs that do not exist)
+    void add(const Mat* Mh, const Mat* Mp, ChanFn chan, int rows_pad, float pe_scale, int hks = 16) {
         const int nb = rows_pad / 32, group = (pairs && nb % 2 == 0) ? 2 : 1;
         for (int rb0 = 0; rb0 < nb; rb0 += group)
-            for (int ks = Mh ? 0 : 16; ks < (Mp ? 20 : 16); ++ks)
+            for (int ks = Mh ? 0 : 16; ks < (Mp ? 20 : 16); ++ks) {
+                if (ks >= hks && ks < 16) continue;
                 for (int g = 0; g < group; ++g) frag(Mh, Mp, chan, rb0 + g, ks, pe_scale);
+            }
     }
 };
 
@@ -332,6 +335,18 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         S.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
         if (S.w.size() != (size_t)1952 * 512) { err = "internal: weight stream has " + std::to_string(S.w.size() / 512) + " fragments, expected 1952"; return 1; }
         H.sarena = S.w;
+        // the 8-wave K3's stream without the MFMAs that only multiply padding: lin3 of the SDF net has 256 - sdf_dim outputs (205: 7 row
+        // blocks), lin4 reads them in 14 k-steps (ra_k3.hpp run_net).  The kernel is compiled for that shape.
+        if (Sm[3].rows > 224 || Sm[4].cols > 224) { err = "SDF skip layer has " + std::to_string(Sm[3].rows) + " outputs, the distance kernel is built for <= 224 (multires differs from the compiled variant)"; return 1; }
+        StreamBuilder St;
+        St.half = P.half;
+        for (int i = 0; i < 8; ++i) St.add(i == 0 ? nullptr : &Rm[i], i == 0 ? &Rm[0] : (i == 4 ? &Rpe4 : nullptr), pe_chan_resd, 256, 1.f);
+        St.add(&Rhead, nullptr, pe_chan_resd, 32, 1.f);
+        for (int l = 0; l < 8; ++l)
+            St.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, l == 3 ? 224 : 256, sp, l == 4 ? 14 : 16);
+        St.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
+        if (St.w.size() != (size_t)1920 * 512) { err = "internal: trimmed weight stream has " + std::to_string(St.w.size() / 512) + " fragments, expected 1920"; return 1; }
+        H.sarena_trim = St.w;
         StreamBuilder Sp;           // the same stream in pair order
         Sp.half = P.half;
         Sp.pairs = true;

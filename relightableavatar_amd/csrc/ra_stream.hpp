@@ -29,8 +29,12 @@ constexpr float SP_INV = 0.0069314718055994531f;    // ln(2) / beta
 constexpr int ST_MAXW = 8;                          // waves per workgroup: 8 (tile = 256 points), or 4 / 2 for small launches
 constexpr int ST_RING = 8;                          // ring stages
 constexpr int ST_STAGE_BYTES = 16384;               // 16 fragments of 1 KB
-constexpr int ST_FRAGS = 1952;                      // fragments per tile
+constexpr int ST_FRAGS = 1952;                      // fragments per tile, every layer padded to 256 rows / 16-wide k-steps of 256 inputs
 constexpr int ST_STAGES = ST_FRAGS / 16;            // 122
+// the 8-wave K3 walks a TRIMMED stream: the SDF net's lin3 has 205 outputs (7 row blocks, not 8) and lin4 reads them in 14 k-steps
+// (+ 4 encoding k-steps = 18, not 20): 32 MFMAs per tile less (1.6 %)
+constexpr int ST_FRAGS_TRIM = ST_FRAGS - 16 - 16;    // 1920
+constexpr int ST_STAGES_TRIM = ST_FRAGS_TRIM / 16;   // 120
 constexpr int ST_AHEAD = ST_RING - 2;               // stages in flight: stage st+6 refills the slot of stage st-2, whose reads
                                                     // were all consumed by MFMAs issued before the barrier (no lgkmcnt wait needed)
 constexpr int ST_PF = 4;                            // A fragments read ahead of their MFMA
@@ -158,14 +162,16 @@ __device__ __forceinline__ void init_acc(f32x16& acc, const float* bias_rb, int 
 // One row block: KS MFMAs (fragments F0.. of the tile's stream) into `acc`, interleaved with the pending epilogue
 // of `accPrev` (activation ACT_PREV) into the B fragments o0, o1.  Bm: hidden-part B fragments (KS >= 16),
 // Bp: encoding B fragments (KS == 4 or the last 4 k-steps of KS == 20).
-template <typename E, int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT>
+// KH: hidden k-steps of the layer (KS - KH encoding k-steps follow); ELAST: with EARLY, the last slot whose results may still be
+// written (the pending outputs are this block's own inputs at k-steps 2 PRB - 2, 2 PRB - 1 for a previous layer of PRB row blocks)
+template <typename E, int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT, int KH = (KS == 4 ? 0 : 16), int ELAST = 13>
 __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&Bm)[16], const u32x4 (&Bp)[4],
                                           u32x4& o0, u32x4& o1, const float* bias_rb, int h) {
     init_acc(acc, bias_rb, h);
     float ta[16];
     static_for<0, KS>([&](auto ks_) {
         constexpr int ks = decltype(ks_)::value;
-        const u32x4 bw = (KS == 4) ? Bp[ks & 3] : (ks < 16 ? Bm[ks & 15] : Bp[ks & 3]);
+        const u32x4 bw = ks < KH ? Bm[ks & 15] : Bp[(ks - KH) & 3];
         acc = Tr<E>::mfma(P.af[(FM0 + ks) % ST_PF], __builtin_bit_cast(X8<E>, bw), acc);
         if constexpr (!(TAIL && ks + ST_PF >= KS)) P.template fetch<(FM0 + ks + ST_PF) % 16>();
         if constexpr (PENDING) {
@@ -176,7 +182,7 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
                 constexpr int e = decltype(e_)::value;
                 constexpr bool SP = ACT_PREV == ACT_SOFTPLUS && RA_ABL != 1 && RA_ABL != 3 && RA_ABL != 6;
                 constexpr int DEPTH = SP ? 3 : 0;
-                constexpr int LAST = (KS == 4) ? 3 : (EARLY ? 13 : KS - 1);
+                constexpr int LAST = (KS == 4) ? 3 : (EARLY ? ELAST : KS - 1);
                 constexpr int s0 = (KS == 4) ? 0 : (e * (LAST - DEPTH + 1)) / 16;
                 if constexpr (SP && KS != 4) {
                     if constexpr (s0 == ks) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
@@ -211,20 +217,23 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
     });
 }
 
-// a 256-row layer: 8 row blocks; on entry `accB` holds the pending last row block of the previous layer (if PEND_IN,
-// activation ACT_IN, destination Bm[14], Bm[15]); on exit accB holds this layer's pending row block 7.
-template <typename E, int NW, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
+// a layer of NRB row blocks (8: 256 rows); on entry `accB` holds the pending last row block of the previous layer (if PEND_IN,
+// activation ACT_IN; that layer had PRB row blocks: destination Bm[2 PRB - 2], Bm[2 PRB - 1]); on exit this layer's last row block is
+// pending — in accB for an even NRB, in accA for an odd one (the caller swaps the two for the layers that follow).
+template <typename E, int NW, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT, int NRB = 8, int KH = (KS == 4 ? 0 : 16), int PRB = 8>
 __device__ __forceinline__ void layer(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&Bm)[16], const u32x4 (&Bp)[4], u32x4 (&Bo)[16],
                                       const float* bias, int h) {
-    row_block<E, NW, 0, KS, ACT_IN, PEND_IN, true, false>(P, accA, accB, Bm, Bp, Bm[14], Bm[15], bias, h);
-    row_block<E, NW, (1 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], bias + 32, h);
-    row_block<E, NW, (2 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], bias + 64, h);
-    row_block<E, NW, (3 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], bias + 96, h);
-    row_block<E, NW, (4 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], bias + 128, h);
-    row_block<E, NW, (5 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], bias + 160, h);
-    row_block<E, NW, (6 * KS) % 16, KS, ACT, true, false, false>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], bias + 192, h);
-    row_block<E, NW, (7 * KS) % 16, KS, ACT, true, false, false>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], bias + 224, h);
+    row_block<E, NW, 0, KS, ACT_IN, PEND_IN, true, false, PipeT, KH, 2 * PRB - 3>(P, accA, accB, Bm, Bp, Bm[2 * PRB - 2], Bm[2 * PRB - 1], bias, h);
+    row_block<E, NW, (1 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, Bm, Bp, Bo[0], Bo[1], bias + 32, h);
+    row_block<E, NW, (2 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, Bm, Bp, Bo[2], Bo[3], bias + 64, h);
+    row_block<E, NW, (3 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, Bm, Bp, Bo[4], Bo[5], bias + 96, h);
+    row_block<E, NW, (4 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, Bm, Bp, Bo[6], Bo[7], bias + 128, h);
+    row_block<E, NW, (5 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, Bm, Bp, Bo[8], Bo[9], bias + 160, h);
+    row_block<E, NW, (6 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, Bm, Bp, Bo[10], Bo[11], bias + 192, h);
+    if constexpr (NRB == 8)
+        row_block<E, NW, (7 * KS) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, Bm, Bp, Bo[12], Bo[13], bias + 224, h);
 }
+
 
 // ---- paired row blocks: the latency variant for launches that cannot fill the chip -------------------------------------------
 // With ONE wave per SIMD the 16 MFMAs of a row block are a dependent chain on one accumulator and issue every ~64 cycles
