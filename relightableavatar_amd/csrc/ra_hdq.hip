@@ -159,6 +159,9 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
             v.w = __int_as_float((int)id);
         }
         pts[i] = v;        // padded with +inf points: (p - inf)^2 = inf never beats a finite bound
+        // the same points per leaf as x[32] | y[32] | z[32]: the leaf scan reads candidate PAIRS with wave-uniform addresses
+        float* soa = reinterpret_cast<float*>(pts + (size_t)nl * BVH_LEAF) + (size_t)(i >> 5) * (3 * BVH_LEAF) + (i & 31);
+        soa[0] = v.x; soa[BVH_LEAF] = v.y; soa[2 * BVH_LEAF] = v.z;
     }
     // leaf boxes into LDS scratch (reuse red-sized arrays is too small -> reuse keys' tail? keep simple: global + LDS copy)
     __shared__ float lb[BVH_MAXL][6];
@@ -211,6 +214,10 @@ __device__ __forceinline__ float box_dist2(const float p[3], float lx, float ly,
     const float dz = fmaxf(fmaxf(lz - p[2], p[2] - hz), 0.f);
     return dx * dx + dy * dy + dz * dz;
 }
+
+// squared distance with ONE rounding order for every scan (what the compiler's contraction of dx*dx + dy*dy + dz*dz has produced since
+// round 1): exact-neighbour ties and the last bit of the coarse distance do not depend on which scan found the vertex
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) { return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, dy * dy)); }
 
 // top-3 insertion; ties resolved towards the lower vertex index (what an ascending scan gives).
 // Pure value selects under one wave-uniform guard: keeps the six state words in VGPRs (a 3-way
@@ -291,21 +298,44 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         const unsigned long long lm = __ballot(live);
         const int first = lm ? __ffsll((long long)lm) - 1 : 0;
         const int lane = threadIdx.x & 63;
-        // one coalesced load per leaf (lane k holds point k; the array is padded with +inf to whole
-        // leaves), then 32 register broadcasts: no per-point memory latency
-        // A leaf (32 points) sits in two float4 registers per lane: lane l holds points l & 15 and 16 + (l & 15), i.e.
-        // every 16-lane row carries the whole leaf, and a candidate's coordinates reach all lanes as the DPP operand
-        // of the subtraction itself (row_newbcast k): per candidate 3 DPP subtracts + mul + 2 fma + compare + branch.
+        // Leaf scan on packed fp32: a leaf is stored as x[32] | y[32] | z[32] (bvh_build_kernel), a PAIR of candidates is three 8-byte
+        // reads at wave-uniform addresses (scalar loads: the operands arrive in SGPR pairs) and 3 v_pk_add + v_pk_mul + 2 v_pk_fma for
+        // 2 x 64 distances, one min + compare + not-taken branch per pair: ~4.5 issue slots per candidate (the earlier scan — leaf in
+        // two float4 registers per lane, coordinates as DPP row broadcasts of the subtraction — took 11: a DPP op costs two slots).
+        // d = fma(dz, dz, fma(dx, dx, dy * dy)) in both halves: the rounding the O(N) validation scan has (dist2 below).
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 px2 = {p[0], p[0]}, py2 = {p[1], p[1]}, pz2 = {p[2], p[2]};
+        // Eight candidates per coordinate arrive as one s_load_dwordx8 (constant address space: the structure was written by an earlier
+        // kernel); the next eight are requested after the first group of the current eight has been tested, so that the compiler's
+        // lgkmcnt(0) before the first use does not wait for the request just issued.  Four candidates per branch: two independent
+        // packed chains (no dependent-issue bubbles).
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        typedef const f8 __attribute__((address_space(4))) cf8;
         auto scan_leaf = [&](int l) __attribute__((always_inline)) {
-            const float4 pa = fr.bvh_pts[l * BVH_LEAF + (lane & 15)];
-            const float4 pb = fr.bvh_pts[l * BVH_LEAF + 16 + (lane & 15)];
-            static_for<0, 32>([&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                const float4& q = k < 16 ? pa : pb;
-                const float dx = p[0] - row_bcast<k & 15>(q.x), dy = p[1] - row_bcast<k & 15>(q.y), dz = p[2] - row_bcast<k & 15>(q.z);
-                const float d = dx * dx + dy * dy + dz * dz;
-                if (__builtin_expect(__ballot(d <= d2) != 0ull, 0))          // the vertex id is only needed on the rare insert path
-                    knn_insert(d, __builtin_amdgcn_readlane(__float_as_int(q.w), k & 15), d0, d1, d2, i0, i1, i2);
+            cf8* L = (cf8*)(fr.bvh_soa + (size_t)l * (3 * BVH_LEAF));
+            f8 cx = L[0], cy = L[4], cz = L[8], nx = cx, ny = cy, nz = cz;
+            static_for<0, 4>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                static_for<0, 2>([&](auto g_) {
+                    constexpr int g = decltype(g_)::value;
+                    const f2 ax = {cx[4 * g], cx[4 * g + 1]}, ay = {cy[4 * g], cy[4 * g + 1]}, az = {cz[4 * g], cz[4 * g + 1]};
+                    const f2 bx = {cx[4 * g + 2], cx[4 * g + 3]}, by = {cy[4 * g + 2], cy[4 * g + 3]}, bz = {cz[4 * g + 2], cz[4 * g + 3]};
+                    const f2 dxa = px2 - ax, dya = py2 - ay, dza = pz2 - az, dxb = px2 - bx, dyb = py2 - by, dzb = pz2 - bz;
+                    f2 da = dya * dya, db = dyb * dyb;
+                    da = __builtin_elementwise_fma(dxa, dxa, da);
+                    db = __builtin_elementwise_fma(dxb, dxb, db);
+                    da = __builtin_elementwise_fma(dza, dza, da);
+                    db = __builtin_elementwise_fma(dzb, dzb, db);
+                    if (__builtin_expect(__ballot(fminf(fminf(da.x, da.y), fminf(db.x, db.y)) <= d2) != 0ull, 0)) {   // vertex ids: only on the rare insert path
+                        const float4* v = fr.bvh_pts + l * BVH_LEAF + 8 * q + 4 * g;
+                        knn_insert(da.x, __float_as_int(v[0].w), d0, d1, d2, i0, i1, i2);
+                        knn_insert(da.y, __float_as_int(v[1].w), d0, d1, d2, i0, i1, i2);
+                        knn_insert(db.x, __float_as_int(v[2].w), d0, d1, d2, i0, i1, i2);
+                        knn_insert(db.y, __float_as_int(v[3].w), d0, d1, d2, i0, i1, i2);
+                    }
+                    if constexpr (g == 0 && q < 3) { nx = L[q + 1]; ny = L[4 + q + 1]; nz = L[8 + q + 1]; }
+                });
+                cx = nx; cy = ny; cz = nz;
             });
         };
         auto sdist = [&](int j) __attribute__((always_inline)) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
             for (int j = 0; j < nv; ++j) {
                 const float4 v = sv[j];
                 const float dx = p[0] - v.x, dy = p[1] - v.y, dz = p[2] - v.z;
-                const float d = dx * dx + dy * dy + dz * dz;
+                const float d = dist2(dx, dy, dz);
                 knn_insert(d, v0 + j, d0, d1, d2, i0, i1, i2);
             }
         }
