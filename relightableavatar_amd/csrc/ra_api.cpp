@@ -141,7 +141,7 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     const int nleaf = c->use_bvh ? bvh_leaf_count(nv) : 0;
     const int nsuper = bvh_super_count(nleaf);
     if (nleaf > 0) {
-        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * (16 + 12)) || c->fbvh_pairs.ensure((size_t)(nleaf + nsuper) * 32)) return 1;
+        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * (16 + 12)) || c->fbvh_pairs.ensure((size_t)(nleaf + nsuper) * 32 + (size_t)nsuper * 192)) return 1;
         launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float4>(), c->fbvh_pairs.as<float4>(),
                          c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf, nleaf, nsuper, s);
         RA_HIP(hipGetLastError());
@@ -155,7 +155,7 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     fr.pnorm = (float*)f->pnorm; fr.tverts = (float*)f->tverts; fr.bias_r0 = c->fbias_r0.as<float>();
     fr.bias_r4 = c->fbias_r4.as<float>(); fr.bias_c3 = c->fbias_c3.as<float>(); fr.n_verts = nv;
     fr.bvh_pts = c->fbvh_pts.as<float4>(); fr.bvh_soa = reinterpret_cast<const float*>(fr.bvh_pts + (size_t)nleaf * 32); fr.bvh_lbox = c->fbvh_pairs.as<float4>();
-    fr.bvh_sbox = c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf; fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
+    fr.bvh_sbox = c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf; fr.bvh_lpair = reinterpret_cast<const float*>(fr.bvh_sbox + (size_t)2 * nsuper); fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
     c->have_frame = true;
     RA_HIP(hipGetLastError());
     return 0;

@@ -191,6 +191,14 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         }
         sbox[2 * sidx] = make_float4(lo[0], lo[1], lo[2], 0.f);
         sbox[2 * sidx + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        // the super box's 8 leaf boxes as 4 PAIR records of 12 floats (lo.x[2] lo.y[2] lo.z[2] hi.x[2] hi.y[2] hi.z[2]): the sweep tests two
+        // leaf boxes per packed instruction.  Missing leaves of the last super box: an inverted box, infinitely far from everything.
+        float* rec = reinterpret_cast<float*>(sbox + 2 * (size_t)ns) + (size_t)sidx * (6 * BVH_FAN);
+        for (int e = 0; e < BVH_FAN; ++e) {
+            const int l = sidx * BVH_FAN + e;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rec[12 * (e >> 1) + 2 * c + (e & 1)] = l < nl ? lb[l][c] : (c < 3 ? 3e38f : -3e38f);
+        }
     }
 }
 
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
     static_assert(SPLIT == 1 || (BVH && SPLIT >= 2 && SPLIT <= 16), "SPLIT > 1: the workgroup is SPLIT waves on the same 64 queries");
     constexpr int NT = SPLIT == 1 ? KNN_THREADS : 64 * SPLIT;      // threads per workgroup
     // BVH: super + leaf boxes (2 float4 each); brute force: a vertex tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? (BVH_MAXS + BVH_MAXL) * 32 : VT * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? 16 : VT * 16];       // the O(N) scan's vertex tile
     const int n = rs.n_dev ? min(*rs.n_dev, n_launch) : n_launch;
     const int base = blockIdx.x * (SPLIT == 1 ? KNN_THREADS : 64);
     if (base >= n) return;               // whole block idle (uniform)
@@ -288,12 +296,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         // (conservative box distance vs the lane's current third-best), all loads have wave-uniform
         // addresses and no load depends on another one.  Seed: the leaf nearest to the wave's first
         // live lane is scanned first so that every lane starts with a finite bound.
-        float4* sb = reinterpret_cast<float4*>(smem);                 // [ns][2] then [nl][2]
         const int nl = fr.bvh_leaves, ns = fr.bvh_supers;
-        float4* lbx = sb + 2 * ns;
-        for (int j = threadIdx.x; j < 2 * ns; j += NT) sb[j] = fr.bvh_sbox[j];
-        for (int j = threadIdx.x; j < 2 * nl; j += NT) lbx[j] = fr.bvh_lbox[j];
-        __syncthreads();
         if (!live) { d0 = d1 = d2 = -1.f; }            // idle lanes: every test fails, nothing is inserted
         const unsigned long long lm = __ballot(live);
         const int first = lm ? __ffsll((long long)lm) - 1 : 0;
@@ -338,39 +341,59 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                 cx = nx; cy = ny; cz = nz;
             });
         };
-        auto sdist = [&](int j) __attribute__((always_inline)) { const float4 lo = sb[2 * j], hi = sb[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
-        auto ldist = [&](int j) __attribute__((always_inline)) { const float4 lo = lbx[2 * j], hi = lbx[2 * j + 1]; return box_dist2(p, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); };
-        // --- seed: nearest super box, then nearest leaf in it, as seen by the first live lane
-        int seed;
-        {
-            float best = 3.4e38f;
-            int bi = 0;
-            for (int j = 0; j < ns; ++j) { const float d = sdist(j); if (d < best) { best = d; bi = j; } }
-            bi = __builtin_amdgcn_readlane(bi, first);
-            best = 3.4e38f;
-            int bl = bi * BVH_FAN;
-            const int l1 = min(nl, (bi + 1) * BVH_FAN);
-            for (int l = bi * BVH_FAN; l < l1; ++l) { const float d = ldist(l); if (d < best) { best = d; bl = l; } }
-            seed = __builtin_amdgcn_readlane(bl, first);
-        }
-        int n_scan = 1, n_open = 0;
-        scan_leaf(seed);
-        // --- which super boxes can still matter to some lane (BVH_MAXS <= 64 -> one 64-bit mask)
-        unsigned long long open = 0ull;
-        for (int j = 0; j < ns; ++j)
-            if (__ballot(sdist(j) * 0.99999f <= d2) != 0ull) open |= 1ull << j;
-        int ord = 0;
-        while (open) {
-            const int sidx = __ffsll((long long)open) - 1;
-            open &= open - 1ull;
-            if (SPLIT > 1 && (ord++ % SPLIT) != (int)(threadIdx.x >> 6)) continue;
-            ++n_open;
-            const int l1 = min(nl, (sidx + 1) * BVH_FAN);
-            for (int l = sidx * BVH_FAN; l < l1; ++l) {
-                if (l == seed) continue;
-                if (__ballot(ldist(l) * 0.99999f <= d2) == 0ull) continue;
-                scan_leaf(l);
-                ++n_scan;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef const f4 __attribute__((address_space(4))) cf4;
+        int n_scan = 0, n_open = 0;
+        if (lm != 0ull) {
+            // --- seed: the super box, then the leaf in it, nearest to the wave's first live query.  Lane j looks at box j (one box test and
+            // a wave minimum instead of a loop over the boxes in every lane); ties -> lowest index.
+            int seed;
+            {
+                auto bc = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), first)); };
+                const float q[3] = {bc(p[0]), bc(p[1]), bc(p[2])};
+                auto wave_argmin = [&](float d) __attribute__((always_inline)) {
+                    float m = d;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+                    return __ffsll((long long)__ballot(d == m)) - 1;
+                };
+                float d = 3.4e38f;
+                if (lane < ns) { const float4 lo = fr.bvh_sbox[2 * lane], hi = fr.bvh_sbox[2 * lane + 1]; d = box_dist2(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); }
+                const int bi = wave_argmin(d);
+                d = 3.4e38f;
+                const int l = bi * BVH_FAN + lane;
+                if (lane < BVH_FAN && l < nl) { const float4 lo = fr.bvh_lbox[2 * l], hi = fr.bvh_lbox[2 * l + 1]; d = box_dist2(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); }
+                seed = bi * BVH_FAN + wave_argmin(d);
+            }
+            n_scan = 1;
+            scan_leaf(seed);
+            // --- the sweep: a super box is opened when any lane may still find a closer vertex in it; its 8 leaf boxes are tested in pairs
+            // (packed subtract / multiply-add on SGPR operands: 18 VALU per pair, 17 per box before), each leaf against the bounds as they
+            // stand after the scans before it.  Boxes come through the scalar cache (no LDS staging, no barrier in the sweep).
+            // SPLIT > 1: wave w of the workgroup sweeps super boxes w, w + SPLIT, ... (a static deal: every wave prunes with its own bounds).
+#pragma unroll 1
+            for (int j = SPLIT > 1 ? (int)(threadIdx.x >> 6) : 0; j < ns; j += SPLIT) {
+                cf4* sbx = (cf4*)(fr.bvh_sbox + 2 * j);
+                const f4 slo = sbx[0], shi = sbx[1];
+                if (__ballot(box_dist2(p, slo.x, slo.y, slo.z, shi.x, shi.y, shi.z) * 0.99999f <= d2) == 0ull) continue;
+                ++n_open;
+#pragma unroll 1
+                for (int pr = 0; pr < BVH_FAN / 2; ++pr) {
+                    cf4* rec = (cf4*)(fr.bvh_lpair + (size_t)j * (6 * BVH_FAN) + 12 * pr);
+                    const f4 ra = rec[0], rb = rec[1], rc = rec[2];          // lo.x[2] lo.y[2] | lo.z[2] hi.x[2] | hi.y[2] hi.z[2]
+                    const f2 ax = f2{ra.x, ra.y} - px2, ay = f2{ra.z, ra.w} - py2, az = f2{rb.x, rb.y} - pz2;
+                    const f2 bx = px2 - f2{rb.z, rb.w}, by = py2 - f2{rc.x, rc.y}, bz = pz2 - f2{rc.z, rc.w};
+                    const f2 ex = {__builtin_fmaxf(__builtin_fmaxf(ax.x, bx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bx.y), 0.f)};
+                    const f2 ey = {__builtin_fmaxf(__builtin_fmaxf(ay.x, by.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ay.y, by.y), 0.f)};
+                    const f2 ez = {__builtin_fmaxf(__builtin_fmaxf(az.x, bz.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(az.y, bz.y), 0.f)};
+                    f2 dd = ex * ex;
+                    dd = __builtin_elementwise_fma(ey, ey, dd);
+                    dd = __builtin_elementwise_fma(ez, ez, dd);
+                    dd *= 0.99999f;
+                    const int l = j * BVH_FAN + 2 * pr;
+                    if (l != seed && __ballot(dd.x <= d2) != 0ull) { scan_leaf(l); ++n_scan; }
+                    if (l + 1 != seed && __ballot(dd.y <= d2) != 0ull) { scan_leaf(l + 1); ++n_scan; }
+                }
             }
         }
         if (SPLIT > 1) {
