@@ -141,7 +141,7 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     const int nleaf = c->use_bvh ? bvh_leaf_count(nv) : 0;
     const int nsuper = bvh_super_count(nleaf);
     if (nleaf > 0) {
-        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * (16 + 12)) || c->fbvh_pairs.ensure((size_t)(nleaf + nsuper) * 32 + (size_t)nsuper * 192)) return 1;
+        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * (16 + 16)) || c->fbvh_pairs.ensure((size_t)(nleaf + nsuper) * 32 + (size_t)nsuper * 192)) return 1;
         launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float4>(), c->fbvh_pairs.as<float4>(),
                          c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf, nleaf, nsuper, s);
         RA_HIP(hipGetLastError());

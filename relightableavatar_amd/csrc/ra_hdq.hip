@@ -21,6 +21,17 @@
 namespace {
 
 constexpr int KNN_THREADS = 256;
+
+#ifdef RA_COARSE_TS
+// test builds (tools/coarse_timestamps.py): the first 64 workgroups of each of the last 64 coarse launches stamp the cycle counter of
+// every wave at the phase boundaries of the search.  [launch & 63][workgroup][wave][8]: 0 start, 1 query point ready, 2 seed found,
+// 3 seed leaf scanned, 4 sweep done, 5 merged (split variants), 6 end of kernel, 7 = leaves scanned << 32 | groups of 4 candidates that entered the insert path << 12 | super boxes opened
+__device__ long long ra_coarse_ts[64 * 64 * 16 * 8];
+extern "C" int ra_coarse_read_timestamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ra_coarse_ts), sizeof(ra_coarse_ts)); }
+#define RA_CSTAMP(k) do { if (tsp) { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) tsp[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define RA_CSTAMP(k) do { } while (0)
+#endif
 constexpr int VT = 2048;    // vertices per LDS tile (32 KB)
 
 __device__ __forceinline__ void inv3d(const float R[9], float M[9]) {   // blend_utils.py:125-165
@@ -159,9 +170,9 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
             v.w = __int_as_float((int)id);
         }
         pts[i] = v;        // padded with +inf points: (p - inf)^2 = inf never beats a finite bound
-        // the same points per leaf as x[32] | y[32] | z[32]: the leaf scan reads candidate PAIRS with wave-uniform addresses
-        float* soa = reinterpret_cast<float*>(pts + (size_t)nl * BVH_LEAF) + (size_t)(i >> 5) * (3 * BVH_LEAF) + (i & 31);
-        soa[0] = v.x; soa[BVH_LEAF] = v.y; soa[2 * BVH_LEAF] = v.z;
+        // the same points per leaf as x[32] | y[32] | z[32] | id[32]: the leaf scan reads groups of candidates with wave-uniform addresses
+        float* soa = reinterpret_cast<float*>(pts + (size_t)nl * BVH_LEAF) + (size_t)(i >> 5) * (4 * BVH_LEAF) + (i & 31);
+        soa[0] = v.x; soa[BVH_LEAF] = v.y; soa[2 * BVH_LEAF] = v.z; soa[3 * BVH_LEAF] = v.w;
     }
     // leaf boxes into LDS scratch (reuse red-sized arrays is too small -> reuse keys' tail? keep simple: global + LDS copy)
     __shared__ float lb[BVH_MAXL][6];
@@ -264,13 +275,24 @@ __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
 // SPLIT > 1 (small launches, < 1 wave per SIMD: the serial sweep of one wave IS the launch time): the SPLIT waves of a
 // workgroup serve the SAME 64 queries and share out the opened super boxes; their three-bests are merged through LDS.
 // Each wave prunes against its own (weaker) bound, which is still conservative, so the merged result is exact.
-template <bool BVH, int SPLIT>
+// STAGE (split variants on a mesh that fits: launch_hdq_coarse): the workgroup first copies the whole box structure into LDS.  A small
+// launch is a chain of dependent reads per wave (box -> leaf boxes -> leaf quarter -> ...), each 1.5-2 k cycles through the scalar cache
+// on its first touch (tools/coarse_timestamps.py: 6-8 k cycles for ONE 32-point leaf, 544 cycles of arithmetic); from LDS each is ~100.
+template <bool BVH, int SPLIT, bool STAGE = false>
 __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
                                                                   HdqOut out, int dbg) {
     static_assert(SPLIT == 1 || (BVH && SPLIT >= 2 && SPLIT <= 16), "SPLIT > 1: the workgroup is SPLIT waves on the same 64 queries");
+    static_assert(!STAGE || SPLIT > 1, "the LDS copy is for the latency-bound split variants");
+    extern __shared__ __attribute__((aligned(16))) float bvh_lds[];      // STAGE: leaves (x|y|z|id) then super boxes then leaf-box pair records
     constexpr int NT = SPLIT == 1 ? KNN_THREADS : 64 * SPLIT;      // threads per workgroup
     // BVH: super + leaf boxes (2 float4 each); brute force: a vertex tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? 16 : VT * 16];       // the O(N) scan's vertex tile
+#ifdef RA_COARSE_TS
+    long long* tsp = blockIdx.x < 64 ? ra_coarse_ts + ((((dbg >> 8) & 63) * 64 + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 : nullptr;
+    dbg &= 255;
+    if (tsp && (threadIdx.x & 63) == 0) { tsp[1] = tsp[2] = tsp[3] = tsp[4] = tsp[5] = tsp[6] = tsp[7] = 0; }
+    RA_CSTAMP(0);
+#endif
     const int n = rs.n_dev ? min(*rs.n_dev, n_launch) : n_launch;
     const int base = blockIdx.x * (SPLIT == 1 ? KNN_THREADS : 64);
     if (base >= n) return;               // whole block idle (uniform)
@@ -279,6 +301,13 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
     const bool live_q = i < n && !(rs.skip && rs.skip[i < n ? i : 0]);
     bool live = live_q;
     if (__syncthreads_count(live_q) == 0) return;       // nothing to query in this workgroup (uniform)
+    if constexpr (STAGE) {
+        const int n_soa = fr.bvh_leaves * BVH_LEAF, n_box = fr.bvh_supers * (2 + 3 * BVH_FAN / 2);       // in float4
+        const float4* g0 = reinterpret_cast<const float4*>(fr.bvh_soa);
+        float4* l4 = reinterpret_cast<float4*>(bvh_lds);
+        for (int j = threadIdx.x; j < n_soa; j += NT) l4[j] = g0[j];
+        for (int j = threadIdx.x; j < n_box; j += NT) l4[n_soa + j] = fr.bvh_sbox[j];          // the pair records follow the super boxes
+    }
     float x[3] = {0.f, 0.f, 0.f};
     if (live) ray_point(rs, i, x);
     // world -> pose: (x - Th) R   (blend_utils.py:252-261)
@@ -287,6 +316,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = xt[0] * fr.R[c] + xt[1] * fr.R[3 + c] + xt[2] * fr.R[6 + c];
 
+    RA_CSTAMP(1);
     float d0 = 3.0e38f, d1 = 3.0e38f, d2 = 3.0e38f;
     int i0 = 0, i1 = 0, i2 = 0;    // valid indices also for idle lanes (they run the table look-ups below)
     if (dbg & 1) { d0 = 1e-4f; d1 = 2e-4f; d2 = 3e-4f; i0 = 0; i1 = 1; i2 = 2; }
@@ -297,6 +327,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         // addresses and no load depends on another one.  Seed: the leaf nearest to the wave's first
         // live lane is scanned first so that every lane starts with a finite bound.
         const int nl = fr.bvh_leaves, ns = fr.bvh_supers;
+        if constexpr (STAGE) __syncthreads();
         if (!live) { d0 = d1 = d2 = -1.f; }            // idle lanes: every test fails, nothing is inserted
         const unsigned long long lm = __ballot(live);
         const int first = lm ? __ffsll((long long)lm) - 1 : 0;
@@ -308,15 +339,37 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         // d = fma(dz, dz, fma(dx, dx, dy * dy)) in both halves: the rounding the O(N) validation scan has (dist2 below).
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 px2 = {p[0], p[0]}, py2 = {p[1], p[1]}, pz2 = {p[2], p[2]};
+#ifdef RA_COARSE_TS
+        int n_rare = 0;
+#endif
         // Eight candidates per coordinate arrive as one s_load_dwordx8 (constant address space: the structure was written by an earlier
         // kernel); the next eight are requested after the first group of the current eight has been tested, so that the compiler's
         // lgkmcnt(0) before the first use does not wait for the request just issued.  Four candidates per branch: two independent
         // packed chains (no dependent-issue bubbles).
         typedef float f8 __attribute__((ext_vector_type(8)));
-        typedef const f8 __attribute__((address_space(4))) cf8;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        // wave-uniform reads of the structure: scalar loads through the constant address space, or LDS broadcasts (STAGE)
+        auto soa8 = [&](int off) __attribute__((always_inline)) {
+            if constexpr (STAGE) return *reinterpret_cast<const f8*>(bvh_lds + off);
+            else return *(const f8 __attribute__((address_space(4)))*)(fr.bvh_soa + off);
+        };
+        auto soa_id4 = [&](int off) __attribute__((always_inline)) {
+            if constexpr (STAGE) return *reinterpret_cast<const i4*>(bvh_lds + off);
+            else return *(const i4 __attribute__((address_space(4)))*)(fr.bvh_soa + off);
+        };
+        const int box0 = nl * (4 * BVH_LEAF);                         // LDS offset of the super boxes (floats)
+        auto box4 = [&](int off) __attribute__((always_inline)) {                       // offset in floats from the first super box
+            if constexpr (STAGE) return *reinterpret_cast<const f4*>(bvh_lds + box0 + off);
+            else return *(const f4 __attribute__((address_space(4)))*)(reinterpret_cast<const float*>(fr.bvh_sbox) + off);
+        };
+        auto box1 = [&](int off) __attribute__((always_inline)) {                       // per-lane read (seed search)
+            if constexpr (STAGE) return bvh_lds[box0 + off];
+            else return reinterpret_cast<const float*>(fr.bvh_sbox)[off];
+        };
         auto scan_leaf = [&](int l) __attribute__((always_inline)) {
-            cf8* L = (cf8*)(fr.bvh_soa + (size_t)l * (3 * BVH_LEAF));
-            f8 cx = L[0], cy = L[4], cz = L[8], nx = cx, ny = cy, nz = cz;
+            const int L = l * (4 * BVH_LEAF);
+            f8 cx = soa8(L), cy = soa8(L + BVH_LEAF), cz = soa8(L + 2 * BVH_LEAF), nx = cx, ny = cy, nz = cz;
             static_for<0, 4>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
                 static_for<0, 2>([&](auto g_) {
@@ -329,20 +382,23 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                     db = __builtin_elementwise_fma(dxb, dxb, db);
                     da = __builtin_elementwise_fma(dza, dza, da);
                     db = __builtin_elementwise_fma(dzb, dzb, db);
-                    if (__builtin_expect(__ballot(fminf(fminf(da.x, da.y), fminf(db.x, db.y)) <= d2) != 0ull, 0)) {   // vertex ids: only on the rare insert path
-                        const float4* v = fr.bvh_pts + l * BVH_LEAF + 8 * q + 4 * g;
-                        knn_insert(da.x, __float_as_int(v[0].w), d0, d1, d2, i0, i1, i2);
-                        knn_insert(da.y, __float_as_int(v[1].w), d0, d1, d2, i0, i1, i2);
-                        knn_insert(db.x, __float_as_int(v[2].w), d0, d1, d2, i0, i1, i2);
-                        knn_insert(db.y, __float_as_int(v[3].w), d0, d1, d2, i0, i1, i2);
+                    if (__builtin_expect(__ballot(fminf(fminf(da.x, da.y), fminf(db.x, db.y)) <= d2) != 0ull, 0)) {
+#ifdef RA_COARSE_TS
+                        ++n_rare;
+#endif
+                        // the vertex ids are only needed here; near the surface this path is NOT rare (the 64 queries of a wave find their
+                        // neighbours all over the leaf under them): one scalar load, not a vector-memory round trip per group
+                        const i4 id = soa_id4(L + 3 * BVH_LEAF + 8 * q + 4 * g);
+                        knn_insert(da.x, id.x, d0, d1, d2, i0, i1, i2);
+                        knn_insert(da.y, id.y, d0, d1, d2, i0, i1, i2);
+                        knn_insert(db.x, id.z, d0, d1, d2, i0, i1, i2);
+                        knn_insert(db.y, id.w, d0, d1, d2, i0, i1, i2);
                     }
-                    if constexpr (g == 0 && q < 3) { nx = L[q + 1]; ny = L[4 + q + 1]; nz = L[8 + q + 1]; }
+                    if constexpr (g == 0 && q < 3) { nx = soa8(L + 8 * (q + 1)); ny = soa8(L + BVH_LEAF + 8 * (q + 1)); nz = soa8(L + 2 * BVH_LEAF + 8 * (q + 1)); }
                 });
                 cx = nx; cy = ny; cz = nz;
             });
         };
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        typedef const f4 __attribute__((address_space(4))) cf4;
         int n_scan = 0, n_open = 0;
         if (lm != 0ull) {
             // --- seed: the super box, then the leaf in it, nearest to the wave's first live query.  Lane j looks at box j (one box test and
@@ -358,29 +414,30 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                     return __ffsll((long long)__ballot(d == m)) - 1;
                 };
                 float d = 3.4e38f;
-                if (lane < ns) { const float4 lo = fr.bvh_sbox[2 * lane], hi = fr.bvh_sbox[2 * lane + 1]; d = box_dist2(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); }
+                if (lane < ns) { const int o = 8 * lane; d = box_dist2(q, box1(o), box1(o + 1), box1(o + 2), box1(o + 4), box1(o + 5), box1(o + 6)); }
                 const int bi = wave_argmin(d);
                 d = 3.4e38f;
-                const int l = bi * BVH_FAN + lane;
-                if (lane < BVH_FAN && l < nl) { const float4 lo = fr.bvh_lbox[2 * l], hi = fr.bvh_lbox[2 * l + 1]; d = box_dist2(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z); }
+                // leaf `lane` of that super box, from its pair record (a missing leaf is an inverted box: infinitely far)
+                if (lane < BVH_FAN) { const int o = 8 * ns + bi * (6 * BVH_FAN) + 12 * (lane >> 1) + (lane & 1); d = box_dist2(q, box1(o), box1(o + 2), box1(o + 4), box1(o + 6), box1(o + 8), box1(o + 10)); }
                 seed = bi * BVH_FAN + wave_argmin(d);
             }
+            RA_CSTAMP(2);
             n_scan = 1;
             scan_leaf(seed);
+            RA_CSTAMP(3);
             // --- the sweep: a super box is opened when any lane may still find a closer vertex in it; its 8 leaf boxes are tested in pairs
             // (packed subtract / multiply-add on SGPR operands: 18 VALU per pair, 17 per box before), each leaf against the bounds as they
             // stand after the scans before it.  Boxes come through the scalar cache (no LDS staging, no barrier in the sweep).
             // SPLIT > 1: wave w of the workgroup sweeps super boxes w, w + SPLIT, ... (a static deal: every wave prunes with its own bounds).
 #pragma unroll 1
             for (int j = SPLIT > 1 ? (int)(threadIdx.x >> 6) : 0; j < ns; j += SPLIT) {
-                cf4* sbx = (cf4*)(fr.bvh_sbox + 2 * j);
-                const f4 slo = sbx[0], shi = sbx[1];
+                const f4 slo = box4(8 * j), shi = box4(8 * j + 4);
                 if (__ballot(box_dist2(p, slo.x, slo.y, slo.z, shi.x, shi.y, shi.z) * 0.99999f <= d2) == 0ull) continue;
                 ++n_open;
 #pragma unroll 1
                 for (int pr = 0; pr < BVH_FAN / 2; ++pr) {
-                    cf4* rec = (cf4*)(fr.bvh_lpair + (size_t)j * (6 * BVH_FAN) + 12 * pr);
-                    const f4 ra = rec[0], rb = rec[1], rc = rec[2];          // lo.x[2] lo.y[2] | lo.z[2] hi.x[2] | hi.y[2] hi.z[2]
+                    const int ro = 8 * ns + j * (6 * BVH_FAN) + 12 * pr;
+                    const f4 ra = box4(ro), rb = box4(ro + 4), rc = box4(ro + 8);          // lo.x[2] lo.y[2] | lo.z[2] hi.x[2] | hi.y[2] hi.z[2]
                     const f2 ax = f2{ra.x, ra.y} - px2, ay = f2{ra.z, ra.w} - py2, az = f2{rb.x, rb.y} - pz2;
                     const f2 bx = px2 - f2{rb.z, rb.w}, by = py2 - f2{rc.x, rc.y}, bz = pz2 - f2{rc.z, rc.w};
                     const f2 ex = {__builtin_fmaxf(__builtin_fmaxf(ax.x, bx.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(ax.y, bx.y), 0.f)};
@@ -396,6 +453,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                 }
             }
         }
+        RA_CSTAMP(4);
+#ifdef RA_COARSE_TS
+        if (tsp && (threadIdx.x & 63) == 0) tsp[7] = ((long long)n_scan << 32) | ((long long)n_rare << 12) | n_open;
+#endif
         if (SPLIT > 1) {
             __shared__ float md[SPLIT > 1 ? SPLIT - 1 : 1][3][64];
             __shared__ int mi[SPLIT > 1 ? SPLIT - 1 : 1][3][64];
@@ -419,6 +480,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                 live = false;           // waves 1.. only helped with the search
             }
         }
+        RA_CSTAMP(5);
         if ((dbg & 4) && out.counters && lane == 0) {
             atomicAdd(&out.counters->n_shadow_rays, (unsigned long long)n_scan);      // profiling aid: leaves scanned
             atomicAdd(&out.counters->n_hit_pixels, (unsigned long long)n_open);       //                supers opened
@@ -490,6 +552,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         wcount[NT / 64] = (dbg & 8) ? base : (tot ? atomicAdd(out.fine_count, tot) : 0);
     }
     __syncthreads();
+    RA_CSTAMP(6);
     if (!fine || (dbg & 16)) return;
     const int slot = wcount[NT / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
     // gaussian-weighted blend of the per-vertex transforms (base_network.py:287-296)
@@ -569,13 +632,19 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     const dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS);
     // launches below ~1.5 waves per SIMD are latency-bound: spread each group of 64 queries over the 4 waves of a workgroup
     int dbg = 0, probe = 0, split_max = 98304;
+    bool allow_stage = true;
 #ifdef RA_TESTING            // profiling aids (test builds only, tools/build_variant.sh)
     // RA_COARSE_DBG: 1 skip the search, 2 skip everything after it.  RA_COARSE_PROBE: an extra launch in ablation mode `probe` on the
     // SAME inputs before every real launch (which then overwrites its outputs): the ablated time is read from a kernel trace
     static const int e_dbg = getenv("RA_COARSE_DBG") ? atoi(getenv("RA_COARSE_DBG")) : 0;
     static const int e_probe = getenv("RA_COARSE_PROBE") ? atoi(getenv("RA_COARSE_PROBE")) : 0;
     static const int e_split = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 98304;
-    dbg = e_dbg; probe = e_probe; split_max = e_split;
+    static const int e_stage = getenv("RA_COARSE_STAGE") ? atoi(getenv("RA_COARSE_STAGE")) : 1;
+    dbg = e_dbg; probe = e_probe; split_max = e_split; allow_stage = e_stage != 0;
+#endif
+#ifdef RA_COARSE_TS
+    static int launch_no = 0;
+    dbg |= (launch_no++ & 63) << 8;
 #endif
     for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
         const int d = pass == 0 ? probe : dbg;
@@ -583,7 +652,17 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
         {
             // more waves per 64 queries the smaller the launch (about 4-8 k waves in flight on the 1024 SIMDs)
             const int groups = (n + 63) / 64;
-            if (n <= split_max / 8) hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
+            // Smallest launches (one workgroup per CU or fewer): the box structure in LDS if it fits beside the merge buffers (SMPL: 216
+            // leaves, 27 super boxes = 114 KB).  Measured (MI355X, 512 x 512): 5 k queries per launch (one rank of eight) 7.00 -> 6.85 ms per
+            // frame; at 40 k queries the copy costs more than it saves (one workgroup per CU instead of four: 3.00 -> 3.29 ms).
+            const size_t lds = ((size_t)fr.bvh_leaves * (4 * BVH_LEAF) + (size_t)fr.bvh_supers * (8 + 6 * BVH_FAN)) * sizeof(float);
+            if (n <= split_max / 8) {
+                if (allow_stage && lds <= 134 * 1024) {
+                    static bool raised = false;             // allow > 64 KB of dynamic LDS, once
+                    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(hdq_coarse_kernel<true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 134 * 1024); raised = true; }
+                    hipLaunchKernelGGL((hdq_coarse_kernel<true, 16, true>), dim3(groups), dim3(1024), lds, s, fr, rs, n, th, inv2r2, out, d);
+                } else hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
+            }
             else if (n <= split_max / 2) hipLaunchKernelGGL((hdq_coarse_kernel<true, 8>), dim3(groups), dim3(512), 0, s, fr, rs, n, th, inv2r2, out, d);
             else hipLaunchKernelGGL((hdq_coarse_kernel<true, 4>), dim3(groups), dim3(256), 0, s, fr, rs, n, th, inv2r2, out, d);
         }
