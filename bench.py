@@ -26,6 +26,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from relightableavatar_amd import synthetic, shard          # noqa: E402
+from relightableavatar_amd.pipeline import FramePipeline    # noqa: E402
 from relightableavatar_amd.config import make_cfg           # noqa: E402
 from relightableavatar_amd.networks import make_network     # noqa: E402
 from relightableavatar_amd.renderer import make_renderer    # noqa: E402
@@ -173,6 +174,7 @@ def main():
     ap.add_argument('--static-frame', action='store_true', help='A/B: do not re-pose the body every step (round-1 behaviour: per-frame set-up outside the timed region)')
     ap.add_argument('--k4-batch', type=int, default=0, help='cfg.k4_batch_slots: full queries per forward+backward launch pair (0 = library default)')
     ap.add_argument('--soak', type=float, default=3.0, help='seconds of untimed frames BEFORE the W warm-up steps: the chip is power-limited on this path (DESIGN.md section 4), so the clock of a cold 0.7 s burst is not the sustained one')
+    ap.add_argument('--frames-in-flight', type=int, default=2, help='frames kept in flight on as many HIP streams (relightableavatar_amd/pipeline.py): the latency-bound small-kernel phase of frame f + 1 runs beside the light-visibility stage of frame f, the stages themselves are serialised by a gate.  1 = strictly sequential frames')
     ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 
@@ -209,23 +211,28 @@ def main():
         kw['novel_light_timing'] = False     # nobody reads `diff` here: no host sync inside the frame
     cfg = make_cfg(args.mode, mlp_dtype=args.dtype, **kw)
     relight = args.mode in ('relight', 'novel_light')
-    net = make_network(cfg)
-    net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg))
-    net = net.to(dev).eval()
-    renderer = make_renderer(cfg, net)
-    base = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0,
-                                                    skin_noise=args.skin_noise), dev)
+    D = max(1, args.frames_in_flight)
+    pipe = FramePipeline(cfg, synthetic.make_state_dict(0, relight=relight, cfg=cfg), dev, depth=D)
+    net, renderer = pipe.networks[0], pipe.renderers[0]
+    # one batch per replica: a frame in flight owns its body state and its in-place grown box until it has been consumed
+    bases = [synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0,
+                                                      skin_noise=args.skin_noise), dev) for _ in range(D)]
+    base = bases[0]
     P = base.ray_o.shape[1]
     wb0 = base.wbounds.clone()
     mask0 = base.mask_at_box.clone()
-    eng = net.engine()
+    engs = pipe.engines()
 
     mask_host = base.mask_at_box.cpu()          # the loader's copy: the shard plan is host work (shard.make_plan)
     wbh0 = wb0.cpu()
     nw = args.emulate_world if args.emulate_world > 1 else world          # --emulate-world N: rank 0's share of an N-rank job, no collective
     rk = 0 if args.emulate_world > 1 else rank
 
-    def step():
+    frame_no = [0]
+
+    def frame(net_r, rend_r):
+        base = bases[frame_no[0] % D]
+        eng = net_r.engine()
         # a fresh batch per frame, as the reference's loader delivers: body box (device tensor + the loader's host copy), mask
         base.wbounds.copy_(wb0)
         base.wbounds_host, base.wbounds_host_version = wbh0.clone(), base.wbounds._version
@@ -236,12 +243,18 @@ def main():
         # a new frame has a new mask: the shard plan (ownership + exchange index vectors) is rebuilt every step, inside the timed region
         pl = shard.make_plan(P, nw, base, dev, mask=mask_host, ground=args.ground, render_chunk_size=cfg.render_chunk_size, use_cache=False) if nw > 1 else None
         if args.mode == 'novel_light':      # config 5: main pass + all probes re-shaded in one launch (per-rank shard)
-            out = renderer.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
+            out = rend_r.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
             rgb = torch.cat([out[n].rgb_map for n in base.novel_lights], dim=-1)
             return rgb if args.emulate_world > 1 else shard.gather_maps(rgb, P, rank, world, plan=pl, ground=args.ground)
         if args.emulate_world > 1:
-            return renderer.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
-        return shard.render_sharded(renderer, base, ('rgb_map', 'acc_map'), rank, world, plan=pl)
+            return rend_r.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
+        return shard.render_sharded(rend_r, base, ('rgb_map', 'acc_map'), rank, world, plan=pl)
+
+    def step():
+        # queued on the next replica's stream (frames-in-flight 1: the current stream); the timed region ends with a device-wide sync
+        p = pipe.submit(fn=frame)
+        frame_no[0] += 1
+        return p
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -266,34 +279,47 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    eng.reset_counters()
-    eng.enable_timing(True)
+    for e in engs:
+        e.reset_counters()
+        e.enable_timing(True)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync()
     dt = time.perf_counter() - t0
-    eng.enable_timing(False)
+    for e in engs:
+        e.enable_timing(False)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    cnt = eng.counters()
-    mlp_ms, mlp_launches = eng.kernel_time(1 if args.mode == 'anisdf' else 0)
+    from relightableavatar_amd.base_utils import dotdict
+    cnt = dotdict()
+    for e in engs:                                  # every replica counted its own frames
+        for k, v in e.counters().items():
+            cnt[k] = cnt.get(k, 0) + v
+    # the dominant kernel: the full query on the volume path, else the 8-wave distance query (the launches that fill the chip; kind 2) —
+    # a frame without such launches (sphere tracing at 512 x 512, a small rank share) reports all distance-query launches (kind 0)
+    wide = args.mode != 'anisdf' and cnt.get('n_fine_sdf_wide', 0) > 0
+    kind = 1 if args.mode == 'anisdf' else (2 if wide else 0)
+    mlp_ms, mlp_launches = 0.0, 0
+    for e in engs:
+        ms_e, n_e = e.kernel_time(kind)
+        mlp_ms, mlp_launches = mlp_ms + ms_e, mlp_launches + n_e
     cnts = torch.tensor([cnt.n_fine_sdf, cnt.n_fine_full, cnt.n_coarse, cnt.n_hit_pixels, cnt.n_shadow_rays], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(cnts)
     if rank == 0:
         ms = dt / args.steps * 1e3
-        kname = 'mlp_sdf_stream_kernel'
-        units, f_unit = cnt.n_fine_sdf, F_SDF
+        kname = 'mlp_sdf_stream_kernel<f16|bf16, 8>' if wide else 'mlp_sdf_stream_kernel'
+        units, f_unit = (cnt.n_fine_sdf_wide if wide else cnt.n_fine_sdf), F_SDF
         if args.mode == 'anisdf':           # the volume path has no distance-only queries: its dominant kernel is the full query
             # the full query = two kernels per launch (forward with tape, reverse-mode backward + colour net); the timer brackets both
             kname, units, f_unit = 'mlp_fwd_tape_kernel+mlp_bwd_heads_kernel', cnt.n_fine_full, F_FULL_ANISDF
         achieved = (units * f_unit) / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-        default_cmd = args.mode == 'relight' and H == 512 and world == 1 and kname == 'mlp_sdf_stream_kernel' and not args.ground
-        traffic, traffic_src = hbm_traffic_per_launch(kname) if default_cmd else (None, None)
+        default_cmd = args.mode == 'relight' and H == 512 and world == 1 and wide and not args.ground and args.emulate_world <= 1
+        traffic, traffic_src = hbm_traffic_per_launch('mlp_sdf_stream_kernel_w8') if default_cmd else (None, None)
         if args.mode == 'anisdf' and H == 512 and world == 1 and '+' in kname:
             traffic, traffic_src = hbm_traffic_per_launch(kname, 'anisdf512')
         line = {
@@ -317,6 +343,7 @@ def main():
         line['config']['frame_setup'] = 'static frame (set-up excluded)' if args.static_frame else 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
         line['config']['soak'] = f'{n_soak} untimed frames in {args.soak:.1f} s before the {args.warmup} warm-up steps'
         line['config']['soak_frames'] = n_soak
+        line['config']['frames_in_flight'] = D
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ref = cpu_baseline(cfg, H, args.skin_noise)
             if args.mode in ('relight', 'sphere_tracing', 'anisdf') and not args.ground and args.emulate_world <= 1:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 3
+#define RA_ABI_VERSION 4
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -213,6 +213,7 @@ typedef struct ra_counters {       /* cumulative since ra_reset_counters; read w
     uint64_t n_shadow_rays;
     uint64_t n_hit_pixels;
     uint64_t n_shaded;             /* pixel x probe shading evaluations                       */
+    uint64_t n_fine_sdf_wide;      /* the part of n_fine_sdf computed by the 8-wave distance kernel (launches that fill the chip) */
 } ra_counters;
 int ra_get_counters(ra_ctx* ctx, ra_counters* out, void* stream); /* synchronises stream */
 int ra_reset_counters(ra_ctx* ctx, void* stream);
@@ -220,9 +221,22 @@ int ra_reset_counters(ra_ctx* ctx, void* stream);
 /* time (ms) spent in the fused MLP kernel launches since the last reset, measured with HIP
  * events on `stream`; n_launches receives the launch count.  Synchronises. */
 int ra_get_mlp_time(ra_ctx* ctx, float* ms, int* n_launches, void* stream);
-/* the same for one kernel family: kind 0 = fused distance query (K3), 1 = full query with normals / material / colour (K4) */
+/* the same for one kernel family: kind 0 = fused distance query (K3, every width), 1 = full query with normals / material / colour (K4),
+ * 2 = the 8-wave distance query only (the launches that fill the chip: the frame's dominant kernel), 3 = the 2- / 4-wave distance query */
 int ra_get_kernel_time(ra_ctx* ctx, int kind, float* ms, int* n_launches, void* stream);
 int ra_enable_timing(ra_ctx* ctx, int on);
+/* ---- frames in flight --------------------------------------------------------------------------------------------
+ * Throughput aid with no counterpart in the reference (its frame loop is sequential: lib/evaluators, run.py).  Several contexts on
+ * several HIP streams render DIFFERENT frames at once; contexts that share a gate run their light-visibility stages (the frame's
+ * large distance-query launches, sphere_tracing_renderer.py:265-344) one after the other in submission order, while everything
+ * else of the next frame (pose, box structure, the 16 latency-bound surface-tracing iterations, normals, shading) runs beside the
+ * previous frame's stage.  Frames are bit-identical with and without.  A gate is used from ONE host thread; it must outlive the
+ * contexts attached to it (detach with gate = NULL). */
+typedef struct ra_gate ra_gate;
+int ra_gate_create(ra_gate** out, int device);
+int ra_gate_destroy(ra_gate* gate);
+int ra_set_gate(ra_ctx* ctx, ra_gate* gate);
+
 /* 1 (default): exact 3-NN through the per-frame vertex BVH; 0: brute force over all vertices (validation path).
  * Takes effect at the next ra_set_frame. Both return identical neighbours. */
 int ra_set_knn_mode(ra_ctx* ctx, int use_bvh);

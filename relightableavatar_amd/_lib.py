@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RA_LIB_PATH') or os.path.join(_HERE, 'librelightableavatar_hip.so')    # override: kernel experiments (tools/)
 _lib = None
-ABI_VERSION = 3          # RA_ABI_VERSION of include/relightableavatar.h
+ABI_VERSION = 4          # RA_ABI_VERSION of include/relightableavatar.h
 
 
 class RaError(RuntimeError):
@@ -83,7 +83,7 @@ class ra_image_params(C.Structure):
 
 
 class ra_counters(C.Structure):
-    _fields_ = [(k, C.c_uint64) for k in ('n_coarse', 'n_fine_sdf', 'n_fine_full', 'n_shadow_rays', 'n_hit_pixels', 'n_shaded')]
+    _fields_ = [(k, C.c_uint64) for k in ('n_coarse', 'n_fine_sdf', 'n_fine_full', 'n_shadow_rays', 'n_hit_pixels', 'n_shaded', 'n_fine_sdf_wide')]
 
 
 # every symbol include/relightableavatar.h declares
@@ -117,6 +117,9 @@ SYMBOLS = {
     'ra_get_kernel_time': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
     'ra_enable_timing': (C.c_int, [C.c_void_p, C.c_int]),
     'ra_set_knn_mode': (C.c_int, [C.c_void_p, C.c_int]),
+    'ra_gate_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    'ra_gate_destroy': (C.c_int, [C.c_void_p]),
+    'ra_set_gate': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ra_pose_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_pose_in), C.POINTER(ra_pose_out), C.c_void_p]),
     'ra_shift_envmap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'ra_add_light_probe': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),

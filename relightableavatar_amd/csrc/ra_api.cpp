@@ -53,6 +53,30 @@ int ra_ctx_create(ra_ctx** out, int device) {
     return 0;
 }
 
+int ra_gate_create(ra_gate** out, int device) {
+    RA_CHECK(out, "ra_gate_create: null out");
+    RA_HIP(hipSetDevice(device));
+    ra_gate* g = new ra_gate();
+    g->device = device;
+    if (hipEventCreateWithFlags(&g->done, hipEventDisableTiming) != hipSuccess) { delete g; ra_set_error("ra_gate_create: hipEventCreate failed"); return 1; }
+    *out = g;
+    return 0;
+}
+int ra_gate_destroy(ra_gate* g) {
+    if (!g) return 0;
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    hipEventDestroy(g->done);
+    delete g;
+    return 0;
+}
+int ra_set_gate(ra_ctx* c, ra_gate* g) {
+    RA_CHECK(c, "ra_set_gate: null context");
+    RA_CHECK(!g || g->device == c->device, "ra_set_gate: gate and context live on different devices");
+    c->gate = g;
+    return 0;
+}
+
 int ra_ctx_destroy(ra_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
@@ -224,7 +248,7 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
-        Timer t(c, s, 0);
+        Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
         k3_launch(c, io, n, s);
     }
     return 0;
@@ -343,7 +367,7 @@ int ra_observed_sdf(ra_ctx* c, const float* bpts, int n, float* sdf, void* strea
     io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = sdf; io.dist_th = 1.f; io.smooth = 0;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     {
-        Timer t(c, s, 0);
+        Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
         k3_launch(c, io, n, s);
     }
     RA_HIP(hipGetLastError());
@@ -450,6 +474,8 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         ssdf = c->buf<float>("sh_sdf", NR, &err);
     }
     if (err) return 1;
+    // frames in flight: this stage (the frame's large launches) starts when the stage submitted before it through the same gate has ended
+    if (c->gate && c->gate->armed) RA_HIP(hipStreamWaitEvent(s, c->gate->done, 0));
     launch_shadow_gen(g, P, s, c->cnt_zero);     // the chunk's bulk memset covers the first shadow stage; a second one zeroes its counter itself
     c->cnt_zero = false;
     if (traced) {
@@ -466,6 +492,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
         launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);
     }
+    if (c->gate) { RA_HIP(hipEventRecord(c->gate->done, s)); c->gate->armed = true; }
     *lvis_out = lvis;
     *ldot_out = ldot;
     return 0;
@@ -771,6 +798,7 @@ int ra_get_counters(ra_ctx* c, ra_counters* out, void* stream) {
     out->n_shadow_rays = h[3];
     out->n_hit_pixels = h[4];
     out->n_shaded = c->n_shaded + h[4];
+    out->n_fine_sdf_wide = h[5];
     return 0;
 }
 
@@ -1039,13 +1067,14 @@ int ra_enable_timing(ra_ctx* c, int on) {
 
 int ra_get_kernel_time(ra_ctx* c, int kind, float* ms, int* n_launches, void* stream) {
     RA_CHECK(c && ms && n_launches, "ra_get_kernel_time: null argument");
-    RA_CHECK(kind == 0 || kind == 1, "ra_get_kernel_time: kind must be 0 (distance query) or 1 (full query)");
+    RA_CHECK(kind >= 0 && kind <= 3, "ra_get_kernel_time: kind must be 0 (distance query), 1 (full query), 2 (8-wave distance query) or 3 (narrow distance query)");
     RA_HIP(hipSetDevice(c->device));
     RA_HIP(hipStreamSynchronize((hipStream_t)stream));
     float tot = 0.f;
     int n = 0;
     for (size_t i = 0; i < c->ev_used; ++i) {
-        if (c->ev_kind[i] != kind) continue;
+        const int k = c->ev_kind[i];          // internal: 0 = 8-wave K3, 2 = narrow K3, 1 = K4
+        if (!(kind == 0 ? (k == 0 || k == 2) : kind == 1 ? k == 1 : kind == 2 ? k == 0 : k == 2)) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { tot += t; ++n; }
     }

@@ -71,6 +71,7 @@ struct FrameState {         // device pointers owned by the ctx
 
 struct DevCounters {       // device-side work counters (ra_get_counters)
     unsigned long long n_coarse, n_fine_sdf, n_fine_full, n_shadow_rays, n_hit_pixels;
+    unsigned long long n_fine_sdf_wide;      // the part of n_fine_sdf that went through the 8-wave K3 (launches that fill the chip)
 };
 
 struct MlpIO {
@@ -111,6 +112,9 @@ struct FullIO {             // the full query: geometry with normal + material /
 // K3 (ra_k3.hpp): HDQ fine distance query; activations stay in registers, weights stream through LDS (sarena: ra_pack.cpp StreamBuilder).
 // One translation unit per operand type: IEEE half (production) and bfloat16.
 // sarena_pairs: the same fragments with the row blocks of a layer interleaved in pairs (the 2- / 4-wave latency variants)
+// K3 workgroup width by the launch's upper bound of fine points (ra_k3.hpp launch_k3): 2 / 4 waves (one per SIMD) for launches that
+// cannot fill the 256 CUs with 256-point tiles, 8 waves otherwise
+inline int k3_waves(int max_slots) { return max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8); }
 void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
                                int max_slots, hipStream_t stream);
 void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,

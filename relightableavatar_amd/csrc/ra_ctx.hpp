@@ -28,8 +28,16 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// serialises the light-visibility stages of the contexts that share it (include/relightableavatar.h, "frames in flight")
+struct ra_gate {
+    int device = 0;
+    hipEvent_t done = nullptr;      // end of the last stage submitted through the gate
+    bool armed = false;
+};
+
 struct ra_ctx {
     int device = 0;
+    ra_gate* gate = nullptr;
     ra_config cfg{};
     bool have_cfg = false, have_weights = false, have_frame = false;
     std::map<std::string, std::vector<float>> state_dict;

@@ -164,7 +164,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     if (tid == 0) sm.count = *io.count;
     __syncthreads();
     const int count = sm.count;
-    if (blockIdx.x == 0 && tid == 0 && io.counters) atomicAdd(&io.counters->n_fine_sdf, (unsigned long long)count);
+    if (blockIdx.x == 0 && tid == 0 && io.counters) {
+        atomicAdd(&io.counters->n_fine_sdf, (unsigned long long)count);
+        if (NW == 8) atomicAdd(&io.counters->n_fine_sdf_wide, (unsigned long long)count);
+    }
     const int ntiles = (count + ST_TM - 1) / ST_TM;
     if ((int)blockIdx.x >= ntiles) return;
 
@@ -259,7 +262,7 @@ template <typename E>
 static void launch_k3(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
                       hipStream_t stream) {
     if (max_slots <= 0) return;
-    int nw = max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8);
+    int nw = k3_waves(max_slots);
 #ifdef RA_TESTING            // test / experiment builds only (tools/build_variant.sh): force the workgroup width
     static const int force = getenv("RA_STREAM_NW") ? atoi(getenv("RA_STREAM_NW")) : 0;
     if (force) nw = force;

@@ -253,6 +253,11 @@ class Engine:
     def reset_counters(self):
         check(self.lib.ra_reset_counters(self.ctx, self.stream), 'ra_reset_counters')
 
+    def set_gate(self, gate):
+        """attach (or, with None, detach) a pipeline.Gate: contexts sharing one run their light-visibility stages one after the other"""
+        check(self.lib.ra_set_gate(self.ctx, gate.handle if gate is not None else C.c_void_p()), 'ra_set_gate')
+        self._gate = gate        # keeps it alive as long as the context refers to it
+
     def set_knn_mode(self, use_bvh=True):
         check(self.lib.ra_set_knn_mode(self.ctx, int(use_bvh)), 'ra_set_knn_mode')
         self._frame_key = None
@@ -333,7 +338,8 @@ class Engine:
         return float(ms.value), int(n.value)
 
     def kernel_time(self, kind):
-        """(ms, launches) of one kernel family since the last reset: 0 = fused distance query (K3), 1 = full query (K4)."""
+        """(ms, launches) of one kernel family since the last reset: 0 = fused distance query (K3, every width), 1 = full query (K4),
+        2 = the 8-wave K3 only (launches that fill the chip), 3 = the 2- / 4-wave K3."""
         ms, n = C.c_float(), C.c_int()
         check(self.lib.ra_get_kernel_time(self.ctx, int(kind), C.byref(ms), C.byref(n), self.stream), 'ra_get_kernel_time')
         return float(ms.value), int(n.value)

@@ -38,18 +38,18 @@ cp $OUT/kt_g/r_kernel_stats.csv $OUT/${RN}_relight_ground512_kernel_stats.csv
 i=0
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --soak 0 > /dev/null 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --soak 0 --frames-in-flight 1 > /dev/null 2>&1
 done
 # the same two HBM counters for the volume path (the full query's tape traffic)
 for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmcv$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline --soak 0 > /dev/null 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmcv$i -o r -- python3 $R/bench.py --mode anisdf --steps 2 --warmup 1 --no-cpu-baseline --soak 0 --frames-in-flight 1 > /dev/null 2>&1
 done
 python3 - <<'P'
 import csv, glob, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof'
 rn = os.environ.get('RA_ROUND', 'r03')
-fams = (('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
+fams = (('mlp_sdf_stream_kernelIDF16_Li8E', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream_kernel<_Float16, 8>', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
         ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'))
 for pat, name in (('/pmc[0-9]*/', 'relight512'), ('/pmcv[0-9]*/', 'anisdf512')):      # one summary per workload
     agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
