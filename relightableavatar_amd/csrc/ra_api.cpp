@@ -258,6 +258,13 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
 // cfg.k4_batch_slots fine slots that share ONE tape (4.9 KB per slot).  n is only the upper bound of the device-side
 // count: launch pairs beyond it find no tile and exit at once.
 int full_query(ra_ctx* c, FullIO io, int n, hipStream_t s) {
+    // frames in flight: a full query that fills the chip (the volume path's) takes its turn at the gate like a light-visibility stage
+    const bool gated = c->gate && n > 65536;
+    if (gated && c->gate->armed) RA_HIP(hipStreamWaitEvent(s, c->gate->done, 0));
+    struct Release {
+        ra_ctx* c; hipStream_t s; bool on;
+        ~Release() { if (on) { hipEventRecord(c->gate->done, s); c->gate->armed = true; } }
+    } release{c, s, gated};
     Timer t(c, s, 1);
     const int batch = c->cfg.k4_batch_slots > 0 ? c->cfg.k4_batch_slots : (1 << 20);
     const int cap = n < batch ? n : batch;
