@@ -255,6 +255,13 @@ typedef struct ra_ground_params {
     ra_trace_params shadow;     /* cfg.env_lvis as a trace-parameter block */
     float shadow_near_offset;   /* cfg.env_lvis.near_offset */
     int no_visibility, local_visibility;
+    /* Several of the reference's render chunks in ONE call (their launches merged; pixels identical): pixel r of the call belongs to chunk j
+     * with box_start[j] <= r < box_start[j + 1] and its shadow rays are clipped against boxes[6 j .. 6 j + 5], the box the reference's
+     * in-place growth (sphere_tracing_renderer.py:1054-1056) had reached at that chunk — computed by the caller, in the reference's float
+     * arithmetic.  n_boxes = 0 or 1: the call is one chunk and uses the bbox argument.  At most 32 boxes per call. */
+    int n_boxes;
+    const float* boxes;         /* host, n_boxes x 6 */
+    const int* box_start;       /* host, n_boxes + 1 ascending pixel indices, box_start[0] = 0, box_start[n_boxes] = P */
 } ra_ground_params;
 
 typedef struct ra_ground_out {  /* device buffers with P rows, any may be NULL */

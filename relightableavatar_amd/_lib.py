@@ -54,7 +54,8 @@ class ra_sphere_params(C.Structure):
 class ra_ground_params(C.Structure):
     _fields_ = [('normal', C.c_float * 3), ('origin', C.c_float * 3), ('albedo', C.c_float * 3), ('attach_envmap', C.c_int),
                 ('env_r', C.c_float), ('shading_multiplier', C.c_float), ('shadow', ra_trace_params), ('shadow_near_offset', C.c_float),
-                ('no_visibility', C.c_int), ('local_visibility', C.c_int)]
+                ('no_visibility', C.c_int), ('local_visibility', C.c_int), ('n_boxes', C.c_int), ('boxes', C.POINTER(C.c_float)),
+                ('box_start', C.POINTER(C.c_int))]
 
 
 GROUND_OUT_KEYS = ('rgb', 'surf', 'albedo', 'shade', 'spec', 'depth', 'lvis', 'ldot')

@@ -454,7 +454,8 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
 // visibility; rays that face the light and cross the box are sphere traced with the DFSS state machine (HOT LOOP B).
 static int light_visibility_stage(ra_ctx* c, const float* surf, const float* norm_slots, const float* acc, const int* hit_idx,
                                   const int* hit_count, int P, const float* bbox, float near_offset, const ra_trace_params& shadow,
-                                  int no_visibility, int local_visibility, float** lvis_out, float** ldot_out, hipStream_t s) {
+                                  int no_visibility, int local_visibility, float** lvis_out, float** ldot_out, hipStream_t s,
+                                  int n_boxes = 0, const float* boxes = nullptr, const int* box_start = nullptr) {
     int err = 0;
     const int L = c->n_lights;
     const size_t NR = (size_t)P * L;
@@ -463,6 +464,12 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
     ShadowGen g{};
     g.surf = surf; g.norm = norm_slots; g.acc = acc; g.hit_idx = hit_idx; g.hit_count = hit_count; g.ldir = c->light_dir.as<float>();
     for (int k = 0; k < 6; ++k) g.bbox[k] = bbox[k];
+    g.n_boxes = n_boxes > 1 ? n_boxes : 0;
+    for (int j = 0; j < g.n_boxes; ++j) {
+        for (int k = 0; k < 6; ++k) g.boxes[j][k] = boxes[6 * j + k];
+        g.box_start[j] = box_start[j];
+    }
+    if (g.n_boxes) g.box_start[g.n_boxes] = box_start[g.n_boxes];
     g.near_offset = near_offset; g.L = L; g.no_visibility = no_visibility; g.local_visibility = local_visibility;
     g.lvis = lvis; g.ldot = ldot;
     const bool traced = !(no_visibility || local_visibility);
@@ -651,6 +658,11 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     RA_CHECK(ray_o && ray_d && acc && bbox && probe, "ra_render_ground_chunk: null argument");
     RA_CHECK(c->cfg.relight && c->n_lights > 0, "ra_render_ground_chunk: needs the relight network's light set");
     RA_CHECK((long long)P * c->n_lights < (1ll << 31), "ra_render_ground_chunk: chunk too large (P x lights must fit an int)");
+    if (p->n_boxes > 1) {
+        RA_CHECK(p->n_boxes <= RA_MAX_BOXES && p->boxes && p->box_start, "ra_render_ground_chunk: at most 32 boxes per call, with their tables");
+        RA_CHECK(p->box_start[0] == 0 && p->box_start[p->n_boxes] == P, "ra_render_ground_chunk: box_start must run from 0 to P");
+        for (int j = 0; j < p->n_boxes; ++j) RA_CHECK(p->box_start[j] <= p->box_start[j + 1], "ra_render_ground_chunk: box_start must ascend");
+    }
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     zero_chunk_counters(c, s);
@@ -680,7 +692,7 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     }
     float *lvis = nullptr, *ldot = nullptr;
     if (light_visibility_stage(c, surf, nslots, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow, p->no_visibility,
-                               p->local_visibility, &lvis, &ldot, s)) return 1;
+                               p->local_visibility, &lvis, &ldot, s, p->n_boxes, p->boxes, p->box_start)) return 1;
     auto zero = [&](void* dst, int C) { if (dst) hipMemsetAsync(dst, 0, (size_t)P * C * sizeof(float), s); };
     zero(out->rgb, 3); zero(out->albedo, 3); zero(out->shade, 3); zero(out->spec, 3);
     zero(out->lvis, c->n_lights); zero(out->ldot, c->n_lights);

@@ -658,8 +658,10 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
             const size_t lds = ((size_t)fr.bvh_leaves * (4 * BVH_LEAF) + (size_t)fr.bvh_supers * (8 + 6 * BVH_FAN)) * sizeof(float);
             if (n <= split_max / 8) {
                 if (allow_stage && lds <= 134 * 1024) {
-                    static bool raised = false;             // allow > 64 KB of dynamic LDS, once
-                    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(hdq_coarse_kernel<true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 134 * 1024); raised = true; }
+                    static bool raised[64] = {};            // allow > 64 KB of dynamic LDS, once per device
+                    int dev = 0;
+                    hipGetDevice(&dev);
+                    if (!raised[dev & 63]) { hipFuncSetAttribute(reinterpret_cast<const void*>(hdq_coarse_kernel<true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 134 * 1024); raised[dev & 63] = true; }
                     hipLaunchKernelGGL((hdq_coarse_kernel<true, 16, true>), dim3(groups), dim3(1024), lds, s, fr, rs, n, th, inv2r2, out, d);
                 } else hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
             }

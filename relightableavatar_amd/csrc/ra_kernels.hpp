@@ -81,6 +81,7 @@ void launch_surface_composite(const float* raw, int C, int S, const int* hit_cou
                               const SurfaceMaps& m, hipStream_t s);
 
 // shadow rays
+constexpr int RA_MAX_BOXES = 32;
 struct ShadowGen {
     const float* surf;    // P x 3 (full ray indexing)
     const float* norm;    // hit-slot x 3
@@ -89,6 +90,12 @@ struct ShadowGen {
     const int* hit_count;
     const float* ldir;    // L x 3 unit light directions
     float bbox[6];
+    // several render chunks of the reference in ONE launch (the ground pass): ray r belongs to chunk j with box_start[j] <= r < box_start[j + 1]
+    // and is clipped against boxes[j] — the box the reference's in-place growth (sphere_tracing_renderer.py:1054-1056) had reached at that
+    // chunk, computed by the caller with the same float arithmetic.  n_boxes <= 1: every ray uses bbox.
+    int n_boxes;
+    float boxes[RA_MAX_BOXES][6];
+    int box_start[RA_MAX_BOXES + 1];
     float near_offset;
     int L;
     int no_visibility, local_visibility;

@@ -323,8 +323,15 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
     const bool hv = h < nh;
     int r = 0;
     float nrm[3] = {0.f, 0.f, 0.f}, o[3] = {0.f, 0.f, 0.f}, acc = 0.f;
+    float box[6] = {g.bbox[0], g.bbox[1], g.bbox[2], g.bbox[3], g.bbox[4], g.bbox[5]};
     if (hv) {
         r = g.hit_idx[h];
+        if (g.n_boxes > 1) {                        // the box of the render chunk this ray belongs to (kernel arguments: scalar loads)
+            int j = 0;
+            for (int k = 1; k < g.n_boxes; ++k) j += r >= g.box_start[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) box[k] = g.boxes[j][k];
+        }
         nrm[0] = g.norm[3 * h]; nrm[1] = g.norm[3 * h + 1]; nrm[2] = g.norm[3 * h + 2];
         o[0] = g.surf[3 * r]; o[1] = g.surf[3 * r + 1]; o[2] = g.surf[3 * r + 2];
         acc = g.acc[r];
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
                 lv = 0.f;
                 if (front) {
                     const float d[3] = {dx, dy, dz};
-                    aabb_near_far(g.bbox, o, d, nr, fr);
+                    aabb_near_far(box, o, d, nr, fr);
                     nr = fmaxf(nr, g.near_offset);                                                        // :311
                     fr = fmaxf(fr, g.near_offset);
                     trace = nr < fr;

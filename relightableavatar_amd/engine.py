@@ -185,11 +185,18 @@ class Engine:
                                 shadow_near_offset=c.env_lvis.near_offset, no_visibility=int(c.no_visibility),
                                 local_visibility=int(c.local_visibility))
 
-    def render_ground_chunk(self, ray_o, ray_d, acc, bbox6, probe, params, outs: dict):
-        """N1: one chunk of full-frame rays against the ground plane (render_ground); outs: name -> (P,3)/(P,) views."""
+    def render_ground_chunk(self, ray_o, ray_d, acc, bbox6, probe, params, outs: dict, boxes=None, box_start=None):
+        """N1: one chunk of full-frame rays against the ground plane (render_ground); outs: name -> (P,3)/(P,) views.
+        boxes / box_start: several of the reference's chunks in this one call, pixel r clipped against the box of its own chunk."""
         P = ray_o.shape[0]
         go = ra_ground_out(**{k: _ptr(outs.get(k)) for k in _lib.GROUND_OUT_KEYS})
         bb = (C.c_float * 6)(*[float(v) for v in bbox6])
+        if boxes is not None and len(boxes) > 1:
+            flat = (C.c_float * (6 * len(boxes)))(*[float(v) for b in boxes for v in b])
+            starts = (C.c_int * (len(boxes) + 1))(*[int(v) for v in box_start])
+            params.n_boxes, params.boxes, params.box_start = len(boxes), C.cast(flat, C.POINTER(C.c_float)), C.cast(starts, C.POINTER(C.c_int))
+        else:
+            params.n_boxes, params.boxes, params.box_start = 0, None, None
         check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
                                               probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
 

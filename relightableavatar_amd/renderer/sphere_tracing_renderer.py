@@ -172,12 +172,26 @@ class Renderer(nn.Module):
         if cfg.vis_novel_light:              # cached for the per-probe re-shade (render_ground :541-543; 4 KB per frame pixel)
             L = cfg.env_h * cfg.env_w
             out.lvis, out.ldot = torch.zeros(F, L, device=dev), torch.zeros(F, L, device=dev)
+        # The reference's chunks bound ITS memory; pixels are independent.  Consecutive chunks are rendered by ONE launch sequence of up to
+        # cfg.ground_chunk_rays pixels (0: chunk exactly as the reference), every pixel clipped against the box its own chunk had reached
+        # (the in-place growth, once per chunk incl. empty ones, is data independent): identical pixels, 17 x fewer launches at 512 x 512.
+        limit = int(cfg.get('ground_chunk_rays', 0))
+        group = []                                  # (a, b, box) of the chunks waiting for a launch
+
+        def flush():
+            if group:
+                a0, b1 = group[0][0], group[-1][1]
+                eng.render_ground_chunk(g_o[a0:b1], g_d[a0:b1], acc_g[a0:b1], group[0][2], probe, gp, {k: v[a0:b1] for k, v in out.items()},
+                                        boxes=[g[2] for g in group], box_start=[g[0] - a0 for g in group] + [b1 - a0])
+                group.clear()
         for a, b in ranges:
             bbox6 = self._grow_bounds(batch)
             if b <= a:
                 continue
-            eng.render_ground_chunk(g_o[a:b], g_d[a:b], acc_g[a:b], bbox6, probe, gp,
-                                    {k: v[a:b] for k, v in out.items()})
+            if group and (a != group[-1][1] or len(group) == 32 or b - group[0][0] > limit):
+                flush()
+            group.append((a, b, bbox6))
+        flush()
         n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, device=dev, dtype=torch.float32), dim=0)
         grd = dotdict(rgb_map=out.rgb[None], surf_map=out.surf[None], albedo_map=out.albedo[None], roughness_map=torch.ones(1, F, device=dev),
                       spec_map=out.spec[None], norm_map=n[None, None].expand(1, F, 3), shade_map=out.shade[None],

@@ -671,6 +671,23 @@ def test_query_skip_is_exact():
     assert fine[0] < fine[1], fine
 
 
+def test_merged_ground_chunks_are_exact():
+    """cfg.ground_chunk_rays: consecutive render chunks of the ground-plane pass share one launch sequence, every pixel clipped against
+    the box the reference's in-place growth had reached at ITS chunk (sphere_tracing_renderer.py:1054-1056) — bit-identical to chunking
+    exactly as the reference does (ground_chunk_rays = 0), here with 8 ground chunks of 2048 pixels and therefore 8 different boxes"""
+    from relightableavatar_amd.renderer import make_renderer
+    outs = []
+    for merged in (262144, 5000, 0):              # all 8 chunks in one launch; groups of two; the reference's chunking
+        cfg, net, dev = build('relight', vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0],
+                              render_chunk_size=2048, ground_chunk_rays=merged)
+        out = make_renderer(cfg, net).render(synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True), dev))
+        outs.append({k: out[k].cpu() for k in ('rgb_map', 'acc_map', 'shade_map', 'surf_map')})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[2][k]), k
+        assert torch.equal(outs[1][k], outs[2][k]), k
+    assert float(outs[0]['shade_map'].abs().sum()) > 0
+
+
 def test_frames_in_flight_are_bit_identical():
     """relightableavatar_amd/pipeline.py: frames rendered two at a time on two HIP streams (contexts sharing a gate that serialises
     their light-visibility stages) equal the frames rendered one after the other, bit for bit — alternating poses, so that a frame
