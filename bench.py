@@ -286,6 +286,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_host = time.perf_counter() - t0           # all steps queued: the host's share (the GPU is the bound while this stays below dt)
     sync()
     dt = time.perf_counter() - t0
     for e in engs:
@@ -344,6 +345,7 @@ def main():
         line['config']['soak'] = f'{n_soak} untimed frames in {args.soak:.1f} s before the {args.warmup} warm-up steps'
         line['config']['soak_frames'] = n_soak
         line['config']['frames_in_flight'] = D
+        line['host_enqueue_ms_per_step'] = t_host / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ref = cpu_baseline(cfg, H, args.skin_noise)
             if args.mode in ('relight', 'sphere_tracing', 'anisdf') and not args.ground and args.emulate_world <= 1:

@@ -293,7 +293,7 @@ int ra_blend_ground(ra_ctx* ctx, const float* ground, const float* human, const 
  * K, R: 9 doubles row-major, T: 3 doubles (host); bounds: 6 floats (host: min xyz, max xyz = batch.wbounds).
  * Device outputs with capacity H*W rays: ray_o, ray_d (n,3) f32; near, far (n) f32 — the in-box rays in row-major
  * pixel order, exactly the reference's boolean-mask order; mask_at_box: H*W uint8.  *n_rays receives the count
- * (synchronises the stream).  Directions are computed in fp64 and rounded once (the reference computes them in the
+ * (synchronises the stream); n_rays = NULL: no read-back, no synchronisation (the caller knows the count, e.g. H*W for an unbounded box).  Directions are computed in fp64 and rounded once (the reference computes them in the
  * camera's dtype and casts to float32); near/far follow the reference's float32 arithmetic operation by operation. */
 int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
                 void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream);

@@ -1051,7 +1051,7 @@ int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const
                 void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream) {
     RA_CHECK(c, "ra_gen_rays: null ctx");
     RA_CHECK(H > 0 && W > 0 && (long long)H * W < (1ll << 30), "ra_gen_rays: bad image size");
-    RA_CHECK(K && R && T && bounds && ray_o && ray_d && near && far && mask_at_box && n_rays, "ra_gen_rays: null argument");
+    RA_CHECK(K && R && T && bounds && ray_o && ray_d && near && far && mask_at_box, "ra_gen_rays: null argument");
     hipStream_t s = (hipStream_t)stream;
     RA_HIP(hipSetDevice(c->device));
     RayCam cam;
@@ -1073,8 +1073,10 @@ int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const
     int* count_dev = pix + n;
     RA_CHECK(launch_gen_rays(cam, (unsigned char*)mask_at_box, pix, count_dev, temp, tb, (float*)ray_o, (float*)ray_d, (float*)near,
                              (float*)far, s) == 0, "ra_gen_rays: device selection failed");
-    RA_HIP(hipMemcpyAsync(n_rays, count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-    RA_HIP(hipStreamSynchronize(s));
+    if (n_rays) {           // the count on the host costs a synchronisation; a caller that knows it (an unbounded box: H * W) passes NULL
+        RA_HIP(hipMemcpyAsync(n_rays, count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        RA_HIP(hipStreamSynchronize(s));
+    }
     return 0;
 }
 

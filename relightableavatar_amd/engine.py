@@ -269,10 +269,11 @@ class Engine:
         check(self.lib.ra_set_knn_mode(self.ctx, int(use_bvh)), 'ra_set_knn_mode')
         self._frame_key = None
 
-    def gen_rays(self, H, W, K, R, T, bounds):
+    def gen_rays(self, H, W, K, R, T, bounds, count=None):
         """N2: rays of an H x W pinhole view culled against the body's bounding box, on the device.
         K, R (3,3), T (3,) or (3,1): anything numpy can read; bounds (2,3).  Returns the reference's
-        get_rays_within_bounds outputs as device tensors: ray_o, ray_d (P,3), near, far (P,), mask_at_box (H,W) bool."""
+        get_rays_within_bounds outputs as device tensors: ray_o, ray_d (P,3), near, far (P,), mask_at_box (H,W) bool.
+        count: the number of in-box rays if the caller knows it (H * W for an unbounded box): skips the read-back and its synchronisation."""
         import numpy as np
         Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
         Rd = np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(9))
@@ -286,8 +287,8 @@ class Engine:
         cnt = C.c_int(0)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
         check(self.lib.ra_gen_rays(self.ctx, int(H), int(W), dp(Kd), dp(Rd), dp(Td), bd.ctypes.data_as(C.POINTER(C.c_float)),
-                                   _ptr(ro), _ptr(rd), _ptr(near), _ptr(far), _ptr(mask), C.byref(cnt), self.stream), 'ra_gen_rays')
-        P = cnt.value
+                                   _ptr(ro), _ptr(rd), _ptr(near), _ptr(far), _ptr(mask), C.byref(cnt) if count is None else None, self.stream), 'ra_gen_rays')
+        P = cnt.value if count is None else int(count)
         return dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(int(H), int(W)).bool())
 
     def pose_frame(self, poses, tjoints, parents, tverts, weights, big_A, faces, Rh, Th, padding=0.05):

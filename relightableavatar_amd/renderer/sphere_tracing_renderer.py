@@ -150,7 +150,9 @@ class Renderer(nn.Module):
         dev = eng.device
         H, W = int(batch.meta.H.item()), int(batch.meta.W.item())
         big = torch.tensor([[-1e9] * 3, [1e9] * 3])
-        rays = eng.gen_rays(H, W, batch.cam_K[0].cpu().numpy(), batch.cam_R[0].cpu().numpy(), batch.cam_T[0].cpu().numpy(), big)
+        # the camera as host numbers: the loader's host copies when it kept them (synthetic.to_device), else one read-back each
+        cam = [(batch[k + '_host'] if k + '_host' in batch else batch[k])[0].cpu().numpy() for k in ('cam_K', 'cam_R', 'cam_T')]
+        rays = eng.gen_rays(H, W, cam[0], cam[1], cam[2], big, count=H * W)        # unbounded box: every pixel is a ray, no count to wait for
         g_o, g_d = rays.ray_o.contiguous(), rays.ray_d.contiguous()
         assert g_o.shape[0] == H * W
         pix = batch.get('ground_pix', None)
@@ -160,7 +162,9 @@ class Renderer(nn.Module):
             g_o, g_d = g_o[pix].contiguous(), g_d[pix].contiguous()
             inds, ranges = batch.ground_inds.to(dev), batch.ground_chunks
         else:
-            inds = batch.mask_at_box.reshape(-1).to(dev).nonzero()[:, 0] if self.ground_inds is None else self.ground_inds.to(dev)
+            # the in-box pixels' frame indices; their number is the ray count, so nonzero need not report it (no host sync)
+            inds = (torch.nonzero_static(batch.mask_at_box.reshape(-1).to(dev), size=ret.acc_map.shape[1])[:, 0] if self.ground_inds is None
+                    else self.ground_inds.to(dev))
             ranges = chunks(H * W, cfg.render_chunk_size)
         F = g_o.shape[0]
         acc_h = ret.acc_map[0]
@@ -192,7 +196,9 @@ class Renderer(nn.Module):
                 flush()
             group.append((a, b, bbox6))
         flush()
-        n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, device=dev, dtype=torch.float32), dim=0)
+        if getattr(self, '_ground_n', None) is None or self._ground_n.device != dev:
+            self._ground_n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, dtype=torch.float32), dim=0).to(dev)     # constant of cfg
+        n = self._ground_n
         grd = dotdict(rgb_map=out.rgb[None], surf_map=out.surf[None], albedo_map=out.albedo[None], roughness_map=torch.ones(1, F, device=dev),
                       spec_map=out.spec[None], norm_map=n[None, None].expand(1, F, 3), shade_map=out.shade[None],
                       cpts_map=torch.zeros(1, F, 3, device=dev), bpts_map=torch.zeros(1, F, 3, device=dev), depth_map=out.depth[None])

@@ -40,13 +40,60 @@ _PLANS = {}
 
 
 def _deal(owner: np.ndarray, world: int):
-    """owner (n,) -> per-rank ascending index lists, counts, and the exchange's inverse (order, src)."""
-    idx = [np.flatnonzero(owner == r) for r in range(world)]          # world passes over n: cheaper than a stable argsort
-    counts = [int(i.size) for i in idx]
+    """owner (n,) -> per-rank ascending index lists, counts, and the exchange's inverse (order, src).
+    The lists are views of `order` (rays grouped by owner, original order inside): one stable sort of the one-byte owners (numpy
+    sorts bytes by counting) instead of `world` passes over the rays."""
+    order = np.argsort(owner.astype(np.uint8 if world <= 256 else np.int64, copy=False), kind='stable').astype(np.int64, copy=False)
+    counts = np.bincount(owner, minlength=world)[:world].tolist()
+    offs = np.concatenate([[0], np.cumsum(counts)]).tolist()
+    idx = [order[offs[r]:offs[r + 1]] for r in range(world)]
     n_max = max(counts) if counts else 0
-    order = np.concatenate(idx) if idx else np.zeros(0, np.int64)      # rays grouped by owner, original order inside
-    src = np.concatenate([r * n_max + np.arange(c, dtype=np.int64) for r, c in enumerate(counts)]) if idx else np.zeros(0, np.int64)
-    return idx, counts, n_max, order, src
+    src = np.arange(order.size, dtype=np.int64) + np.repeat(np.arange(world, dtype=np.int64) * n_max - np.asarray(offs[:-1], np.int64), counts)
+    return idx, counts, n_max, order, src, offs
+
+
+def _upload(arrays, device):
+    """int64 index vectors -> device tensors with ONE transfer.  Through a pinned staging block and non-blocking: a pageable
+    `tensor.to(device)` waits for everything queued on the stream before it (measured: 1.5 ms each with a frame in flight,
+    10 per plan — the host could not run ahead of the GPU any more)."""
+    sizes = [int(a.size) for a in arrays]
+    if device.type != 'cuda':
+        return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)) for a in arrays]
+    stage = torch.empty(max(sum(sizes), 1), dtype=torch.int64, pin_memory=True)        # the caching host allocator recycles the block
+    view, o = stage.numpy(), 0
+    for a, n in zip(arrays, sizes):
+        view[o:o + n] = a
+        o += n
+    dev = stage.to(device, non_blocking=True)
+    return list(torch.split(dev[:o], sizes)) if o else [dev[:0] for _ in sizes]
+
+
+_FRAMES = {}
+
+
+def _frame_deal(H: int, W: int, world: int, device):
+    """What the tile rule fixes for an H x W frame whatever its mask: the owner of every pixel (one byte each) and the whole deal of the
+    full-frame ground pass (per-rank pixel lists, exchange index vectors — on the device —, the position of every pixel in its owner's
+    list).  A function of the frame size only: computed once and kept (a 1024 x 1024 frame: 25 ms of numpy per call otherwise)."""
+    key = (H, W, world, str(device))
+    f = _FRAMES.get(key)
+    if f is None:
+        if len(_FRAMES) > 8:
+            _FRAMES.clear()
+        y, x = np.divmod(np.arange(H * W), W)
+        owner = ((y // TILE + x // TILE) % world).astype(np.uint8 if world <= 256 else np.int64)
+        f = _FRAMES[key] = dotdict(owner=owner, ground=None)
+    return f
+
+
+def _frame_ground(f, H: int, W: int, world: int, device):
+    if f.ground is None:
+        idx, counts, n_max, order, src, offs = _deal(f.owner, world)
+        pos = np.empty(H * W, np.int64)
+        pos[order] = np.arange(H * W, dtype=np.int64) - np.repeat(np.asarray(offs[:-1], np.int64), counts)
+        order_d, src_d = _upload([order, src], device)
+        f.ground = dotdict(idx=idx, counts=counts, n_max=n_max, offs=offs, pos=pos, order=order_d, src=src_d, chunks={})
+    return f.ground
 
 
 def _chunk_ranges(idx: np.ndarray, total: int, chunk_size: int):
@@ -96,28 +143,33 @@ def make_plan(P: int, world: int, batch=None, device=None, mask=None, ground: bo
         pix = np.flatnonzero(m)
         if pix.size != P:
             pix = None
+    fd = _frame_deal(H, W, world, device) if pix is not None else None
     if pix is not None:
-        owner = ((pix // W) // TILE + (pix % W) // TILE) % world      # diagonal stripes: horizontally AND vertically adjacent tiles differ
+        owner = fd.owner[pix]                        # diagonal stripes of 8 x 8 tiles: horizontally AND vertically adjacent tiles differ
     else:
-        owner = (np.arange(P) // RUN) % world
-    idx, counts, n_max, order, src = _deal(owner, world)
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(device, non_blocking=True)
-    pl = dotdict(P=P, world=world, H=H, W=W, owner=torch.from_numpy(owner.astype(np.int64)), counts=counts, n_max=n_max,
-                 idx=[up(i) for i in idx], order=up(order), src=up(src), idx_host=idx)
-    if render_chunk_size is not None:
-        pl.render_chunks = [_chunk_ranges(i, P, render_chunk_size) for i in idx]
+        owner = ((np.arange(P) // RUN) % world).astype(np.uint8 if world <= 256 else np.int64)
+    idx, counts, n_max, order, src, offs = _deal(owner, world)
+    host = [order, src]
     if ground:
         if pix is None:
             raise ValueError('shard.make_plan: the ground-plane pass needs mask_at_box and meta.H / meta.W (full-frame pixels)')
+        fg = _frame_ground(fd, H, W, world, device)
+        # where a rank's human rays sit in its ground pixel list (human pixels are a subset of the rank's ground pixels)
+        host += [fg.pos[pix[i]] for i in idx]
+    dev = _upload(host, device)                      # every per-frame index vector of the plan in one transfer
+    per_rank = lambda t, o: [t[o[r]:o[r + 1]] for r in range(world)]
+    pl = dotdict(P=P, world=world, H=H, W=W, owner=torch.from_numpy(owner.astype(np.int64)), counts=counts, n_max=n_max,
+                 idx=per_rank(dev[0], offs), order=dev[0], src=dev[1], idx_host=idx)
+    if render_chunk_size is not None:
+        pl.render_chunks = [_chunk_ranges(i, P, render_chunk_size) for i in idx]
+    if ground:
         F = H * W
-        fp = np.arange(F)
-        g_owner = ((fp // W) // TILE + (fp % W) // TILE) % world
-        g_idx, g_counts, g_n_max, g_order, g_src = _deal(g_owner, world)
-        g = dotdict(F=F, counts=g_counts, n_max=g_n_max, idx=[up(i) for i in g_idx], order=up(g_order), src=up(g_src), idx_host=g_idx)
-        # where this rank's human rays sit in its ground pixel list (both ascending, human pixels are a subset)
-        g.inds = [up(np.searchsorted(g_idx[r], pix[idx[r]])) for r in range(world)]
+        g = dotdict(F=F, counts=fg.counts, n_max=fg.n_max, idx=per_rank(fg.order, fg.offs), order=fg.order, src=fg.src, idx_host=fg.idx,
+                    inds=dev[2:2 + world])
         if render_chunk_size is not None:
-            g.chunks = [_chunk_ranges(i, F, render_chunk_size) for i in g_idx]
+            if render_chunk_size not in fg.chunks:
+                fg.chunks[render_chunk_size] = [_chunk_ranges(i, F, render_chunk_size) for i in fg.idx]
+            g.chunks = fg.chunks[render_chunk_size]
         pl.ground = g
     if key is not None:
         if len(_PLANS) > 16:

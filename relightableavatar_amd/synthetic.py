@@ -348,7 +348,9 @@ def to_device(batch, device):
     if isinstance(batch.get('wbounds', None), torch.Tensor) and not batch['wbounds'].is_cuda:
         out['wbounds_host'] = batch['wbounds'].clone()
     for k, v in batch.items():
-        if k == 'meta' or k.startswith('wbounds_host'):
+        if k in ('cam_K', 'cam_R', 'cam_T') and isinstance(v, torch.Tensor) and not v.is_cuda:
+            out[k + '_host'] = v             # the ground pass generates its full-frame rays from the camera (host doubles)
+        if k == 'meta' or k.endswith('_host') or k.startswith('wbounds_host'):
             out.setdefault(k, v)
         elif isinstance(v, torch.Tensor):
             out[k] = v.to(device)
