@@ -165,9 +165,9 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     const int nleaf = c->use_bvh ? bvh_leaf_count(nv) : 0;
     const int nsuper = bvh_super_count(nleaf);
     if (nleaf > 0) {
-        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * (16 + 16)) || c->fbvh_pairs.ensure((size_t)(nleaf + nsuper) * 32 + (size_t)nsuper * 192)) return 1;
-        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float4>(), c->fbvh_pairs.as<float4>(),
-                         c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf, nleaf, nsuper, s);
+        // leaves: 512 B each; boxes: super boxes (lo | hi), then per super box the four pair records of its leaf boxes
+        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * 16) || c->fbvh_pairs.ensure((size_t)nsuper * (32 + 192))) return 1;
+        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float>(), c->fbvh_pairs.as<float4>(), nleaf, nsuper, s);
         RA_HIP(hipGetLastError());
     }
     launch_fold_bias(c->cond_r0.as<float>(), cond, 0, cond, f->poses, c->b_r0.as<float>(), c->fbias_r0.as<float>(), s);
@@ -178,8 +178,8 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     fr.R = (float*)f->R; fr.Th = (float*)f->Th; fr.vertA = c->fvertA.as<float>(); fr.pverts4 = c->fpverts4.as<float4>();
     fr.pnorm = (float*)f->pnorm; fr.tverts = (float*)f->tverts; fr.bias_r0 = c->fbias_r0.as<float>();
     fr.bias_r4 = c->fbias_r4.as<float>(); fr.bias_c3 = c->fbias_c3.as<float>(); fr.n_verts = nv;
-    fr.bvh_pts = c->fbvh_pts.as<float4>(); fr.bvh_soa = reinterpret_cast<const float*>(fr.bvh_pts + (size_t)nleaf * 32); fr.bvh_lbox = c->fbvh_pairs.as<float4>();
-    fr.bvh_sbox = c->fbvh_pairs.as<float4>() + (size_t)2 * nleaf; fr.bvh_lpair = reinterpret_cast<const float*>(fr.bvh_sbox + (size_t)2 * nsuper); fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
+    fr.bvh_soa = c->fbvh_pts.as<float>();
+    fr.bvh_sbox = c->fbvh_pairs.as<float4>(); fr.bvh_lpair = reinterpret_cast<const float*>(fr.bvh_sbox + (size_t)2 * nsuper); fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
     c->have_frame = true;
     RA_HIP(hipGetLastError());
     return 0;

@@ -60,9 +60,7 @@ struct FrameState {         // device pointers owned by the ctx
     float* bias_c3;  // 256 (colour net, cond_fix)
     int n_verts;
     // exact 3-NN acceleration: Morton-sorted vertices, boxes of 32-point leaves and of 8-leaf groups
-    const float4* bvh_pts;    // n_verts sorted points, w = original vertex index (int bits)
-    const float* bvh_soa;     // the same points per leaf as x[32] | y[32] | z[32] | id[32] (behind bvh_pts in the same buffer)
-    const float4* bvh_lbox;   // per leaf: lo, hi
+    const float* bvh_soa;     // Morton-sorted vertices per 32-point leaf as x[32] | y[32] | z[32] | id[32] (id = original vertex index, int bits)
     const float4* bvh_sbox;   // per super box: lo, hi
     const float* bvh_lpair;   // per super box: its 8 leaf boxes as 4 pair records of 12 floats (behind bvh_sbox in the same buffer)
     int bvh_leaves;           // 0 -> brute force

@@ -107,8 +107,8 @@ __device__ __forceinline__ unsigned expand10(unsigned v) {
     return v;
 }
 
-__global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __restrict__ pv, int n, float4* __restrict__ pts,
-                                                                float4* __restrict__ lbox, float4* __restrict__ sbox, int nl, int ns) {
+__global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __restrict__ pv, int n, float* __restrict__ leaves,
+                                                                float4* __restrict__ sbox, int nl, int ns) {
     __shared__ unsigned long long keys[BVH_MAXN];     // code << 32 | index (static: 128 KB of the CU's 160 KB)
     __shared__ float red[6][BVH_THREADS / 64];
     __shared__ float bb[6];
@@ -162,6 +162,8 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
             }
             __syncthreads();
         }
+    // the sorted points per leaf as x[32] | y[32] | z[32] | id[32] (the leaf scan reads groups of candidates with wave-uniform addresses),
+    // padded with +inf points: (p - inf)^2 = inf never beats a finite bound
     for (int i = tid; i < nl * BVH_LEAF; i += BVH_THREADS) {
         float4 v = make_float4(__int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7fffffff));
         if (i < n) {
@@ -169,9 +171,7 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
             v = pv[id];
             v.w = __int_as_float((int)id);
         }
-        pts[i] = v;        // padded with +inf points: (p - inf)^2 = inf never beats a finite bound
-        // the same points per leaf as x[32] | y[32] | z[32] | id[32]: the leaf scan reads groups of candidates with wave-uniform addresses
-        float* soa = reinterpret_cast<float*>(pts + (size_t)nl * BVH_LEAF) + (size_t)(i >> 5) * (4 * BVH_LEAF) + (i & 31);
+        float* soa = leaves + (size_t)(i >> 5) * (4 * BVH_LEAF) + (i & 31);
         soa[0] = v.x; soa[BVH_LEAF] = v.y; soa[2 * BVH_LEAF] = v.z; soa[3 * BVH_LEAF] = v.w;
     }
     // leaf boxes into LDS scratch (reuse red-sized arrays is too small -> reuse keys' tail? keep simple: global + LDS copy)
@@ -186,8 +186,6 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
                 hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
             }
         }
-        lbox[2 * l] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        lbox[2 * l + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { lb[l][c] = lo[c]; lb[l][3 + c] = hi[c]; }
     }
@@ -619,9 +617,8 @@ int bvh_leaf_count(int n_verts) {
 }
 int bvh_super_count(int n_leaves) { return (n_leaves + BVH_FAN - 1) / BVH_FAN; }
 
-void launch_bvh_build(const float4* pverts4, int n_verts, float4* bvh_pts, float4* lbox, float4* sbox, int n_leaves, int n_supers,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(bvh_build_kernel, dim3(1), dim3(BVH_THREADS), 0, s, pverts4, n_verts, bvh_pts, lbox, sbox, n_leaves, n_supers);
+void launch_bvh_build(const float4* pverts4, int n_verts, float* leaves, float4* sbox, int n_leaves, int n_supers, hipStream_t s) {
+    hipLaunchKernelGGL(bvh_build_kernel, dim3(1), dim3(BVH_THREADS), 0, s, pverts4, n_verts, leaves, sbox, n_leaves, n_supers);
 }
 
 void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
