@@ -13,7 +13,8 @@ of frame f + 1 runs beside the stage of frame f.  Frames are bit-identical to se
     for p in pending:
         out = p.result()                              # makes the caller's current stream wait for that frame
 
-A batch must stay alive and unchanged until its frame has been consumed (`ra_set_frame` reads R / Th / pnorm / tverts in place).
+A batch must stay UNCHANGED until its frame has been consumed (`ra_set_frame` reads R / Th / pnorm / tverts in place); the pipeline keeps it
+alive (the Pending holds it, and its tensors are recorded on the replica's stream, so dropping the batch right after submit() is safe).
 """
 import ctypes as C
 
@@ -56,8 +57,9 @@ def _record(v, stream):
 class Pending:
     """a frame queued on a replica's stream"""
 
-    def __init__(self, value, event, stream):
+    def __init__(self, value, event, stream, inputs=None):
         self._value, self._event, self.stream = value, event, stream
+        self._inputs = inputs           # the batch stays referenced at least as long as its frame is pending
 
     def result(self):
         """the frame's output; the caller's current stream waits for it (no host synchronisation)"""
@@ -103,11 +105,15 @@ class FramePipeline:
             st = torch.cuda.current_stream(self.device)
         else:
             st.wait_stream(torch.cuda.current_stream(self.device))     # the inputs were produced on the caller's stream
+            # the batch was allocated on the caller's stream and is read on the replica's (the library also keeps POINTERS into it until
+            # the frame is done: ra_set_frame reads R / Th / pnorm / tverts in place): tell the caching allocator, or memory the caller
+            # frees right after submit() is handed out again while the frame still reads it
+            _record(batch, st)
         with torch.cuda.stream(st):
             val = fn(net, rend) if fn is not None else rend.render(batch)
             ev = torch.cuda.Event()
             ev.record(st)
-        return Pending(val, ev, st)
+        return Pending(val, ev, st, batch)
 
     def engines(self):
         return [n.engine() for n in self.networks]

@@ -703,9 +703,10 @@ def test_frames_in_flight_are_bit_identical():
     for b in batches:
         out = serial.render(b)
         want.append({k: out[k].clone() for k in keys})
-    fresh = [synthetic.to_device(synthetic.make_batch(192, 192, seed=k % 2, posed=True), dev) for k in range(6)]     # render() grows wbounds in place
     pipe = FramePipeline(cfg, sd, dev, depth=2)
-    pending = [pipe.submit(b) for b in fresh]
+    # fresh batches (render() grows wbounds in place), NOT kept by the caller: the pipeline must keep a frame's inputs alive and off the
+    # allocator's free list while the replica's stream still reads them (a dropped batch once came back as the next frame's memory)
+    pending = [pipe.submit(synthetic.to_device(synthetic.make_batch(192, 192, seed=k % 2, posed=True), dev)) for k in range(6)]
     for k, p in enumerate(pending):
         out = p.result()
         for key in keys:
