@@ -92,6 +92,8 @@ def _frame_ground(f, H: int, W: int, world: int, device):
         pos = np.empty(H * W, np.int64)
         pos[order] = np.arange(H * W, dtype=np.int64) - np.repeat(np.asarray(offs[:-1], np.int64), counts)
         order_d, src_d = _upload([order, src], device)
+        if torch.device(device).type == 'cuda':
+            torch.cuda.current_stream(device).synchronize()     # kept and used from any stream later (frames in flight): make the one upload visible to all, once
         f.ground = dotdict(idx=idx, counts=counts, n_max=n_max, offs=offs, pos=pos, order=order_d, src=src_d, chunks={})
     return f.ground
 
