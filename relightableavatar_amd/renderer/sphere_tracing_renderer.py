@@ -198,6 +198,7 @@ class Renderer(nn.Module):
         flush()
         if getattr(self, '_ground_n', None) is None or self._ground_n.device != dev:
             self._ground_n = torch.nn.functional.normalize(torch.tensor(cfg.ground_normal, dtype=torch.float32), dim=0).to(dev)     # constant of cfg
+            torch.cuda.current_stream(dev).synchronize()         # made once, then read from whatever stream renders (frames in flight)
         n = self._ground_n
         grd = dotdict(rgb_map=out.rgb[None], surf_map=out.surf[None], albedo_map=out.albedo[None], roughness_map=torch.ones(1, F, device=dev),
                       spec_map=out.spec[None], norm_map=n[None, None].expand(1, F, 3), shade_map=out.shade[None],
