@@ -165,6 +165,39 @@ def test_bvh_equals_brute_force(relight):
         assert a.fine_count == b.fine_count
 
 
+def test_bvh_equals_brute_force_on_other_mesh_sizes(relight):
+    """the box structure on meshes that are not SMPL-sized: a handful of vertices (one super box, padded leaves), counts that are
+    not multiples of the 32-point leaf or the 8-leaf super box (missing leaves are inverted boxes), a mesh too large for the LDS
+    copy of the 16-way variant (9 500 vertices: it must fall back to the scalar-cache path), and one beyond the builder's limit
+    (16 384: brute force) — large and small launches, always the same neighbours and distances as the O(N) scan"""
+    from relightableavatar_amd.base_utils import dotdict
+    _, _, dev, body, eng = relight
+    g = torch.Generator().manual_seed(11)
+    x = ((torch.rand(70000, 3, generator=g) - 0.5) * 2.0).to(dev)
+    n0 = body.pverts.shape[1]
+    try:
+        for n in (37, 1000, 6887, 9500, 16500):
+            rep = (n + n0 - 1) // n0
+            b = dotdict(body)
+            for k in ('pverts', 'pnorm', 'tverts', 'weights'):
+                v = body[k][0]
+                v = torch.cat([v + (0.003 * j if k in ('pverts', 'tverts') else 0.0) for j in range(rep)])[:n]      # copies shifted by 3 mm
+                b[k] = v[None].contiguous()
+            for q in (70000, 20000, 3000):          # one wave per 64 queries / 8 waves / 16 waves (LDS copy when the mesh fits)
+                eng.set_knn_mode(True)
+                eng.set_frame(b, force=True)
+                a = eng.debug_hdq(x[:q].contiguous(), 0.125)
+                eng.set_knn_mode(False)
+                eng.set_frame(b, force=True)
+                c = eng.debug_hdq(x[:q].contiguous(), 0.125)
+                assert int((a.nn_batch != c.nn_batch).sum()) == 0, (n, q)
+                assert float((a.sdf_coarse - c.sdf_coarse).abs().max()) == 0.0, (n, q)
+                assert a.fine_count == c.fine_count, (n, q)
+    finally:
+        eng.set_knn_mode(True)
+        eng.set_frame(body, force=True)
+
+
 def test_hdq_sdf(ops, relight):
     _, net, dev, body, _ = relight
     x = ops['hdq_x'].to(dev)

@@ -1,6 +1,6 @@
 """Where does a wave of the coarse level (hdq_coarse_kernel) spend its cycles?  Instrumented build:
     tools/build_variant.sh hdqts ra_hdq.hip "-DRA_COARSE_TS"      then on the GPU box     RA_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_tmp/variants/hdqts.so python tools/coarse_timestamps.py [mode]
-Renders frames of `mode` (default sphere_tracing, 512 x 512) and prints, for each of the last 64 coarse launches, the median cycles
+Renders frames of `mode` (default sphere_tracing, 512 x 512; an optional second argument N renders rank 0's shard of an N-rank job) and prints, for each of the last 64 coarse launches, the median cycles
 per phase over the waves of the first 64 workgroups."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,13 +11,17 @@ from relightableavatar_amd.config import make_cfg
 from relightableavatar_amd.networks import make_network
 from relightableavatar_amd.renderer import make_renderer
 mode = sys.argv[1] if len(sys.argv) > 1 else 'sphere_tracing'
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device('cuda:0')
 cfg = make_cfg(mode)
 relight = mode in ('relight', 'novel_light')
 net = make_network(cfg); net.load_state_dict(synthetic.make_state_dict(0, relight=relight, cfg=cfg)); net = net.to(dev).eval()
 renderer = make_renderer(cfg, net)
-batch = synthetic.to_device(synthetic.make_batch(512, 512, seed=0, posed=True, skin_noise=2.0), dev)
+from relightableavatar_amd import shard
 for _ in range(2):
+    batch = synthetic.to_device(synthetic.make_batch(512, 512, seed=0, posed=True, skin_noise=2.0), dev)
+    if world > 1:
+        batch = shard.shard_batch(batch, 0, world, cfg.render_chunk_size)
     renderer.render(batch)
 torch.cuda.synchronize()
 L = _lib.lib()
