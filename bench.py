@@ -174,7 +174,7 @@ def main():
     ap.add_argument('--static-frame', action='store_true', help='A/B: do not re-pose the body every step (round-1 behaviour: per-frame set-up outside the timed region)')
     ap.add_argument('--k4-batch', type=int, default=0, help='cfg.k4_batch_slots: full queries per forward+backward launch pair (0 = library default)')
     ap.add_argument('--soak', type=float, default=3.0, help='seconds of untimed frames BEFORE the W warm-up steps: the chip is power-limited on this path (DESIGN.md section 4), so the clock of a cold 0.7 s burst is not the sustained one')
-    ap.add_argument('--frames-in-flight', type=int, default=2, help='frames kept in flight on as many HIP streams (relightableavatar_amd/pipeline.py): the latency-bound small-kernel phase of frame f + 1 runs beside the light-visibility stage of frame f, the stages themselves are serialised by a gate.  1 = strictly sequential frames')
+    ap.add_argument('--frames-in-flight', type=int, default=3, help='frames kept in flight on as many HIP streams (relightableavatar_amd/pipeline.py): the latency-bound small-kernel phase of frame f + 1 runs beside the light-visibility stage of frame f, the stages themselves are serialised by a gate.  1 = strictly sequential frames')
     ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 

@@ -21,8 +21,8 @@ python3 $R/bench.py --mode novel_light --size 1024 --probes 8 --steps 5 --warmup
 python3 $R/bench.py --skin-noise 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_skin_noise0.json 2>> $OUT/bench.err        # the body the contract is asserted on, with its PSNR
 # sequential frames (one in flight) next to the default two: the whole frame and one rank's share of 2 / 4 / 8
 : > $OUT/${RN}_frames_in_flight.jsonl
-for d in 1 2 3; do python3 $R/bench.py --frames-in-flight $d --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err; done
-for n in 2 4 8; do python3 $R/bench.py --frames-in-flight 1 --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err; done
+for d in 1 2 3 4; do python3 $R/bench.py --frames-in-flight $d --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err; done
+for d in 1 2; do for n in 2 4 8; do python3 $R/bench.py --frames-in-flight $d --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err; done; done
 python3 $R/bench.py --frames-in-flight 1 --mode sphere_tracing --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err
 : > $OUT/${RN}_emulate_world.jsonl
 for n in 2 4 8; do python3 $R/bench.py --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world.jsonl 2>> $OUT/bench.err; done
