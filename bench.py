@@ -160,8 +160,8 @@ def dry_rank(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--mode', default='relight', choices=['relight', 'sphere_tracing', 'anisdf', 'novel_light'])
     ap.add_argument('--probes', type=int, default=8, help='novel_light: number of 16x32 probes re-shaded per frame')
