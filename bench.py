@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ground', action='store_true', help='relight: add the ground-plane pass (cfg.vis_ground_shading, SURVEY.md 8f row N1)')
     ap.add_argument('--emulate-world', type=int, default=0, help='tuning aid: render only rank 0\'s shard of an N-rank job on one GPU (no collective); value is then NOT a whole-job rate')
+    ap.add_argument('--emulate-rank', type=int, default=0, help='with --emulate-world: which rank\'s shard to render (load balance of the tile deal)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL on ROCm; gloo only with --dry')
     ap.add_argument('--dry', action='store_true', help='no HIP engine: launcher + process-group plumbing on CPU tensors (CPU test of the N > 1 path)')
     ap.add_argument('--static-frame', action='store_true', help='A/B: do not re-pose the body every step (round-1 behaviour: per-frame set-up outside the timed region)')
@@ -226,7 +227,7 @@ def main():
     mask_host = base.mask_at_box.cpu()          # the loader's copy: the shard plan is host work (shard.make_plan)
     wbh0 = wb0.cpu()
     nw = args.emulate_world if args.emulate_world > 1 else world          # --emulate-world N: rank 0's share of an N-rank job, no collective
-    rk = 0 if args.emulate_world > 1 else rank
+    rk = args.emulate_rank if args.emulate_world > 1 else rank
 
     frame_no = [0]
 
@@ -345,6 +346,8 @@ def main():
         line['config']['soak'] = f'{n_soak} untimed frames in {args.soak:.1f} s before the {args.warmup} warm-up steps'
         line['config']['soak_frames'] = n_soak
         line['config']['frames_in_flight'] = D
+        if args.emulate_world > 1:
+            line['config']['emulate_world'], line['config']['emulate_rank'] = args.emulate_world, args.emulate_rank
         line['host_enqueue_ms_per_step'] = t_host / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ref = cpu_baseline(cfg, H, args.skin_noise)

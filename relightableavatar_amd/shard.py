@@ -3,7 +3,8 @@
 Rays are independent units (no cross-ray reduction anywhere in the path), but their cost varies
 ~1000x between a miss and a hit pixel and hits are spatially clustered, so pixels are dealt to ranks
 in small tiles, round-robin: 8x8 pixel tiles when the batch carries `mask_at_box` + `meta.H/W`
-(the in-box rays are the mask's pixels in row-major order), runs of 64 consecutive rays otherwise.
+(the in-box rays are the mask's pixels in row-major order; the tiles that hold in-box pixels are dealt in raster order), runs of 64
+consecutive rays otherwise.
 Tiles — not single pixels — because the coarse level of the distance query sweeps its vertex boxes
 per wave of 64 neighbouring rays: a rank that owned every N-th pixel would spread each wave over an
 N times larger image area and lose most of the pruning (measured: 6.4 ms instead of 1.3 ms of
@@ -82,7 +83,9 @@ def _frame_deal(H: int, W: int, world: int, device):
             _FRAMES.clear()
         y, x = np.divmod(np.arange(H * W), W)
         owner = ((y // TILE + x // TILE) % world).astype(np.uint8 if world <= 256 else np.int64)
-        f = _FRAMES[key] = dotdict(owner=owner, ground=None)
+        tiles_x = (W + TILE - 1) // TILE
+        tile = ((y // TILE) * tiles_x + x // TILE).astype(np.int32)           # the 8 x 8 tile of every pixel, raster order of tiles
+        f = _FRAMES[key] = dotdict(owner=owner, tile=tile, n_tiles=tiles_x * ((H + TILE - 1) // TILE), ground=None)
     return f
 
 
@@ -146,8 +149,17 @@ def make_plan(P: int, world: int, batch=None, device=None, mask=None, ground: bo
         if pix.size != P:
             pix = None
     fd = _frame_deal(H, W, world, device) if pix is not None else None
-    if pix is not None:
-        owner = fd.owner[pix]                        # diagonal stripes of 8 x 8 tiles: horizontally AND vertically adjacent tiles differ
+    if pix is not None and not ground:
+        # the tiles that hold in-box pixels, dealt round robin in raster order: every rank gets the same number of tiles (+-1) whatever the
+        # shape of the mask, and its cost — hit pixels — spreads evenly (512 x 512 frame, 8 ranks: hits per rank max / mean 1.03 against
+        # 1.08 for fixed diagonal stripes, min / mean 0.97 against 0.87; the slowest rank sets the frame time)
+        tid = fd.tile[pix]
+        present = np.bincount(tid, minlength=fd.n_tiles) > 0
+        tile_rank = ((np.cumsum(present) - 1) % world).astype(fd.owner.dtype)
+        owner = tile_rank[tid]
+    elif pix is not None:
+        # with the ground pass: fixed diagonal stripes over the WHOLE frame, so that a rank's in-box pixels are a subset of its ground pixels
+        owner = fd.owner[pix]
     else:
         owner = ((np.arange(P) // RUN) % world).astype(np.uint8 if world <= 256 else np.int64)
     idx, counts, n_max, order, src, offs = _deal(owner, world)

@@ -25,10 +25,11 @@ for d in 1 2 3 4; do python3 $R/bench.py --frames-in-flight $d --steps 20 --warm
 for d in 1 2; do for n in 2 4 8; do python3 $R/bench.py --frames-in-flight $d --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err; done; done
 python3 $R/bench.py --frames-in-flight 1 --mode sphere_tracing --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err
 : > $OUT/${RN}_emulate_world.jsonl
-for n in 2 4 8; do python3 $R/bench.py --emulate-world $n --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world.jsonl 2>> $OUT/bench.err; done
+# EVERY rank's share (the slowest rank sets the frame time of a real job): config.emulate_rank says which
+for n in 2 4 8; do for r in $(seq 0 $((n-1))); do python3 $R/bench.py --emulate-world $n --emulate-rank $r --steps 20 --warmup 3 --soak 1 --no-cpu-baseline >> $OUT/${RN}_emulate_world.jsonl 2>> $OUT/bench.err; done; done
 # config 5 (1024 x 1024, 8 probes) and the README command (novel light + ground) as one rank of an N-rank job
 : > $OUT/${RN}_emulate_world_config5.jsonl
-for n in 1 2 4 8; do python3 $R/bench.py --emulate-world $n --size 1024 --mode novel_light --probes 8 --steps 10 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world_config5.jsonl 2>> $OUT/bench.err; done
+for n in 1 2 4 8; do for r in $(seq 0 $((n-1))); do python3 $R/bench.py --emulate-world $n --emulate-rank $r --size 1024 --mode novel_light --probes 8 --steps 10 --warmup 3 --soak 1 --no-cpu-baseline >> $OUT/${RN}_emulate_world_config5.jsonl 2>> $OUT/bench.err; done; done
 for n in 1 2 4 8; do python3 $R/bench.py --emulate-world $n --size 512 --mode novel_light --ground --probes 2 --steps 10 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_emulate_world_config5.jsonl 2>> $OUT/bench.err; done
 $R/tools/frame_anatomy.sh w8 44 -- --emulate-world 8 --steps 10 --warmup 3 > $OUT/${RN}_emulate_world8_kernels.txt 2>> $OUT/bench.err
 cd /tmp
