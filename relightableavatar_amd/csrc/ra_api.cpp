@@ -432,7 +432,10 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
     launch_trace_init(ts, n, nullptr, *p, s);
     RaySet rs{};
     rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t;
+    rs.nn_hint = c->buf<int>("tr_nn", (size_t)n * 3, &err);      // every iteration starts from the neighbours of the one before
+    if (err) return 1;
     for (int it = 0; it < p->iters; ++it) {
+        rs.hint_valid = it > 0;
         if (hdq_pass(c, rs, n, p->dist_th, 1, sdf, s)) return 1;
         launch_trace_update(ts, sdf, n, nullptr, it, *p, s);
     }
@@ -499,7 +502,10 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         r2.mode = 2; r2.o = surf; r2.t = sh.t; r2.pix = g.ray_pix; r2.light = g.ray_light; r2.ldir = c->light_dir.as<float>();
         r2.n_dev = g.ray_count;
         r2.skip = c->cfg.query_skip ? sh.stuck : nullptr;
+        r2.nn_hint = c->buf<int>("lv_nn", NR * 3, &err);       // every iteration starts from the neighbours of the one before
+        if (err) return 1;
         for (int it = 0; it < shadow.iters; ++it) {
+            r2.hint_valid = it > 0;
             if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
             launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
         }
@@ -558,7 +564,10 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     launch_trace_init(ts, P, nullptr, p->surface, s);
     RaySet rs{};
     rs.mode = 1; rs.o = ray_o; rs.d = ray_d; rs.t = ts.t; rs.skip = c->cfg.query_skip ? ts.stuck : nullptr;
+    rs.nn_hint = c->buf<int>("sf_nn", (size_t)P * 3, &err);      // every iteration starts from the neighbours of the one before
+    if (err) return 1;
     for (int it = 0; it < p->surface.iters; ++it) {
+        rs.hint_valid = it > 0;
         if (hdq_pass(c, rs, P, p->surface.dist_th, 1, sdf, s)) return 1;
         launch_trace_update(ts, sdf, P, nullptr, it, p->surface, s);
     }

@@ -239,11 +239,15 @@ __device__ __forceinline__ float dist2(float dx, float dy, float dz) { return __
 // top-3 insertion; ties resolved towards the lower vertex index (what an ascending scan gives).
 // Pure value selects under one wave-uniform guard: keeps the six state words in VGPRs (a 3-way
 // branchy version made LLVM spill them to scratch behind a computed store address).
-__device__ __forceinline__ void knn_insert(float d, int id, float& d0, float& d1, float& d2, int& i0, int& i1, int& i2) {
+// dedup (wave-uniform): the lists may already hold this vertex (hinted start: the previous iteration's neighbours come round again
+// when their leaf is scanned) — a vertex is never entered twice
+__device__ __forceinline__ void knn_insert(float d, int id, float& d0, float& d1, float& d2, int& i0, int& i1, int& i2, bool dedup = false) {
     if (__builtin_expect(__ballot(d <= d2) == 0ull, 1)) return;      // common case: one compare + one scalar branch per candidate
-    const bool c2 = d < d2 || (d == d2 && id < i2);
-    const bool c1 = d < d1 || (d == d1 && id < i1);
-    const bool c0 = d < d0 || (d == d0 && id < i0);
+    bool fresh = true;
+    if (dedup) fresh = (id != i0) & (id != i1) & (id != i2);
+    const bool c2 = fresh && (d < d2 || (d == d2 && id < i2));
+    const bool c1 = fresh && (d < d1 || (d == d1 && id < i1));
+    const bool c0 = fresh && (d < d0 || (d == d0 && id < i0));
     const float nd2 = c1 ? d1 : (c2 ? d : d2);
     const int ni2 = c1 ? i1 : (c2 ? id : i2);
     const float nd1 = c0 ? d0 : (c1 ? d : d1);
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         // d = fma(dz, dz, fma(dx, dx, dy * dy)) in both halves: the rounding the O(N) validation scan has (dist2 below).
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 px2 = {p[0], p[0]}, py2 = {p[1], p[1]}, pz2 = {p[2], p[2]};
+        const bool hinted = rs.nn_hint != nullptr && rs.hint_valid != 0;          // uniform: start from the previous iteration's neighbours
 #ifdef RA_COARSE_TS
         int n_rare = 0;
 #endif
@@ -387,10 +392,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                         // the vertex ids are only needed here; near the surface this path is NOT rare (the 64 queries of a wave find their
                         // neighbours all over the leaf under them): one scalar load, not a vector-memory round trip per group
                         const i4 id = soa_id4(L + 3 * BVH_LEAF + 8 * q + 4 * g);
-                        knn_insert(da.x, id.x, d0, d1, d2, i0, i1, i2);
-                        knn_insert(da.y, id.y, d0, d1, d2, i0, i1, i2);
-                        knn_insert(db.x, id.z, d0, d1, d2, i0, i1, i2);
-                        knn_insert(db.y, id.w, d0, d1, d2, i0, i1, i2);
+                        knn_insert(da.x, id.x, d0, d1, d2, i0, i1, i2, hinted);
+                        knn_insert(da.y, id.y, d0, d1, d2, i0, i1, i2, hinted);
+                        knn_insert(db.x, id.z, d0, d1, d2, i0, i1, i2, hinted);
+                        knn_insert(db.y, id.w, d0, d1, d2, i0, i1, i2, hinted);
                     }
                     if constexpr (g == 0 && q < 3) { nx = soa8(L + 8 * (q + 1)); ny = soa8(L + BVH_LEAF + 8 * (q + 1)); nz = soa8(L + 2 * BVH_LEAF + 8 * (q + 1)); }
                 });
@@ -401,8 +406,26 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         if (lm != 0ull) {
             // --- seed: the super box, then the leaf in it, nearest to the wave's first live query.  Lane j looks at box j (one box test and
             // a wave minimum instead of a loop over the boxes in every lane); ties -> lowest index.
-            int seed;
-            {
+            int seed = -1;
+            if (hinted) {
+                // the ray's neighbours of one iteration ago, re-measured at the new point (the same arithmetic the scans use, so a vertex
+                // that comes round again has the identical distance) and ordered (distance, index)
+                if (live) {
+                    float e[3]; int h[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        h[k] = rs.nn_hint[3 * (size_t)i + k];
+                        const float4 v = fr.pverts4[h[k]];
+                        e[k] = dist2(p[0] - v.x, p[1] - v.y, p[2] - v.z);
+                    }
+                    auto before = [&](int a, int b) { return e[a] < e[b] || (e[a] == e[b] && h[a] < h[b]); };
+                    auto swap = [&](int a, int b) { const float te = e[a]; e[a] = e[b]; e[b] = te; const int th_ = h[a]; h[a] = h[b]; h[b] = th_; };
+                    if (before(1, 0)) swap(0, 1);
+                    if (before(2, 1)) swap(1, 2);
+                    if (before(1, 0)) swap(0, 1);
+                    d0 = e[0]; d1 = e[1]; d2 = e[2]; i0 = h[0]; i1 = h[1]; i2 = h[2];
+                }
+            } else {
                 auto bc = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), first)); };
                 const float q[3] = {bc(p[0]), bc(p[1]), bc(p[2])};
                 auto wave_argmin = [&](float d) __attribute__((always_inline)) {
@@ -420,8 +443,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                 seed = bi * BVH_FAN + wave_argmin(d);
             }
             RA_CSTAMP(2);
-            n_scan = 1;
-            scan_leaf(seed);
+            if (!hinted) {
+                n_scan = 1;
+                scan_leaf(seed);
+            }
             RA_CSTAMP(3);
             // --- the sweep: a super box is opened when any lane may still find a closer vertex in it; its 8 leaf boxes are tested in pairs
             // (packed subtract / multiply-add on SGPR operands: 18 VALU per pair, 17 per box before), each leaf against the bounds as they
@@ -499,6 +524,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                 knn_insert(d, v0 + j, d0, d1, d2, i0, i1, i2);
             }
         }
+    }
+    if (rs.nn_hint && live) {                // the next iteration's starting point (live: wave 0 of a split workgroup holds the merged result)
+        int* hw = rs.nn_hint + 3 * (size_t)i;
+        hw[0] = i0; hw[1] = i1; hw[2] = i2;
     }
     if (dbg & 2) { if (live) out.sdf[i] = d0 + d1 + d2 + (float)(i0 + i1 + i2); return; }
     // signed coarse distances (sample_utils.py:124-128) and the geodesic neighbour rule (:148-160)

@@ -14,6 +14,12 @@ struct RaySet {
     const float* ldir;    // mode 2: n_lights x 3 (unit)
     const int* n_dev;     // optional device-side count (<= n launched); nullptr -> n
     const unsigned char* skip;   // optional: ray i did not move since its last query -> its sdf[i] is still valid, do not re-query
+    // optional: the three nearest vertices every query of this pass finds are written here (3 ints per ray), and — with hint_valid — read
+    // first: the neighbours a ray found one tracing iteration ago give its bounds at the new point at once (3 distance evaluations instead
+    // of a seed search + a 32-candidate leaf scan dense in insertions, in EVERY wave of a split workgroup); any vertex is a valid
+    // candidate, so the result stays the exact 3-NN
+    int* nn_hint;
+    int hint_valid;
 };
 
 struct HdqOut {
