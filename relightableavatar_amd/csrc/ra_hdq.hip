@@ -277,15 +277,10 @@ __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
 // SPLIT > 1 (small launches, < 1 wave per SIMD: the serial sweep of one wave IS the launch time): the SPLIT waves of a
 // workgroup serve the SAME 64 queries and share out the opened super boxes; their three-bests are merged through LDS.
 // Each wave prunes against its own (weaker) bound, which is still conservative, so the merged result is exact.
-// STAGE (split variants on a mesh that fits: launch_hdq_coarse): the workgroup first copies the whole box structure into LDS.  A small
-// launch is a chain of dependent reads per wave (box -> leaf boxes -> leaf quarter -> ...), each 1.5-2 k cycles through the scalar cache
-// on its first touch (tools/coarse_timestamps.py: 6-8 k cycles for ONE 32-point leaf, 544 cycles of arithmetic); from LDS each is ~100.
-template <bool BVH, int SPLIT, bool STAGE = false>
+template <bool BVH, int SPLIT>
 __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
                                                                   HdqOut out, int dbg) {
     static_assert(SPLIT == 1 || (BVH && SPLIT >= 2 && SPLIT <= 16), "SPLIT > 1: the workgroup is SPLIT waves on the same 64 queries");
-    static_assert(!STAGE || SPLIT > 1, "the LDS copy is for the latency-bound split variants");
-    extern __shared__ __attribute__((aligned(16))) float bvh_lds[];      // STAGE: leaves (x|y|z|id) then super boxes then leaf-box pair records
     constexpr int NT = SPLIT == 1 ? KNN_THREADS : 64 * SPLIT;      // threads per workgroup
     // BVH: super + leaf boxes (2 float4 each); brute force: a vertex tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[BVH ? 16 : VT * 16];       // the O(N) scan's vertex tile
@@ -303,13 +298,6 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
     const bool live_q = i < n && !(rs.skip && rs.skip[i < n ? i : 0]);
     bool live = live_q;
     if (__syncthreads_count(live_q) == 0) return;       // nothing to query in this workgroup (uniform)
-    if constexpr (STAGE) {
-        const int n_soa = fr.bvh_leaves * BVH_LEAF, n_box = fr.bvh_supers * (2 + 3 * BVH_FAN / 2);       // in float4
-        const float4* g0 = reinterpret_cast<const float4*>(fr.bvh_soa);
-        float4* l4 = reinterpret_cast<float4*>(bvh_lds);
-        for (int j = threadIdx.x; j < n_soa; j += NT) l4[j] = g0[j];
-        for (int j = threadIdx.x; j < n_box; j += NT) l4[n_soa + j] = fr.bvh_sbox[j];          // the pair records follow the super boxes
-    }
     float x[3] = {0.f, 0.f, 0.f};
     if (live) ray_point(rs, i, x);
     // world -> pose: (x - Th) R   (blend_utils.py:252-261)
@@ -329,7 +317,6 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         // addresses and no load depends on another one.  Seed: the leaf nearest to the wave's first
         // live lane is scanned first so that every lane starts with a finite bound.
         const int nl = fr.bvh_leaves, ns = fr.bvh_supers;
-        if constexpr (STAGE) __syncthreads();
         if (!live) { d0 = d1 = d2 = -1.f; }            // idle lanes: every test fails, nothing is inserted
         const unsigned long long lm = __ballot(live);
         const int first = lm ? __ffsll((long long)lm) - 1 : 0;
@@ -352,24 +339,13 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         typedef float f8 __attribute__((ext_vector_type(8)));
         typedef float f4 __attribute__((ext_vector_type(4)));
         typedef int i4 __attribute__((ext_vector_type(4)));
-        // wave-uniform reads of the structure: scalar loads through the constant address space, or LDS broadcasts (STAGE)
-        auto soa8 = [&](int off) __attribute__((always_inline)) {
-            if constexpr (STAGE) return *reinterpret_cast<const f8*>(bvh_lds + off);
-            else return *(const f8 __attribute__((address_space(4)))*)(fr.bvh_soa + off);
-        };
-        auto soa_id4 = [&](int off) __attribute__((always_inline)) {
-            if constexpr (STAGE) return *reinterpret_cast<const i4*>(bvh_lds + off);
-            else return *(const i4 __attribute__((address_space(4)))*)(fr.bvh_soa + off);
-        };
-        const int box0 = nl * (4 * BVH_LEAF);                         // LDS offset of the super boxes (floats)
+        // wave-uniform reads of the structure: scalar loads through the constant address space
+        auto soa8 = [&](int off) __attribute__((always_inline)) { return *(const f8 __attribute__((address_space(4)))*)(fr.bvh_soa + off); };
+        auto soa_id4 = [&](int off) __attribute__((always_inline)) { return *(const i4 __attribute__((address_space(4)))*)(fr.bvh_soa + off); };
         auto box4 = [&](int off) __attribute__((always_inline)) {                       // offset in floats from the first super box
-            if constexpr (STAGE) return *reinterpret_cast<const f4*>(bvh_lds + box0 + off);
-            else return *(const f4 __attribute__((address_space(4)))*)(reinterpret_cast<const float*>(fr.bvh_sbox) + off);
+            return *(const f4 __attribute__((address_space(4)))*)(reinterpret_cast<const float*>(fr.bvh_sbox) + off);
         };
-        auto box1 = [&](int off) __attribute__((always_inline)) {                       // per-lane read (seed search)
-            if constexpr (STAGE) return bvh_lds[box0 + off];
-            else return reinterpret_cast<const float*>(fr.bvh_sbox)[off];
-        };
+        auto box1 = [&](int off) __attribute__((always_inline)) { return reinterpret_cast<const float*>(fr.bvh_sbox)[off]; };      // per-lane read (seed search)
         auto scan_leaf = [&](int l) __attribute__((always_inline)) {
             const int L = l * (4 * BVH_LEAF);
             f8 cx = soa8(L), cy = soa8(L + BVH_LEAF), cz = soa8(L + 2 * BVH_LEAF), nx = cx, ny = cy, nz = cz;
@@ -657,16 +633,14 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     const float inv2r2 = 1.f / (2.f * blend_radius * blend_radius);
     const dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS);
     // launches below ~1.5 waves per SIMD are latency-bound: spread each group of 64 queries over the 4 waves of a workgroup
-    int dbg = 0, probe = 0, split_max = 98304;
-    bool allow_stage = true;
+    int dbg = 0, probe = 0, split_max = 196608;
 #ifdef RA_TESTING            // profiling aids (test builds only, tools/build_variant.sh)
     // RA_COARSE_DBG: 1 skip the search, 2 skip everything after it.  RA_COARSE_PROBE: an extra launch in ablation mode `probe` on the
     // SAME inputs before every real launch (which then overwrites its outputs): the ablated time is read from a kernel trace
     static const int e_dbg = getenv("RA_COARSE_DBG") ? atoi(getenv("RA_COARSE_DBG")) : 0;
     static const int e_probe = getenv("RA_COARSE_PROBE") ? atoi(getenv("RA_COARSE_PROBE")) : 0;
-    static const int e_split = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 98304;
-    static const int e_stage = getenv("RA_COARSE_STAGE") ? atoi(getenv("RA_COARSE_STAGE")) : 1;
-    dbg = e_dbg; probe = e_probe; split_max = e_split; allow_stage = e_stage != 0;
+    static const int e_split = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 196608;
+    dbg = e_dbg; probe = e_probe; split_max = e_split;
 #endif
 #ifdef RA_COARSE_TS
     static int launch_no = 0;
@@ -678,19 +652,7 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
         {
             // more waves per 64 queries the smaller the launch (about 4-8 k waves in flight on the 1024 SIMDs)
             const int groups = (n + 63) / 64;
-            // Smallest launches (one workgroup per CU or fewer): the box structure in LDS if it fits beside the merge buffers (SMPL: 216
-            // leaves, 27 super boxes = 114 KB).  Measured (MI355X, 512 x 512): 5 k queries per launch (one rank of eight) 7.00 -> 6.85 ms per
-            // frame; at 40 k queries the copy costs more than it saves (one workgroup per CU instead of four: 3.00 -> 3.29 ms).
-            const size_t lds = ((size_t)fr.bvh_leaves * (4 * BVH_LEAF) + (size_t)fr.bvh_supers * (8 + 6 * BVH_FAN)) * sizeof(float);
-            if (n <= split_max / 8) {
-                if (allow_stage && lds <= 134 * 1024) {
-                    static bool raised[64] = {};            // allow > 64 KB of dynamic LDS, once per device
-                    int dev = 0;
-                    hipGetDevice(&dev);
-                    if (!raised[dev & 63]) { hipFuncSetAttribute(reinterpret_cast<const void*>(hdq_coarse_kernel<true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 134 * 1024); raised[dev & 63] = true; }
-                    hipLaunchKernelGGL((hdq_coarse_kernel<true, 16, true>), dim3(groups), dim3(1024), lds, s, fr, rs, n, th, inv2r2, out, d);
-                } else hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
-            }
+            if (n <= split_max / 8) hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
             else if (n <= split_max / 2) hipLaunchKernelGGL((hdq_coarse_kernel<true, 8>), dim3(groups), dim3(512), 0, s, fr, rs, n, th, inv2r2, out, d);
             else hipLaunchKernelGGL((hdq_coarse_kernel<true, 4>), dim3(groups), dim3(256), 0, s, fr, rs, n, th, inv2r2, out, d);
         }
