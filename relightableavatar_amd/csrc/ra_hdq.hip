@@ -277,7 +277,10 @@ __device__ __forceinline__ void ray_point(const RaySet& rs, int i, float x[3]) {
 // SPLIT > 1 (small launches, < 1 wave per SIMD: the serial sweep of one wave IS the launch time): the SPLIT waves of a
 // workgroup serve the SAME 64 queries and share out the opened super boxes; their three-bests are merged through LDS.
 // Each wave prunes against its own (weaker) bound, which is still conservative, so the merged result is exact.
-template <bool BVH, int SPLIT>
+// HINT: the pass starts from the neighbours of the previous tracing iteration (RaySet.nn_hint with hint_valid); compile time, so that the
+// unhinted passes (a trace's first iteration, the volume path) keep the leaner insert path (measured: +13 % on the volume path's launch
+// when the flag was a run-time one)
+template <bool BVH, int SPLIT, bool HINT = false>
 __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coarse_kernel(FrameState fr, RaySet rs, int n_launch, float th, float inv2r2,
                                                                   HdqOut out, int dbg) {
     static_assert(SPLIT == 1 || (BVH && SPLIT >= 2 && SPLIT <= 16), "SPLIT > 1: the workgroup is SPLIT waves on the same 64 queries");
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         // d = fma(dz, dz, fma(dx, dx, dy * dy)) in both halves: the rounding the O(N) validation scan has (dist2 below).
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 px2 = {p[0], p[0]}, py2 = {p[1], p[1]}, pz2 = {p[2], p[2]};
-        const bool hinted = rs.nn_hint != nullptr && rs.hint_valid != 0;          // uniform: start from the previous iteration's neighbours
+        constexpr bool hinted = HINT;          // start from the previous iteration's neighbours
 #ifdef RA_COARSE_TS
         int n_rare = 0;
 #endif
@@ -646,16 +649,24 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     static int launch_no = 0;
     dbg |= (launch_no++ & 63) << 8;
 #endif
+    const bool hint = rs.nn_hint != nullptr && rs.hint_valid != 0;
     for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
         const int d = pass == 0 ? probe : dbg;
         if (fr.bvh_leaves > 0 && n <= split_max)
         {
             // more waves per 64 queries the smaller the launch (about 4-8 k waves in flight on the 1024 SIMDs)
             const int groups = (n + 63) / 64;
-            if (n <= split_max / 8) hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
-            else if (n <= split_max / 2) hipLaunchKernelGGL((hdq_coarse_kernel<true, 8>), dim3(groups), dim3(512), 0, s, fr, rs, n, th, inv2r2, out, d);
-            else hipLaunchKernelGGL((hdq_coarse_kernel<true, 4>), dim3(groups), dim3(256), 0, s, fr, rs, n, th, inv2r2, out, d);
+            if (hint) {
+                if (n <= split_max / 8) hipLaunchKernelGGL((hdq_coarse_kernel<true, 16, true>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
+                else if (n <= split_max / 2) hipLaunchKernelGGL((hdq_coarse_kernel<true, 8, true>), dim3(groups), dim3(512), 0, s, fr, rs, n, th, inv2r2, out, d);
+                else hipLaunchKernelGGL((hdq_coarse_kernel<true, 4, true>), dim3(groups), dim3(256), 0, s, fr, rs, n, th, inv2r2, out, d);
+            } else {
+                if (n <= split_max / 8) hipLaunchKernelGGL((hdq_coarse_kernel<true, 16>), dim3(groups), dim3(1024), 0, s, fr, rs, n, th, inv2r2, out, d);
+                else if (n <= split_max / 2) hipLaunchKernelGGL((hdq_coarse_kernel<true, 8>), dim3(groups), dim3(512), 0, s, fr, rs, n, th, inv2r2, out, d);
+                else hipLaunchKernelGGL((hdq_coarse_kernel<true, 4>), dim3(groups), dim3(256), 0, s, fr, rs, n, th, inv2r2, out, d);
+            }
         }
+        else if (fr.bvh_leaves > 0 && hint) hipLaunchKernelGGL((hdq_coarse_kernel<true, 1, true>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
         else if (fr.bvh_leaves > 0) hipLaunchKernelGGL((hdq_coarse_kernel<true, 1>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
         else hipLaunchKernelGGL((hdq_coarse_kernel<false, 1>), grid, dim3(KNN_THREADS), 0, s, fr, rs, n, th, inv2r2, out, d);
         if (pass == 0) hipMemsetAsync(out.fine_count, 0, sizeof(int), s);
