@@ -458,7 +458,7 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
 static int light_visibility_stage(ra_ctx* c, const float* surf, const float* norm_slots, const float* acc, const int* hit_idx,
                                   const int* hit_count, int P, const float* bbox, float near_offset, const ra_trace_params& shadow,
                                   int no_visibility, int local_visibility, float** lvis_out, float** ldot_out, hipStream_t s,
-                                  int n_boxes = 0, const float* boxes = nullptr, const int* box_start = nullptr) {
+                                  int n_boxes = 0, const float* boxes = nullptr, const int* box_start = nullptr, const int* pix_nn = nullptr) {
     int err = 0;
     const int L = c->n_lights;
     const size_t NR = (size_t)P * L;
@@ -506,6 +506,9 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         if (err) return 1;
         for (int it = 0; it < shadow.iters; ++it) {
             r2.hint_valid = it > 0;
+            // first pass: a shadow ray starts next to its pixel's surface point, whose neighbours the surface trace's last query found
+            r2.hint_src = it == 0 ? pix_nn : nullptr;
+            r2.hint_src_index = it == 0 ? g.ray_pix : nullptr;
             if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
             launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
         }
@@ -606,7 +609,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     float *lvis = nullptr, *ldot = nullptr, *shade = nullptr, *spec = nullptr;
     if (relit) {
         if (light_visibility_stage(c, surf, m.norm, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow,
-                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s)) return 1;
+                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s, 0, nullptr, nullptr, rs.nn_hint)) return 1;
         m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
         shade = c->buf<float>("mp_shade", (size_t)P * 3, &err);
         spec = c->buf<float>("mp_spec", (size_t)P * 3, &err);

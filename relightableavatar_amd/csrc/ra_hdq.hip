@@ -393,7 +393,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
                     float e[3]; int h[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        h[k] = rs.nn_hint[3 * (size_t)i + k];
+                        h[k] = rs.hint_src ? rs.hint_src[3 * (size_t)rs.hint_src_index[i] + k] : rs.nn_hint[3 * (size_t)i + k];
                         const float4 v = fr.pverts4[h[k]];
                         e[k] = dist2(p[0] - v.x, p[1] - v.y, p[2] - v.z);
                     }
@@ -649,7 +649,7 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     static int launch_no = 0;
     dbg |= (launch_no++ & 63) << 8;
 #endif
-    const bool hint = rs.nn_hint != nullptr && rs.hint_valid != 0;
+    const bool hint = (rs.nn_hint != nullptr && rs.hint_valid != 0) || rs.hint_src != nullptr;
     for (int pass = probe ? 0 : 1; pass < 2; ++pass) {
         const int d = pass == 0 ? probe : dbg;
         if (fr.bvh_leaves > 0 && n <= split_max)

@@ -20,6 +20,11 @@ struct RaySet {
     // candidate, so the result stays the exact 3-NN
     int* nn_hint;
     int hint_valid;
+    // optional, for a loop's FIRST pass: start from another pass's neighbours — query i reads the triplet hint_src[3 * hint_src_index[i]]
+    // (the shadow rays of a hit pixel start next to the point whose neighbours the surface trace found last).  Takes precedence over
+    // nn_hint as the source; nn_hint is still written.
+    const int* hint_src;
+    const int* hint_src_index;
 };
 
 struct HdqOut {
