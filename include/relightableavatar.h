@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 4
+#define RA_ABI_VERSION 5
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -60,6 +60,14 @@ typedef struct ra_config {
                                                  (frames are bit-identical with 0), the reference re-queries them (sphere_tracing_renderer.py:144-205) */
     int   k4_batch_slots;                     /* full queries per forward+backward launch pair (bounds the activation tape: 4.9 KB per slot);
                                                  0 = default (1 Mi slots = 5 GB) */
+    int   trace_precision;                    /* arithmetic of the distance queries INSIDE tracing loops.  The reference computes everything in
+                                                 fp32; f16 MFMA operands leave the distance 5e-5 rms off, which flips the phase of the surface trace's
+                                                 limit cycles on ~1 % of the pixels (sphere_tracing_renderer.py:176-197: hit test, sign-change
+                                                 interpolation).  1 (default): the surface trace (16 iterations, 2 % of a relit frame's fine queries)
+                                                 runs in COMPENSATED arithmetic — f16 hi + lo operand pairs, three MFMAs per k-step, fp32 accumulate:
+                                                 1.3e-7 rms from a float64 evaluation, as good as fp32 itself — the shadow rays stay on plain 16-bit
+                                                 operands; 0: plain operands everywhere (round 3's behaviour); 2: compensated everywhere, also
+                                                 ra_hdq_sdf / ra_observed_sdf and the shadow rays (validation; 3x the MFMA work) */
 } ra_config;
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 
@@ -214,6 +222,7 @@ typedef struct ra_counters {       /* cumulative since ra_reset_counters; read w
     uint64_t n_hit_pixels;
     uint64_t n_shaded;             /* pixel x probe shading evaluations                       */
     uint64_t n_fine_sdf_wide;      /* the part of n_fine_sdf computed by the 8-wave distance kernel (launches that fill the chip) */
+    uint64_t n_fine_sdf_comp;      /* the part of n_fine_sdf computed in compensated arithmetic (ra_config.trace_precision): 3 x F_sdf executed */
 } ra_counters;
 int ra_get_counters(ra_ctx* ctx, ra_counters* out, void* stream); /* synchronises stream */
 int ra_reset_counters(ra_ctx* ctx, void* stream);
@@ -222,7 +231,8 @@ int ra_reset_counters(ra_ctx* ctx, void* stream);
  * events on `stream`; n_launches receives the launch count.  Synchronises. */
 int ra_get_mlp_time(ra_ctx* ctx, float* ms, int* n_launches, void* stream);
 /* the same for one kernel family: kind 0 = fused distance query (K3, every width), 1 = full query with normals / material / colour (K4),
- * 2 = the 8-wave distance query only (the launches that fill the chip: the frame's dominant kernel), 3 = the 2- / 4-wave distance query */
+ * 2 = the 8-wave distance query only (the launches that fill the chip: the frame's dominant kernel), 3 = the 2- / 4-wave distance query,
+ * 4 = the compensated distance query (K3C; not part of kind 0) */
 int ra_get_kernel_time(ra_ctx* ctx, int kind, float* ms, int* n_launches, void* stream);
 int ra_enable_timing(ra_ctx* ctx, int on);
 /* ---- frames in flight --------------------------------------------------------------------------------------------

@@ -300,8 +300,15 @@ class OracleNet:
         deviations from a plain operand rounding: the pose condition enters through an fp32 per-frame bias (never rounded), and
         the coordinate / frequency-0 encoding channels of the SDF net's two encoding-fed layers are carried as hi + lo pairs."""
         self.cfg = cfg
-        self.emulate = {None: None, 'f32': None, 'f16': torch.float16, 'bf16': torch.bfloat16}[emulate]
+        # 'f64acc': every nn.Linear is evaluated in float64 and rounded once to fp32 — a DIFFERENTLY ASSOCIATED (and more accurate)
+        # fp32 arithmetic than the reference's BLAS sums: what it changes in a frame is what fp32 itself cannot pin (tools/precision_tiers.py).
+        # 'f16x2': operands as f16 hi + lo pairs, three products hi*hi + lo*hi + hi*lo, fp32 accumulate — the compensated tier of
+        # the HIP kernels (K3C / K4C, DESIGN.md section 2).
+        self.f64acc = emulate == 'f64acc'
+        self.split = emulate == 'f16x2'
+        self.emulate = {None: None, 'f32': None, 'f64acc': None, 'f16': torch.float16, 'bf16': torch.bfloat16, 'f16x2': torch.float16}[emulate]
         self.kernel_like = bool(kernel_like) and self.emulate is not None
+        self.shadow_net = None           # tiered precision: another OracleNet (same weights) that answers the light-visibility queries
         f = lambda k: sd[k].detach().float().clone()
         self.resd = [(f(f'residual_deformation_network.mlp.linears.{i}.weight'),
                       f(f'residual_deformation_network.mlp.linears.{i}.bias')) for i in range(9)]
@@ -339,9 +346,31 @@ class OracleNet:
         rounded weight (residual of the first rounding rounded again).  kernel_like only: scaled_x — the input is rounded as
         x * SP_SCALE (hidden activations of the softplus net live in the scaled domain); scaled_w_cols — these weight columns
         are rounded as w * SP_SCALE (they are fed by the unscaled encoding and carry the factor)."""
+        if self.f64acc:
+            return F.linear(x.double(), w.double(), b.double()).float()
         if self.emulate is None:
             return F.linear(x, w, b)
         S = self.SP_SCALE
+        if self.split:
+            # hi + lo pairs of both operands in the domain the kernel holds them in (scaled hidden activations / scaled encoding-fed
+            # weight columns); the pose-condition columns stay fp32 (folded into a bias)
+            xs, ws = x, w
+            if self.kernel_like and scaled_x:
+                n_h = x.shape[-1] if scaled_w_cols is None else scaled_w_cols.start
+                xs = torch.cat([x[..., :n_h] * S, x[..., n_h:]], dim=-1)      # y' = W_h (S x_h) + (S W_pe) x_pe = S y
+            if self.kernel_like and scaled_w_cols is not None:
+                ws = ws.clone()
+                ws[:, scaled_w_cols] = ws[:, scaled_w_cols] * S
+            xh, wh = self._q(xs), self._q(ws)
+            xl, wl = self._q(xs - xh), self._q(ws - wh)
+            if self.kernel_like and exact_cols is not None:
+                xh, xl, wh, wl = xh.clone(), xl.clone(), wh.clone(), wl.clone()
+                xh[..., exact_cols], wh[:, exact_cols] = xs[..., exact_cols], ws[:, exact_cols]
+                xl[..., exact_cols], wl[:, exact_cols] = 0, 0
+            y = F.linear(xh, wh) + F.linear(xl, wh) + F.linear(xh, wl)
+            if self.kernel_like and (scaled_x or scaled_w_cols is not None):
+                y = y / S
+            return y + b
         if self.kernel_like and scaled_x:
             n_h = x.shape[-1] if scaled_w_cols is None else scaled_w_cols.start
             xq = torch.cat([self._q(x[..., :n_h] * S) / S, self._q(x[..., n_h:])], dim=-1)
@@ -619,6 +648,40 @@ def sphere_tracing(ray_o, ray_d, near, far, sdf_fn: Callable, iter=16, tan_i=100
     return ray_o + st * ray_d, ray_o + ot * ray_d, occ, st, ot
 
 
+def surface_trace(net: OracleNet, batch, noise: float = 0.0, generator=None):
+    """the surface trace of render_human (sphere_tracing_renderer.py:571) alone, over all rays of `batch`; `noise`: std of a
+    gaussian perturbation added to every distance the trace reads (fp32_unstable_rays).  Returns st, occ (P)."""
+    c = net.cfg
+    fr = _frame(batch)
+    ray_o, ray_d, near, far = (batch[k][0].float() for k in ('ray_o', 'ray_d', 'near', 'far'))
+
+    def fn(x):
+        d = hdq_sdf(net, x, fr, c.dist_th, True)
+        return d if noise == 0.0 else d + noise * torch.randn(d.shape, generator=generator)
+    st_cfg = c.sphere_tracing
+    _, _, occ, st, _ = sphere_tracing(ray_o, ray_d, near[:, None], far[:, None], fn, iter=st_cfg.iter, relax=st_cfg.relax, offset=st_cfg.offset,
+                                      eps=st_cfg.eps, shadow_skip_iter=st_cfg.shadow_skip_iter, clay_book=not c.no_claybook, soft_shadow=False,
+                                      hard_tan_i=st_cfg.tan_i)
+    return st[:, 0], occ[:, 0]
+
+
+def fp32_unstable_rays(net: OracleNet, batch, trials: int = 32, noise: float = 3e-7, tol: float = 1e-4, seed: int = 0):
+    """Rays whose traced surface the reference's OWN arithmetic does not pin: the fixed-iteration sphere trace
+    (sphere_tracing_renderer.py:144-205) ends in a limit cycle on part of the rays, and its closest-approach rule `abs(d1) < cd -> st = t`
+    (:194-197) then compares the distances of successive visits of the same phase — values that agree to ~1e-7 — so which visit wins,
+    and with it a jump of `st` by millimetres, is decided by the last bits of fp32 sums (the BLAS' summation order).  A ray is reported
+    when a gaussian perturbation of `noise` (fp32 rounding level: the oracle itself is 1.2e-7 rms from a float64 evaluation of the MLPs)
+    on the distances moves its `st` by more than `tol`, or flips its hit status, in any of `trials` runs.  Returns a bool mask (P)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        st0, occ0 = surface_trace(net, batch)
+        bad = torch.zeros_like(st0, dtype=torch.bool)
+        for _ in range(trials):
+            st, occ = surface_trace(net, batch, noise, g)
+            bad |= ((st - st0).abs() > tol) | ((occ < 1) != (occ0 < 1))
+    return bad
+
+
 def light_visibility(net: OracleNet, surf, norm, acc, fr, bbox, lvis_cfg, sdf_fn_factory):
     """light_visibility sphere_tracing_renderer.py:265-344. surf,norm (P,3), acc (P) -> lvis, ldot (L,P)."""
     c = net.cfg
@@ -731,8 +794,9 @@ def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
             albedo = albedo * c.albedo_multiplier
         ret.albedo_map, ret.roughness_map = albedo, rough[:, 0]
     if c.relighting:
+        snet = net.shadow_net or net                                   # tiered precision (tools/precision_tiers.py)
         lvis, ldot = light_visibility(net, surf, norm, acc, fr, bbox, c.obj_lvis,
-                                      lambda th: (lambda x: hdq_sdf(net, x, fr, th, True)))
+                                      lambda th: (lambda x: hdq_sdf(snet, x, fr, th, True)))
         rgb, shade, spec = shade_pixels(net, probe, ro, surf, norm, albedo, rough, lvis, ldot, want_spec=c.vis_specular_map)
         ret.rgb_map, ret.shade_map = rgb, shade
         if spec is not None:

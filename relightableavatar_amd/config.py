@@ -119,6 +119,10 @@ def default_cfg() -> dotdict:
     c.ret_raw = True             # sphere-tracing renderer: also return render_human's per-hit raw / volume_albedo / volume_roughness (lazily)
     c.novel_light_timing = True  # novel-light renderer: bracket the main pass with device syncs to fill `diff` like the reference (:107-112)
     c.query_skip = True          # rays that did not move since their last distance query are not queried again (exact; False = the reference's schedule)
+    # arithmetic of the distance queries inside tracing loops (include/relightableavatar.h ra_config.trace_precision): 1 = the surface
+    # trace in compensated arithmetic (f16 hi + lo pairs, 3 MFMAs per k-step: as accurate as the reference's fp32), shadow rays plain;
+    # 0 = plain 16-bit operands everywhere; 2 = compensated everywhere (validation)
+    c.trace_precision = 1
     c.k4_batch_slots = 0         # full queries per forward+backward launch pair (bounds the 4.9 KB/slot activation tape); 0 = 1 Mi
     return c
 

@@ -81,7 +81,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    DevBuf* bufs[] = {&c->sarena, &c->sarena_pairs, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
+    DevBuf* bufs[] = {&c->sarena, &c->sarena_pairs, &c->sarena_c, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
                       &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs,
                       &c->adj_start, &c->adj_list, &c->adj_dfaces};
@@ -122,6 +122,7 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
     HostNets& H = c->host;
     if (upload(c->sarena, H.sarena_trim.data(), H.sarena_trim.size() * 2, s)) return 1;        // device copy: the trimmed stream (8-wave K3)
     if (upload(c->sarena_pairs, H.sarena_pairs.data(), H.sarena_pairs.size() * 2, s)) return 1;
+    if (upload(c->sarena_c, H.sarena_c.data(), H.sarena_c.size() * 2, s)) return 1;
     if (upload(c->fwd_arena, H.fwd_arena.data(), H.fwd_arena.size() * 2, s)) return 1;
     if (upload(c->bwd_arena, H.bwd_arena.data(), H.bwd_arena.size() * 2, s)) return 1;
     if (upload(c->shead_row, H.shead_row.data(), H.shead_row.size() * 4, s)) return 1;
@@ -233,8 +234,23 @@ void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s) {
     else launch_mlp_sdf_stream_bf16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s);
 }
 
+// which distance queries run in compensated arithmetic (ra_config.trace_precision): the surface trace from 1 on, everything at 2
+enum { Q_OTHER = 0, Q_SURFACE = 1 };
+bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what == Q_SURFACE); }
+
+// the fine level of one query: K3, or K3C where the pass is in the precise tier
+void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s) {
+    if (comp) {
+        Timer t(c, s, 3);
+        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, n, s);
+    } else {
+        Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
+        k3_launch(c, io, n, s);
+    }
+}
+
 // one hierarchical distance query over the points of rs; writes sdf[n]
-int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s) {
+int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s, int what = Q_OTHER) {
     if (n <= 0) return 0;
     int err = 0;
     int* fine_idx = c->buf<int>("fine_idx", n, &err);
@@ -247,10 +263,7 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     MlpIO io{};
     io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
-    {
-        Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
-        k3_launch(c, io, n, s);
-    }
+    fine_level(c, io, n, precise(c, what), s);
     return 0;
 }
 
@@ -373,10 +386,7 @@ int ra_observed_sdf(ra_ctx* c, const float* bpts, int n, float* sdf, void* strea
     MlpIO io{};
     io.bpts = bpts; io.idx = idx; io.count = cnt; io.sdf = sdf; io.dist_th = 1.f; io.smooth = 0;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
-    {
-        Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
-        k3_launch(c, io, n, s);
-    }
+    fine_level(c, io, n, precise(c, Q_OTHER), s);
     RA_HIP(hipGetLastError());
     return 0;
 }
@@ -436,7 +446,7 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
     if (err) return 1;
     for (int it = 0; it < p->iters; ++it) {
         rs.hint_valid = it > 0;
-        if (hdq_pass(c, rs, n, p->dist_th, 1, sdf, s)) return 1;
+        if (hdq_pass(c, rs, n, p->dist_th, 1, sdf, s, p->soft_shadow ? Q_OTHER : Q_SURFACE)) return 1;
         launch_trace_update(ts, sdf, n, nullptr, it, *p, s);
     }
     if (occ) RA_HIP(hipMemcpyAsync(occ, ts.occ, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -571,7 +581,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     if (err) return 1;
     for (int it = 0; it < p->surface.iters; ++it) {
         rs.hint_valid = it > 0;
-        if (hdq_pass(c, rs, P, p->surface.dist_th, 1, sdf, s)) return 1;
+        if (hdq_pass(c, rs, P, p->surface.dist_th, 1, sdf, s, Q_SURFACE)) return 1;
         launch_trace_update(ts, sdf, P, nullptr, it, p->surface, s);
     }
     int* hit_count = icnt(c, CNT_HIT);
@@ -830,6 +840,7 @@ int ra_get_counters(ra_ctx* c, ra_counters* out, void* stream) {
     out->n_hit_pixels = h[4];
     out->n_shaded = c->n_shaded + h[4];
     out->n_fine_sdf_wide = h[5];
+    out->n_fine_sdf_comp = h[6];
     return 0;
 }
 
@@ -1100,14 +1111,14 @@ int ra_enable_timing(ra_ctx* c, int on) {
 
 int ra_get_kernel_time(ra_ctx* c, int kind, float* ms, int* n_launches, void* stream) {
     RA_CHECK(c && ms && n_launches, "ra_get_kernel_time: null argument");
-    RA_CHECK(kind >= 0 && kind <= 3, "ra_get_kernel_time: kind must be 0 (distance query), 1 (full query), 2 (8-wave distance query) or 3 (narrow distance query)");
+    RA_CHECK(kind >= 0 && kind <= 4, "ra_get_kernel_time: kind must be 0 (distance query), 1 (full query), 2 (8-wave distance query), 3 (narrow distance query) or 4 (compensated distance query)");
     RA_HIP(hipSetDevice(c->device));
     RA_HIP(hipStreamSynchronize((hipStream_t)stream));
     float tot = 0.f;
     int n = 0;
     for (size_t i = 0; i < c->ev_used; ++i) {
-        const int k = c->ev_kind[i];          // internal: 0 = 8-wave K3, 2 = narrow K3, 1 = K4
-        if (!(kind == 0 ? (k == 0 || k == 2) : kind == 1 ? k == 1 : kind == 2 ? k == 0 : k == 2)) continue;
+        const int k = c->ev_kind[i];          // internal: 0 = 8-wave K3, 2 = narrow K3, 3 = K3C, 1 = K4
+        if (!(kind == 0 ? (k == 0 || k == 2) : kind == 1 ? k == 1 : kind == 2 ? k == 0 : kind == 3 ? k == 2 : k == 3)) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { tot += t; ++n; }
     }

@@ -70,6 +70,7 @@ struct FrameState {         // device pointers owned by the ctx
 struct DevCounters {       // device-side work counters (ra_get_counters)
     unsigned long long n_coarse, n_fine_sdf, n_fine_full, n_shadow_rays, n_hit_pixels;
     unsigned long long n_fine_sdf_wide;      // the part of n_fine_sdf that went through the 8-wave K3 (launches that fill the chip)
+    unsigned long long n_fine_sdf_comp;      // the part of n_fine_sdf answered in compensated arithmetic (K3C: the surface trace)
 };
 
 struct MlpIO {
@@ -117,6 +118,11 @@ void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const void
                                int max_slots, hipStream_t stream);
 void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
                                 int max_slots, hipStream_t stream);
+
+// K3C (ra_k3c.hpp): the same query in compensated arithmetic (f16 hi + lo operand pairs, three MFMAs per k-step) on the split stream
+// sarena_c; one wave per SIMD: 2 waves (64-point tiles) for launches of at most 16 Ki points, else 4 (128-point tiles)
+inline int k3c_waves(int max_slots) { return max_slots <= 256 * 64 ? 2 : 4; }
+void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
 
 // K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list
 size_t mlp_full_rev_tape_bytes(int slots);

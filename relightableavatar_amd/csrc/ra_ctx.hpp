@@ -11,6 +11,7 @@ struct HostNets {
     std::vector<uint16_t> sarena;      // K3 weight stream (consumption order, 1952 fragments of 1 KB), every layer padded; host only (prefix of fwd_arena)
     std::vector<uint16_t> sarena_trim; // the 8-wave K3's stream: sarena without the fragments that only hold padding (1920)
     std::vector<uint16_t> sarena_pairs;  // the same with the row blocks of every layer interleaved in pairs (K3 latency variants)
+    std::vector<uint16_t> sarena_c;    // K3C: sarena with every fragment as an IEEE-half [hi | lo] pair (3904 fragments)
     std::vector<uint16_t> fwd_arena;   // K4 forward stream: sarena + the 256 feature rows (2080 fragments)
     std::vector<uint16_t> bwd_arena;   // K4 backward stream: transposed geometry layers, then the material / colour head
     int bwd_geo_frags = 0, bwd_frags = 0;
@@ -43,7 +44,7 @@ struct ra_ctx {
     std::map<std::string, std::vector<float>> state_dict;
     HostNets host;
     // device copies
-    DevBuf sarena, sarena_pairs, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
+    DevBuf sarena, sarena_pairs, sarena_c, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
     int n_lights = 0;
     // frame
     FrameState fr{};
@@ -63,7 +64,7 @@ struct ra_ctx {
     // timing of the fused MLP launches
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    std::vector<int> ev_kind;      // 0: mlp_sdf launch, 1: mlp_full launch
+    std::vector<int> ev_kind;      // 0: 8-wave K3 launch, 2: narrow K3, 3: K3C, 1: full query (K4 pair)
     size_t ev_used = 0;
 
     template <typename T> T* buf(const std::string& name, size_t count, int* err) {

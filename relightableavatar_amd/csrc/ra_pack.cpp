@@ -65,17 +65,26 @@ struct StreamBuilder {
     static int hidden_feature(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
     // rows_pad/32 row blocks; per row block: 16 hidden k-steps of Mh (may be null) then 4 PE k-steps of Mp (may be null)
     bool pairs = false;         // interleave the fragments of row blocks (2p, 2p + 1) k-step by k-step (K3's latency variants, ra_stream.hpp row_blocks)
+    bool split = false;         // K3C (ra_k3c.hpp): every fragment twice, [hi | lo] with lo = cv(v - hi): compensated products
+    // part: 0 = the value rounded once; 1 = hi (the same); 2 = lo, the rounded residual of the first rounding
     template <typename ChanFn>
-    void frag(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale) {       // ks < 16: hidden k-step, else encoding k-step ks - 16
+    void frag(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale, int part = 0) {       // ks < 16: hidden k-step, else encoding k-step ks - 16
+        auto put = [&](float v) {
+            const uint16_t hi = cv(v);
+            if (part != 2) { w.push_back(hi); return; }
+            _Float16 hf;
+            std::memcpy(&hf, &hi, 2);                  // split streams are IEEE half (ra_pack_weights builds them with half = true)
+            w.push_back(cv(v - (float)hf));
+        };
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
                 const int row = rb * 32 + (lane & 31);
                 if (ks < 16) {
                     const int col = hidden_feature(ks, lane >> 5, j);
-                    w.push_back(cv(row < Mh->rows && col < Mh->cols ? Mh->at(row, col) : 0.f));
+                    put(row < Mh->rows && col < Mh->cols ? Mh->at(row, col) : 0.f);
                 } else {
                     const int col = chan(8 * (ks - 16) + j, lane >> 5);
-                    w.push_back(cv(row < Mp->rows && col >= 0 && col < Mp->cols ? Mp->at(row, col) * pe_scale : 0.f));
+                    put(row < Mp->rows && col >= 0 && col < Mp->cols ? Mp->at(row, col) * pe_scale : 0.f);
                 }
             }
     }
@@ -86,7 +95,10 @@ struct StreamBuilder {
         for (int rb0 = 0; rb0 < nb; rb0 += group)
             for (int ks = Mh ? 0 : 16; ks < (Mp ? 20 : 16); ++ks) {
                 if (ks >= hks && ks < 16) continue;
-                for (int g = 0; g < group; ++g) frag(Mh, Mp, chan, rb0 + g, ks, pe_scale);
+                for (int g = 0; g < group; ++g) {
+                    if (split) { frag(Mh, Mp, chan, rb0 + g, ks, pe_scale, 1); frag(Mh, Mp, chan, rb0 + g, ks, pe_scale, 2); }
+                    else frag(Mh, Mp, chan, rb0 + g, ks, pe_scale);
+                }
             }
     }
 };
@@ -355,6 +367,17 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         for (int l = 0; l < 8; ++l) Sp.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
         Sp.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
         H.sarena_pairs = Sp.w;
+        // K3C: the (untrimmed) stream with every fragment as an IEEE-half [hi | lo] pair, whatever the operand type of the plain kernels.
+        // The SDF net's own hi + lo input columns (with_lo) are fed zeros by K3C: its whole encoding is split.
+        StreamBuilder Sc;
+        Sc.half = true;
+        Sc.split = true;
+        for (int i = 0; i < 8; ++i) Sc.add(i == 0 ? nullptr : &Rm[i], i == 0 ? &Rm[0] : (i == 4 ? &Rpe4 : nullptr), pe_chan_resd, 256, 1.f);
+        Sc.add(&Rhead, nullptr, pe_chan_resd, 32, 1.f);
+        for (int l = 0; l < 8; ++l) Sc.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
+        Sc.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
+        if (Sc.w.size() != (size_t)3904 * 512) { err = "internal: split weight stream has " + std::to_string(Sc.w.size() / 512) + " fragments, expected 3904"; return 1; }
+        H.sarena_c = Sc.w;
     }
     {   // K4 (reverse mode) streams, same fragment order / K permutation as the K3 stream.
         // forward: the K3 stream + the 256 feature rows of lin8 (head output, no activation; unscaled weights on scaled inputs)

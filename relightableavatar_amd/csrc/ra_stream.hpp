@@ -307,4 +307,83 @@ __device__ __forceinline__ void layer_pairs(PipeT& P, f32x16& a0, f32x16& a1, f3
     row_blocks<E, NW, 2, (6 * KS) % 16, KS, ACT, true, false, false>(P, b0, b1, a0, a1, Bm, Bp, Bo[8], Bo[9], Bo[10], Bo[11], bias + 192, h);
 }
 
+// ---- compensated row blocks (K3C, ra_k3c.hpp): near-fp32 products from f16 MFMAs ---------------------------------------------
+// Both operands are carried as hi + lo pairs of IEEE halves (x = hi + lo exactly to 22 bits; the lo parts of small values are f16
+// subnormals, which the matrix pipe multiplies exactly) and a k-step is three MFMAs into ONE fp32 accumulator:
+//     acc += Ah Bl;  acc += Al Bh;  acc += Ah Bh                       (Al Bl, 2^-22 of the product, is dropped)
+// The weight stream holds every fragment twice, [hi | lo] per k-step (ra_pack.cpp StreamBuilder::split), so a 16-fragment stage is
+// 8 k-steps; the pending epilogue of the previous row block (activation in fp32, then hi = f16(a), lo = f16(a - hi)) is spread
+// over the 3 KS MFMA slots.  Everything else — K permutation, D fragment == next B fragment, LDS-DMA ring — is ra_stream.hpp's.
+// One wave per SIMD (the B fragments alone are 256 registers): K3C serves the surface trace, whose launches never fill the chip.
+template <int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT, int KH = (KS == 4 ? 0 : 16), int ELAST = 41>
+__device__ __forceinline__ void row_block_c(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&BmH)[16], u32x4 (&BmL)[16], const u32x4 (&BpH)[4],
+                                            const u32x4 (&BpL)[4], u32x4& o0h, u32x4& o1h, u32x4& o0l, u32x4& o1l, const float* bias_rb, int h) {
+    typedef f16 E;
+    init_acc(acc, bias_rb, h);
+    float ta[16];
+    constexpr int NS = 3 * KS, PF = PipeT::PF, PFK = PF / 2;       // PF fragments = PFK k-steps read ahead
+    static_for<0, NS>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int ks = i / 3, m = i % 3;
+        const u32x4 bh = ks < KH ? BmH[ks & 15] : BpH[(ks - KH) & 3];
+        const u32x4 bl = ks < KH ? BmL[ks & 15] : BpL[(ks - KH) & 3];
+        constexpr int fh = (FM0 + 2 * ks) % PF, fl = (FM0 + 2 * ks + 1) % PF;
+        if constexpr (m == 0) acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bl), acc);
+        if constexpr (m == 1) acc = Tr<E>::mfma(P.af[fl], __builtin_bit_cast(X8<E>, bh), acc);
+        if constexpr (m == 2) {
+            acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bh), acc);
+            if constexpr (!(TAIL && ks + PFK >= KS)) {
+                P.template fetch<(FM0 + 2 * (ks + PFK)) % 16>();            // hi first: position 0 of a stage turns the ring
+                P.template fetch<(FM0 + 2 * (ks + PFK) + 1) % 16>();
+            }
+        }
+        if constexpr (PENDING) {
+            static_for<0, 16>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
+                constexpr int DA = SP ? 3 : 0;                       // slots until the activation's value exists
+                constexpr int LAST = EARLY ? ELAST : NS - 1;         // last slot that may still write the outputs
+                constexpr int s0 = (e * (LAST - (DA + 2) + 1)) / 16;
+                if constexpr (SP) {
+                    if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
+                    if constexpr (s0 + 1 == i) ta[e] = 1.f + ta[e];
+                    if constexpr (s0 + 2 == i) ta[e] = __builtin_amdgcn_logf(ta[e]);
+                    if constexpr (s0 + 3 == i) ta[e] = sp_finish(ta[e], accPrev[e]);
+                } else {
+                    if constexpr (s0 == i) ta[e] = max0(accPrev[e]);
+                }
+                if constexpr ((e & 1) && s0 + DA + 1 == i) {          // hi halves of the pair (e - 1, e); ta keeps the residuals
+                    f16x2 hv;
+                    hv[0] = (f16)ta[e - 1]; hv[1] = (f16)ta[e];
+                    const unsigned w = __builtin_bit_cast(unsigned, hv);
+                    if constexpr (e < 8) o0h[e >> 1] = w; else o1h[(e >> 1) & 3] = w;
+                    ta[e - 1] -= (float)hv[0];
+                    ta[e] -= (float)hv[1];
+                }
+                if constexpr ((e & 1) && s0 + DA + 2 == i) {
+                    const unsigned w = pack2<E>(ta[e - 1], ta[e]);
+                    if constexpr (e < 8) o0l[e >> 1] = w; else o1l[(e >> 1) & 3] = w;
+                }
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);        // a lone wave per SIMD: keep the reads PF fragments ahead (see row_blocks)
+    });
+}
+
+// a 256-row layer of compensated row blocks; on entry accB holds the pending last row block of the previous layer (if PEND_IN:
+// destination Bm[14], Bm[15]), on exit this layer's last row block is pending in accB
+template <int NW, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
+__device__ __forceinline__ void layer_c(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&BmH)[16], u32x4 (&BmL)[16], const u32x4 (&BpH)[4], const u32x4 (&BpL)[4],
+                                        u32x4 (&BoH)[16], u32x4 (&BoL)[16], const float* bias, int h) {
+    constexpr int KH = KS == 4 ? 0 : 16, F = 2 * KS;     // fragments per row block
+    row_block_c<NW, 0, KS, ACT_IN, PEND_IN, true, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BmH[14], BmH[15], BmL[14], BmL[15], bias, h);
+    row_block_c<NW, (1 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[0], BoH[1], BoL[0], BoL[1], bias + 32, h);
+    row_block_c<NW, (2 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH[2], BoH[3], BoL[2], BoL[3], bias + 64, h);
+    row_block_c<NW, (3 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[4], BoH[5], BoL[4], BoL[5], bias + 96, h);
+    row_block_c<NW, (4 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH[6], BoH[7], BoL[6], BoL[7], bias + 128, h);
+    row_block_c<NW, (5 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[8], BoH[9], BoL[8], BoL[9], bias + 160, h);
+    row_block_c<NW, (6 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH[10], BoH[11], BoL[10], BoL[11], bias + 192, h);
+    row_block_c<NW, (7 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[12], BoH[13], BoL[12], BoL[13], bias + 224, h);
+}
+
 }  // namespace

@@ -17,8 +17,12 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
         neighbouring query points, the REFERENCE's trace ends in a limit cycle on ~9 % of the hit rays, and a 1e-4 distance perturbation flips the
         cycle's phase on ~1 % of the pixels) no 16-bit-operand arithmetic reaches it: tests/golden/precision_floor.json holds
         the result of the operand-rounding emulation of the oracle (tools/precision_floor.py, SURVEY.md:305's experiment) on
-        the same frames — 50.6 dB / max 4.7e-2 with f16, 40.2 dB with bf16 — and the HIP path is held to that floor (- 3 dB: which of the chaotic
-        pixels flip differs between two equally precise computations) and to >= 55 dB on the 98 % best pixels.
+        the same frames — 50.6 dB / max 4.7e-2 with f16, 40.2 dB with bf16.  Round 4: fp32 itself IS stable on all but ~0.5 % of those rays
+        (tools/precision_tiers.py: a float64-accumulated oracle agrees with the fp32 one to 89-110 dB), and compensating ONLY the surface
+        trace's distance queries (K3C, csrc/ra_k3c.hpp: f16 hi + lo operand pairs, 2 % of a frame's fine queries) reaches the contract:
+        every frame test asserts PSNR >= 50 dB over all rays and max |err| <= 1e-2 over every ray fp32 pins (assert_contract; the rays it
+        does not pin — coin tosses of the reference's own closest-approach rule — are listed in tests/golden/fp32_unstable_rays.json,
+        tools/fp32_stability.py).  Measured: frame_relight 63.8 dB / 3.3e-3 (plain f16: 50.7 / 4.7e-2), frame_novel 66.8-70.3 dB (46-52).
   stage bisect ....................... test_mlp_stage_matches_the_operand_rounding_emulation: HIP sdf vs the kernel-like
         emulation is several times closer than the emulation is to fp32, i.e. the in-kernel loss IS the operand rounding
         (v_sin/v_cos encodings, scaled-domain softplus through v_exp/v_log and the f16 re-pack add nothing measurable).
@@ -132,6 +136,53 @@ def test_mlp_stage_bf16(ops):
     resd, sdf, feat = eng.debug_mlp(ops['mlp_bpts'].to(dev))
     e = err(sdf[:, None], ops['mlp_sdf'])
     assert float(e.max()) < 5e-3 and float(e.mean()) < 1e-3
+
+
+def test_compensated_distance_query_is_fp32_accurate(ops):
+    """K3C (csrc/ra_k3c.hpp): the distance query with f16 hi + lo operand pairs (three MFMAs per k-step) — the tier the surface trace
+    runs in (cfg.trace_precision >= 1).  Against the reference's own MLP outputs and against the fp32 oracle on 20 000 near-surface points it
+    must be as accurate as fp32 arithmetic itself (the fp32 oracle is 1.2e-7 rms from a float64 evaluation; plain f16 operands: 5.9e-5),
+    and its two workgroup widths must agree bit for bit."""
+    from oracle import ra_oracle as O
+    cfg, net, dev = build('relight', trace_precision=2)         # 2: every distance query in the compensated tier (validation setting)
+    body = synthetic.make_body(0, posed=True)
+    eng = net.set_frame(synthetic.to_device(body, dev))
+    sdf = eng.observed_sdf(ops['mlp_bpts'].to(dev)).cpu()
+    e = err(sdf[:, None], ops['mlp_sdf'])
+    assert float(e.max()) < 3e-6 and float(e.mean()) < 5e-7, (float(e.max()), float(e.mean()))      # reference outputs (ops.npz); plain f16: 6e-4 / 8e-5
+    g = torch.Generator().manual_seed(11)
+    d = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1)
+    bpts = d * (0.38 + 0.12 * torch.rand(20000, 1, generator=g))
+    sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+    fr = O._frame(body)
+    f32 = O.observed_sdf(O.OracleNet(sd, cfg), bpts, fr)[:, 0]
+    f64 = O.observed_sdf(O.OracleNet(sd, cfg, emulate='f64acc'), bpts, fr)[:, 0]
+    hip = eng.observed_sdf(bpts.to(dev)).cpu()                  # 20 000 points: the 4-wave workgroups
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt())
+    print(f'compensated tier: HIP vs float64-accumulated oracle rms {rms(hip, f64):.2e} (fp32 oracle vs the same: {rms(f32, f64):.2e}), max {float((hip - f64).abs().max()):.2e}')
+    assert rms(hip, f64) < 4e-7 and float((hip - f64).abs().max()) < 3e-6
+    narrow = eng.observed_sdf(bpts[:9000].to(dev)).cpu()        # 9 000 points: the 2-wave workgroups
+    assert torch.equal(narrow, hip[:9000])
+    # the hierarchical query (coarse level + blend) on world points, ragged size
+    x = (bpts * 1.02)[:12345]
+    ref = O.hdq_sdf(O.OracleNet(sd, cfg), x, fr, 0.125, True)[:, 0]
+    h = eng.hdq_sdf(x.to(dev), 0.125, True).cpu()
+    assert float((h - ref).abs().max()) < 5e-6
+    c = eng.counters()
+    assert c.n_fine_sdf_comp == c.n_fine_sdf > 0
+
+
+def test_trace_precision_tiers():
+    """cfg.trace_precision: 0 = plain 16-bit operands everywhere, 1 (default) = the surface trace compensated, the shadow rays plain"""
+    from relightableavatar_amd.renderer import make_renderer
+    comp = {}
+    for tp in (0, 1):
+        cfg, net, dev = build('relight', trace_precision=tp)
+        out = make_renderer(cfg, net).render(synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True, crop=8), dev))
+        c = net.engine().counters()
+        comp[tp] = (c.n_fine_sdf_comp, c.n_fine_sdf, out.acc_map.clone())
+    assert comp[0][0] == 0 and 0 < comp[1][0] < 0.05 * comp[1][1]
+    assert float(((comp[0][2] > 0) == (comp[1][2] > 0)).float().mean()) > 0.98
 
 
 def test_coarse_level_and_warp(ops, relight):
@@ -310,14 +361,40 @@ def trimmed_psnr(a, b, keep=0.98):
     return float(-10 * torch.log10(((a - b)[m] ** 2).mean()))
 
 
+def unstable_rays(case, n_rays):
+    """bool mask of the rays of a parity ray set whose traced surface the reference's own fp32 arithmetic does not pin
+    (tests/golden/fp32_unstable_rays.json, tools/fp32_stability.py: 3e-7 noise on the distances flips them)"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = json.load(open(os.path.join(here, 'golden', 'fp32_unstable_rays.json')))[case]
+    assert d['n_rays'] == n_rays, (case, d['n_rays'], n_rays)
+    m = torch.zeros(n_rays, dtype=torch.bool)
+    m[d['unstable']] = True
+    return m
+
+
+def assert_contract(rgb, rgb_ref, case, label=None, bad=None):
+    """SURVEY.md:409 for the 16-bit path, asserted outright: rgb PSNR >= 50 dB over ALL rays and max |err| <= 1e-2 over every ray whose
+    reference value fp32 itself pins (about 0.5 % of the rays are coin tosses of the reference's own arithmetic: unstable_rays)."""
+    e = err(rgb, rgb_ref)
+    e = e.reshape(-1, e.shape[-1])
+    bad = unstable_rays(case, e.shape[0]) if bad is None else bad
+    p = float(-10 * torch.log10(torch.mean(e ** 2)))
+    mx, mx_all = float(e[~bad].max()), float(e.max())
+    print(f'{label or case}: rgb PSNR {p:.1f} dB, max |err| {mx:.2e} over the {int((~bad).sum())} fp32-stable rays '
+          f'({int(bad.sum())} unstable, max over all rays {mx_all:.2e}), rays over 1e-2: {int((e.amax(-1) > 1e-2).sum())}')
+    assert p >= 50.0, (label or case, p)
+    assert mx <= 1e-2, (label or case, mx)
+    return p, mx
+
+
 def floor_of(golden_dir_name, dtype='f16'):
     here = os.path.dirname(os.path.abspath(__file__))
     return json.load(open(os.path.join(here, 'golden', 'precision_floor.json')))[f'{golden_dir_name}:{dtype}']
 
 
 def test_frame_relight_smooth_meets_the_contract(golden):
-    """SURVEY.md:409: rgb PSNR >= 50 dB and max |err| <= 1e-2 against the reference — on the frame where the reference's
-    trace converges (smooth skinning field); the emulated-f16 floor of this frame is 64.7 dB / 6.1e-3"""
+    """SURVEY.md:409: rgb PSNR >= 50 dB and max |err| <= 1e-2 against the reference (smooth skinning field); with the surface trace in
+    compensated arithmetic the traced surface agrees to 1e-4 on every ray fp32 pins (plain f16 operands: 3e-4 .. 4e-3)"""
     ref = golden('frame_relight_smooth.npz')
     cfg, net, dev = build('relight', vis_specular_map=True)
     from relightableavatar_amd.renderer import make_renderer
@@ -325,12 +402,9 @@ def test_frame_relight_smooth_meets_the_contract(golden):
                                                      skin_noise=float(ref['skin_noise'])), dev)
     out = make_renderer(cfg, net).render(batch)
     assert bool(((out.acc_map.cpu() > 0) == (T(ref['acc_map']) > 0)).all())
-    p, mx = psnr(out.rgb_map, ref['rgb_map']), float(err(out.rgb_map, ref['rgb_map']).max())
-    fl = floor_of('frame_relight_smooth.npz')['rgb_map']
-    print(f'frame_relight_smooth: rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]}), max {mx:.2e} (floor {fl["max_abs"]:.2e})')
-    assert p >= 50.0 and mx <= 1e-2
-    assert p >= fl['psnr'] - 3.0
-    assert float(err(out.albedo_map, ref['albedo_map']).max()) < 1e-3 and float(err(out.surf_map, ref['surf_map']).max()) < 2e-3
+    assert_contract(out.rgb_map, ref['rgb_map'], 'frame_relight_smooth.npz')
+    ok = ~unstable_rays('frame_relight_smooth.npz', out.rgb_map.shape[1])
+    assert float(err(out.albedo_map, ref['albedo_map'])[0][ok].max()) < 1e-3 and float(err(out.surf_map, ref['surf_map'])[0][ok].max()) < 1e-4
     assert psnr(out.shade_map, ref['shade_map']) >= 50.0
     # row H's full key set: render_human's per-hit leftovers (sphere_tracing_renderer.py:616-650) are in the output (lazily: reading
     # them costs the hit count's read-back) and match the reference's as sets of rows (its hit order is topk's, ours ascending)
@@ -348,21 +422,21 @@ def test_frame_relight_smooth_meets_the_contract(golden):
 
 def test_frame_relight(golden):
     out, ref, batch, net = _frame('relight', 'frame_relight.npz', golden, vis_specular_map=True)
-    fl = floor_of('frame_relight.npz')['rgb_map']
-    p, pt = psnr(out.rgb_map, ref['rgb_map']), trimmed_psnr(out.rgb_map[0], ref['rgb_map'][0])
-    print(f'frame_relight (SURVEY 8d body): rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]}), 98 % best pixels {pt:.1f} dB (floor {fl["psnr_trim2pct"]})')
-    assert p >= fl['psnr'] - 3.0 and pt >= 55.0
+    # the SURVEY 8d body (white noise in the skinning logits): the contract itself, no emulation-derived floor (round 3 asserted floor - 3 dB;
+    # plain f16 operands in the surface trace reach 50.7 dB / max 4.7e-2 here, the compensated tier 63.8 dB / 8.4e-3)
+    assert_contract(out.rgb_map, ref['rgb_map'], 'frame_relight.npz', 'frame_relight (SURVEY 8d body)')
     np.testing.assert_allclose(batch.wbounds.cpu().numpy(), ref['wbounds_after'], atol=1e-6)     # in-place bbox growth quirk
     assert bool(((out.acc_map.cpu() > 0) == (T(ref['acc_map']) > 0)).all())
     within(out, ref, 'albedo_map', 5e-4, 0.99)
     within(out, ref, 'roughness_map', 5e-4, 0.99)
-    within(out, ref, 'surf_map', 1e-3, 0.98)
+    within(out, ref, 'surf_map', 1e-4, 0.98)
     within(out, ref, 'norm_map', 2e-2, 0.97)
     within(out, ref, 'shade_map', 2e-2, 0.97)
     within(out, ref, 'spec_map', 5e-3, 0.97)
-    within(out, ref, 'rgb_map', 1e-2, 0.97)
+    within(out, ref, 'rgb_map', 1e-2, 0.99)
     c = net.engine().counters()
     assert c.n_hit_pixels == 256 and c.n_shadow_rays > 0 and c.n_fine_sdf > c.n_shadow_rays
+    assert 0 < c.n_fine_sdf_comp < 0.05 * c.n_fine_sdf          # the surface trace's queries ran in the compensated tier: 2 % of the frame's
 
 
 def test_frame_novel_light(golden):
@@ -374,10 +448,7 @@ def test_frame_novel_light(golden):
         within(out[n], sub, 'rgb_map', 1e-2, 0.97)
         within(out[n], sub, 'shade_map', 2e-2, 0.97)
         within(out[n], sub, 'spec_map', 5e-3, 0.97)
-        fl = floor_of('frame_novel.npz')[f'{n}.rgb_map']            # emulated-f16 oracle vs the same golden (tools/precision_floor.py)
-        p = psnr(out[n].rgb_map, sub['rgb_map'])
-        print(f'frame_novel {n}: rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]})')
-        assert p >= fl['psnr'] - 3.0 and trimmed_psnr(out[n].rgb_map[0], sub['rgb_map'][0]) > 55
+        assert_contract(out[n].rgb_map, sub['rgb_map'], 'frame_novel.npz', f'frame_novel {n}')
     # the cached per-light visibility / cosine of the main pass (what every probe is re-shaded from) against the reference's
     sub = {k[len('probe00.'):]: v for k, v in ref.items() if k.startswith('probe00.')}
     within(out['probe00'], sub, 'ldot_map', 2e-2, 0.97)          # n . l with the f16 normals
@@ -444,8 +515,8 @@ def test_full_size_properties():
 def test_full_size_sample_meets_the_contract():
     """BASELINE.json's frame (512 x 512 full relight) at FULL size, not only through properties: every ~40th in-box ray of the frame
     rendered by the HIP path and by the oracle (rays are independent units) on the body where the reference's own trace converges
-    (skin_noise 0) is held to SURVEY.md:409's contract for the 16-bit path (rgb PSNR >= 50 dB, max |err| <= 1e-2) on its
-    99 % best rays and to the emulated-f16 floor of the very same sample as a whole.  bench.py reports the same comparison for the benchmarked body in its `psnr_vs_oracle` object."""
+    (skin_noise 0) is held to SURVEY.md:409's contract for the 16-bit path (rgb PSNR >= 50 dB, max |err| <= 1e-2).
+    bench.py reports the same comparison for the benchmarked body in its `psnr_vs_oracle` object."""
     from oracle import ra_oracle as O
     from relightableavatar_amd.renderer import make_renderer
     torch.set_num_threads(16)
@@ -457,20 +528,9 @@ def test_full_size_sample_meets_the_contract():
     hit = ref.acc_map > 0
     assert n >= 1000 and 0.3 < float(hit.float().mean()) < 0.9
     assert float(((out.acc_map.cpu() > 0) == hit).float().mean()) > 0.998
-    e = err(out.rgb_map, ref.rgb_map)
-    p, mx = psnr(out.rgb_map, ref.rgb_map), float(e.max())
-    pp = e[0].amax(-1)
-    keep = pp <= pp.kthvalue(int(round(0.99 * pp.numel()))).values
-    pt = float(-10 * torch.log10((e[0][keep] ** 2).mean()))
-    n_bad = int((pp > 1e-2).sum())
-    fl = floor_of('full_size_sample')['rgb_map']          # the emulated-f16 oracle on the SAME sample (tools/precision_floor.py)
-    print(f'512 x 512 relight, {n} sampled rays ({int(hit.sum())} hit), skin_noise 0: rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]}), '
-          f'99 % best rays {pt:.1f} dB (floor {fl["psnr_trim1pct"]}), max |err| {mx:.2e} (floor {fl["max_abs"]:.2e}), rays over 1e-2: {n_bad} (floor {fl["n_rays_over_1e2"]})')
-    # At full size even the smooth body has a few rays (0.6 % here) on which NO 16-bit-operand arithmetic stays within 1e-2 of the fp32 path
-    # (grazing / silhouette rays whose trace ends on the other side of a fold): the emulated oracle itself reaches 49.95 dB, max 9.7e-2 on
-    # this sample.  The contract is therefore asserted on the 99 % best rays, and the whole sample is held to the emulation's floor.
-    assert pt >= 50.0 and float(e[0][keep].max()) <= 1e-2
-    assert p >= fl['psnr'] - 3.0 and pt >= fl['psnr_trim1pct'] - 3.0 and n_bad <= 2 * fl['n_rays_over_1e2'] + 2
+    # every sampled ray that fp32 pins (1022 of 1028) is held to the contract; round 3 (plain f16 operands in the surface trace) could only
+    # assert it on the 99 % best rays: 50.1 dB, max 9.7e-2, 4 rays over 1e-2
+    assert_contract(out.rgb_map, ref.rgb_map, 'full_size_sample', f'512 x 512 relight, {n} sampled rays ({int(hit.sum())} hit), skin_noise 0')
 
 
 def test_sharded_ground_pass_matches_the_whole_frame():
@@ -535,10 +595,7 @@ def test_multi_chunk_matches_oracle():
     within(out, ref, 'albedo_map', 5e-4, 0.98)
     within(out, ref, 'shade_map', 2e-2, 0.95)
     within(out, ref, 'rgb_map', 1e-2, 0.95)
-    fl = floor_of('multi_chunk')['rgb_map']                        # emulated-f16 oracle vs the fp32 oracle on this very case
-    p = psnr(out.rgb_map, ref.rgb_map)
-    print(f'multi_chunk: rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]})')
-    assert p >= fl['psnr'] - 3.0
+    assert_contract(out.rgb_map, ref.rgb_map, 'multi_chunk')
 
 
 def test_anisdf_sphere_tracing_vs_oracle_other_pose():
@@ -553,10 +610,10 @@ def test_anisdf_sphere_tracing_vs_oracle_other_pose():
     assert float(((out.acc_map.cpu() > 0) == (ref.acc_map > 0)).float().mean()) > 0.99
     within(out, ref, 'rgb_map', 5e-3, 0.97)
     within(out, ref, 'norm_map', 2e-2, 0.95)
-    fl = floor_of('other_pose')                                    # emulated-f16 oracle vs the fp32 oracle on this very case
-    pr, pn = psnr(out.rgb_map, ref.rgb_map), psnr(out.norm_map, ref.norm_map)
-    print(f'other_pose: rgb PSNR {pr:.1f} dB, normals {pn:.1f} dB (emulated-f16 floors {fl["rgb_map"]["psnr"]} / {fl["norm_map"]["psnr"]})')
-    assert pr > 45 and pn >= fl['norm_map']['psnr'] - 3.0
+    assert_contract(out.rgb_map, ref.rgb_map, 'other_pose')
+    pn = psnr(out.norm_map, ref.norm_map)
+    print(f'other_pose: normals {pn:.1f} dB')
+    assert pn >= 60.0            # measured 70.1 dB (round 3, plain f16 surface trace: 58.1; the emulated-f16 floor of the normals alone: 59.3)
 
 
 def test_errors_are_python_exceptions():
@@ -670,13 +727,10 @@ def test_frame_ground(golden):
     np.testing.assert_allclose(batch.wbounds.cpu().numpy(), ref['wbounds_after'], atol=1e-6)
     assert out.rgb_map.shape == (1, H * H, 3) and bool(batch.mask_at_box.all())
     e = err(out.rgb_map, ref['rgb_map'])
-    fl = floor_of('frame_ground.npz')['rgb_map']
-    p = psnr(out.rgb_map, ref['rgb_map'])
-    print(f'frame_ground: rgb PSNR {p:.1f} dB (emulated-f16 floor {fl["psnr"]}), max |err| {float(e.max()):.2e} (floor {fl["max_abs"]:.2e}), '
-          f'elements over 5e-3: {int((e >= 5e-3).sum())} of {e.numel()}')
-    # measured 63.1 dB against the emulation's 68.6: 12 of the 1728 values (four pixels on the body's silhouette, where the human layer's
-    # alpha decides between the two layers) carry it; held to floor - 6 dB and to the emulation's own max error x 3
-    assert float((e < 5e-3).float().mean()) > 0.99 and p >= fl['psnr'] - 6.0 and float(e.max()) <= 3 * fl['max_abs'] + 5e-3
+    # the contract on every pixel of the blended frame (measured 78.2 dB / 1.5e-3; round 3, plain f16 surface trace: 63.1 dB with four
+    # silhouette pixels, where the human layer's alpha decides between the two layers, over 5e-3)
+    assert_contract(out.rgb_map, ref['rgb_map'], 'frame_ground.npz', 'frame_ground', bad=torch.zeros(H * H, dtype=torch.bool))
+    assert float((e < 5e-3).float().mean()) > 0.999
     assert float(err(out.albedo_map, ref['albedo_map']).max()) < 1e-2            # ground: fp32 probe lookups; human pixels: f16 heads
     near = T(ref['surf_map'])[0].abs().amax(-1) < 1e3        # rays parallel to the plane: t = x / (0 + eps * |random edge|^2) in the reference
     assert float((err(out.surf_map, ref['surf_map'])[0][near] < 1e-3).float().mean()) > 0.99
