@@ -328,6 +328,10 @@ typedef struct ra_pose_in {
 typedef struct ra_pose_out { void *A, *joints, *tpose, *pverts, *wverts, *pnorm, *R, *pbounds, *wbounds; } ra_pose_out;
 int ra_pose_frame(ra_ctx* ctx, const ra_pose_in* in, const ra_pose_out* out, void* stream);
 
+/* The reference grows batch.wbounds IN PLACE by cfg.env_lvis.bbox_margin once per render chunk (sphere_tracing_renderer.py:1020-1022,
+ * :1054-1056: bbox[:, 0] -= m; bbox[:, 1] += m).  wbounds: the batch's device tensor, 2 x 3 floats (min | max); one launch. */
+int ra_grow_bounds(ra_ctx* ctx, float* wbounds_dev, float margin, void* stream);
+
 /* ---- N4: environment-map rotation and the light-probe inset -------------------------------------
  * ra_shift_envmap: rotate_envmap's shift_image (lib/utils/relight_utils.py:69-85): out[y][x] = bilinear sample of img at
  * x + 0.5 + shift (wrapped modulo W; grid_sample align_corners=False, border padding), img/out: (H,W,C) device fp32.

@@ -122,6 +122,7 @@ SYMBOLS = {
     'ra_gate_destroy': (C.c_int, [C.c_void_p]),
     'ra_set_gate': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ra_pose_frame': (C.c_int, [C.c_void_p, C.POINTER(ra_pose_in), C.POINTER(ra_pose_out), C.c_void_p]),
+    'ra_grow_bounds': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     'ra_shift_envmap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'ra_add_light_probe': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     'ra_map_to_image': (C.c_int, [C.c_void_p, C.POINTER(ra_image_params)] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -31,13 +31,28 @@ class lazydict(dotdict):
     count on the host, i.e. a device synchronisation that the frame loop must not pay unless somebody reads them."""
 
     class _Thunk:
-        __slots__ = ('fn',)
+        __slots__ = ('fn', 'deps')
 
-        def __init__(self, fn):
-            self.fn = fn
+        def __init__(self, fn, deps=()):
+            self.fn, self.deps = fn, tuple(deps)
 
-    def lazy(self, key, fn):
-        dict.__setitem__(self, key, lazydict._Thunk(fn))
+    def lazy(self, key, fn, deps=()):
+        """deps: the tensors `fn` closes over — whoever hands the dict to another stream (pipeline.Pending.result) must record them on it"""
+        dict.__setitem__(self, key, lazydict._Thunk(fn, deps))
+
+    def pending_tensors(self):
+        """tensors captured by entries that have not been evaluated yet"""
+        out = []
+        for v in dict.values(self):
+            if isinstance(v, lazydict._Thunk):
+                out.extend(v.deps)
+        return out
+
+    def __iter__(self):
+        return iter(list(dict.keys(self)))
+
+    def __reduce__(self):          # pickling / copy.copy evaluate: a raw _Thunk must never leave the dict
+        return (dotdict, (dict(self.items()),))
 
     def __getitem__(self, key):
         v = dict.__getitem__(self, key)

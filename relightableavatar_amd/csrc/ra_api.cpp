@@ -988,6 +988,14 @@ int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void*
     return 0;
 }
 
+int ra_grow_bounds(ra_ctx* c, float* wbounds, float margin, void* stream) {
+    RA_CHECK(c && wbounds, "ra_grow_bounds: null argument");
+    RA_HIP(hipSetDevice(c->device));
+    launch_grow_bounds(wbounds, margin, (hipStream_t)stream);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
 int ra_shift_envmap(ra_ctx* c, const float* img, int H, int W, int C, float shift, float* out, void* stream) {
     RA_CHECK(c, "ra_shift_envmap: null ctx");
     RA_CHECK(img && out && H > 0 && W > 0 && C > 0 && img != out, "ra_shift_envmap: bad arguments");

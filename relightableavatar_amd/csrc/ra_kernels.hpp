@@ -206,6 +206,7 @@ struct GroundReshade {                    // novel_light_sphere_tracing.render_g
 void launch_ground_reshade(const GroundReshade& in, hipStream_t s);
 
 // N4: envmap rotation + light-probe inset (ra_trace.hip)
+void launch_grow_bounds(float* wbounds6, float margin, hipStream_t s);
 void launch_shift_envmap(const float* img, int H, int W, int C, float shift, float* out, hipStream_t s);
 struct ProbeInset { float axes[9]; int H, W, uH, uW, ph, pw; };     // axes: columns = right, -front, -down (gen_light_dir)
 void launch_light_probe(const ProbeInset& p, const float* probe, float* rgb, hipStream_t s);

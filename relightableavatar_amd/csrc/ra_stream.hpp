@@ -315,6 +315,13 @@ __device__ __forceinline__ void layer_pairs(PipeT& P, f32x16& a0, f32x16& a1, f3
 // 8 k-steps; the pending epilogue of the previous row block (activation in fp32, then hi = f16(a), lo = f16(a - hi)) is spread
 // over the 3 KS MFMA slots.  Everything else — K permutation, D fragment == next B fragment, LDS-DMA ring — is ra_stream.hpp's.
 // One wave per SIMD (the B fragments alone are 256 registers): K3C serves the surface trace, whose launches never fill the chip.
+// ONE accumulator chain per row block: keeping the two small products in an accumulator of their own (independent MFMA neighbours, the
+// small terms never see the main sum's rounding) measured 165 against 150 us per 128-point tile — the extra AGPR reads and adds of the
+// fold cost more than the shorter chain gains, and the accuracy is fp32's either way.
+#ifndef RA_K3C_E0
+#define RA_K3C_E0 2          // MFMA slots before the pending epilogue first touches the previous accumulator (its last MFMA is still in the pipe)
+#endif
+
 template <int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT, int KH = (KS == 4 ? 0 : 16), int ELAST = 41>
 __device__ __forceinline__ void row_block_c(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&BmH)[16], u32x4 (&BmL)[16], const u32x4 (&BpH)[4],
                                             const u32x4 (&BpL)[4], u32x4& o0h, u32x4& o1h, u32x4& o0l, u32x4& o1l, const float* bias_rb, int h) {
@@ -330,8 +337,8 @@ __device__ __forceinline__ void row_block_c(PipeT& P, f32x16& acc, const f32x16&
         constexpr int fh = (FM0 + 2 * ks) % PF, fl = (FM0 + 2 * ks + 1) % PF;
         if constexpr (m == 0) acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bl), acc);
         if constexpr (m == 1) acc = Tr<E>::mfma(P.af[fl], __builtin_bit_cast(X8<E>, bh), acc);
+        if constexpr (m == 2) acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bh), acc);
         if constexpr (m == 2) {
-            acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bh), acc);
             if constexpr (!(TAIL && ks + PFK >= KS)) {
                 P.template fetch<(FM0 + 2 * (ks + PFK)) % 16>();            // hi first: position 0 of a stage turns the ring
                 P.template fetch<(FM0 + 2 * (ks + PFK) + 1) % 16>();
@@ -343,7 +350,8 @@ __device__ __forceinline__ void row_block_c(PipeT& P, f32x16& acc, const f32x16&
                 constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
                 constexpr int DA = SP ? 3 : 0;                       // slots until the activation's value exists
                 constexpr int LAST = EARLY ? ELAST : NS - 1;         // last slot that may still write the outputs
-                constexpr int s0 = (e * (LAST - (DA + 2) + 1)) / 16;
+                constexpr int E0 = NS >= 24 ? RA_K3C_E0 : 0;
+                constexpr int s0 = E0 + (e * (LAST - E0 - (DA + 2) + 1)) / 16;
                 if constexpr (SP) {
                     if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
                     if constexpr (s0 + 1 == i) ta[e] = 1.f + ta[e];

@@ -1140,6 +1140,13 @@ __global__ void light_probe_kernel(ProbeInset p, const float* __restrict__ probe
     o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
 }
 
+// the in-place box growth of one render chunk (sphere_tracing_renderer.py:1020-1022): wbounds[0] -= m, wbounds[1] += m, torch's fp32 arithmetic
+__global__ void grow_bounds_kernel(float* __restrict__ wb, float m) {
+    const int k = threadIdx.x;
+    if (k < 6) wb[k] = k < 3 ? wb[k] - m : wb[k] + m;
+}
+void launch_grow_bounds(float* wbounds6, float margin, hipStream_t s) { hipLaunchKernelGGL(grow_bounds_kernel, dim3(1), dim3(64), 0, s, wbounds6, margin); }
+
 void launch_shift_envmap(const float* img, int H, int W, int C, float shift, float* out, hipStream_t s) {
     if (H * W <= 0) return;
     hipLaunchKernelGGL(shift_envmap_kernel, grid_for(H * W), dim3(TPB), 0, s, img, H, W, C, shift, out);

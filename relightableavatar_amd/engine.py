@@ -317,6 +317,13 @@ class Engine:
         check(self.lib.ra_pose_frame(self.ctx, C.byref(pin), C.byref(pout), self.stream), 'ra_pose_frame')
         return o
 
+    def grow_bounds(self, wbounds, margin):
+        """batch.wbounds (1,2,3) -= / += margin in place, one launch (the reference's per-chunk quirk, sphere_tracing_renderer.py:1020-1022)"""
+        assert wbounds.is_cuda and wbounds.dtype == torch.float32 and wbounds.is_contiguous() and wbounds.numel() == 6
+        check(self.lib.ra_grow_bounds(self.ctx, _ptr(wbounds), float(margin), self.stream), 'ra_grow_bounds')
+        torch.autograd.graph.increment_version(wbounds)      # an in-place write torch did not see: keep its version counter honest
+        return wbounds
+
     def shift_envmap(self, image, shift):
         """N4: rotate_envmap's shift_image: (H,W,C) or (1,H,W,C) -> same shape, shifted `shift` pixels with wrap-around."""
         x = _f32(image, self.device)

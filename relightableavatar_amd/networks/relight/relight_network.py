@@ -6,7 +6,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from ... import config, synthetic
+from ... import config
+from ...relight_utils import gen_light_xyz
 from ...base_utils import dotdict
 from ..deform import base_network
 from ..deform.base_network import _Embedder, _MLP, _buffer
@@ -35,7 +36,7 @@ class Network(base_network.Network):
         self.microfacet = Microfacet(f0=cfg.fresnel_f0, lambert_only=cfg.lambert_only, glossy_only=cfg.glossy_only)
         ch = 1 if cfg.achro_light else 3
         self.global_env_map_ = nn.Parameter(torch.rand(cfg.env_h * cfg.envmap_upscale, cfg.env_w * cfg.envmap_upscale, ch) * cfg.envmap_init_intensity)
-        xyz, area = synthetic.gen_light_xyz(cfg.env_h, cfg.env_w, cfg.env_r)
+        xyz, area = gen_light_xyz(cfg.env_h, cfg.env_w, cfg.env_r)
         self.light_xyz_ = _buffer(xyz)
         self.light_area = _buffer(area)
         self.light_sharp = _buffer(1 / (area / math.pi).sqrt())
@@ -47,4 +48,14 @@ class Network(base_network.Network):
 
     @property
     def global_env_map(self):
-        return F.softplus(self.global_env_map_.expand(*self.global_env_map_.shape[:2], 3))   # relight_network.py:86-89
+        """softplus of the optimisable map (relight_network.py:86-89).  In eval mode the parameter does not change from frame to frame:
+        the result is kept until the parameter is written again (its version counter), so a render loop launches nothing for it."""
+        p = self.global_env_map_
+        if self.training or torch.is_grad_enabled() and p.requires_grad:
+            return F.softplus(p.expand(*p.shape[:2], 3))
+        key = (p._version, p.data_ptr(), p.device)
+        if getattr(self, '_env_cache_key', None) != key:
+            with torch.no_grad():
+                self._env_cache = F.softplus(p.expand(*p.shape[:2], 3)).contiguous()
+            self._env_cache_key = key
+        return self._env_cache

@@ -51,6 +51,8 @@ def _record(v, stream):
     elif isinstance(v, dict):
         for x in dict.values(v):            # not v.values(): a lazydict would evaluate its lazy entries
             _record(x, stream)
+        if hasattr(v, 'pending_tensors'):   # what its unevaluated thunks close over (allocated on the replica's stream, read on the consumer's)
+            _record(v.pending_tensors(), stream)
     elif isinstance(v, (list, tuple)):
         for x in v:
             _record(x, stream)

@@ -30,8 +30,11 @@ class Renderer(nn.Module):
         host = batch.get('wbounds_host', None)
         if host is not None and wb.is_cuda and batch.get('wbounds_host_version', None) != wb._version:
             host = None                      # somebody else wrote to the device tensor since the mirror was made: read it back
-        wb[:, 0] -= m
-        wb[:, 1] += m
+        if wb.is_cuda and wb.dtype == torch.float32 and wb.is_contiguous() and wb.numel() == 6:
+            self.net.engine().grow_bounds(wb, m)          # one launch (the slice-and-add pair of torch: four)
+        else:
+            wb[:, 0] -= m
+            wb[:, 1] += m
         if not wb.is_cuda:
             return wb[0].reshape(-1).tolist()
         if host is None:
@@ -101,10 +104,10 @@ class Renderer(nn.Module):
             # per-hit arrays in ascending ray order (the reference's order is topk(sorted=False)'s, implementation-defined).  Their
             # shape needs the hit count on the host: evaluated only when read (the trainers' losses, relight_trainer.py:78-79)
             hits = lambda: (full.acc > 0).nonzero()[:, 0]
-            ret.lazy('raw', lambda: full.raw[hits()].reshape(1, -1, raw_c))                     # B, P_hit * S, C
+            ret.lazy('raw', lambda: full.raw[hits()].reshape(1, -1, raw_c), deps=(full.raw, full.acc))                     # B, P_hit * S, C
             if eng.relight:
-                ret.lazy('volume_albedo', lambda: full.volume_albedo[hits()][None])              # B, P_hit, 3
-                ret.lazy('volume_roughness', lambda: full.volume_roughness[hits()][None, :, None])   # B, P_hit, 1
+                ret.lazy('volume_albedo', lambda: full.volume_albedo[hits()][None], deps=(full.volume_albedo, full.acc))              # B, P_hit, 3
+                ret.lazy('volume_roughness', lambda: full.volume_roughness[hits()][None, :, None], deps=(full.volume_roughness, full.acc))   # B, P_hit, 1
         ret.acc_map = full.acc[None]
         ret.ray_o = full.ray_o[None]
         ret.surf_map, ret.depth_map = full.surf[None], full.depth[None]

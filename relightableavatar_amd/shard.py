@@ -69,6 +69,25 @@ def _upload(arrays, device):
     return list(torch.split(dev[:o], sizes)) if o else [dev[:0] for _ in sizes]
 
 
+def _mark_ready(pl, device):
+    """the plan's index vectors were uploaded (pinned, non-blocking) on the CURRENT stream; a cached plan may be consumed later from any
+    other stream (frames in flight: every replica has its own): remember the event that ends the upload and the block it wrote"""
+    if torch.device(device).type == 'cuda':
+        pl.ready = torch.cuda.Event()
+        pl.ready.record(torch.cuda.current_stream(device))
+    return pl
+
+
+def _use(pl):
+    """called by every consumer of a plan's device tensors: the current stream waits for the plan's upload, and the caching allocator
+    learns that this stream reads the block (so `_PLANS.clear()` cannot recycle it under a running gather)"""
+    ev = pl.get('ready', None)
+    if ev is not None and pl.order.is_cuda:
+        cur = torch.cuda.current_stream(pl.order.device)
+        cur.wait_event(ev)
+        pl.order.record_stream(cur)          # order / src / idx / inds are views of ONE uploaded block
+
+
 _FRAMES = {}
 
 
@@ -185,6 +204,7 @@ def make_plan(P: int, world: int, batch=None, device=None, mask=None, ground: bo
                 fg.chunks[render_chunk_size] = [_chunk_ranges(i, F, render_chunk_size) for i in fg.idx]
             g.chunks = fg.chunks[render_chunk_size]
         pl.ground = g
+    _mark_ready(pl, device)
     if key is not None:
         if len(_PLANS) > 16:
             _PLANS.clear()
@@ -219,6 +239,7 @@ def shard_batch(batch, rank: int, world: int, render_chunk_size=None, plan=None,
     dev = batch.ray_o.device
     if plan is None:
         plan = make_plan(P, world, batch, dev, ground=ground, render_chunk_size=render_chunk_size)
+    _use(plan)
     idx = plan.idx[rank]
     out = dotdict(batch)
     for k in RAY_KEYS:
@@ -260,6 +281,7 @@ def gather_maps(local: torch.Tensor, P: int, rank: int, world: int, group=None, 
     x = local[0] if not squeeze else local[0, :, None]
     if plan is None:
         plan = make_plan(P, world, batch, x.device, ground=ground)
+    _use(plan)
     pl = plan.ground if ground else plan
     full = _exchange(x, pl.n_max, pl.order, pl.src, pl.F if ground else P, world, group)[None]
     return full[..., 0] if squeeze else full

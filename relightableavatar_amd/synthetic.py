@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .base_utils import dotdict
+from .relight_utils import gen_light_xyz          # noqa: F401  (re-exported: the synthetic state_dict carries the light buffers)
 
 N_VERTS = 6890
 N_BONES = 52
@@ -137,22 +138,6 @@ def make_state_dict(seed: int = 0, relight: bool = True, cfg=None) -> dict:
         sd['xyz_embedder.freq_bands'] = freq_bands(10)
         sd['view_embedder.freq_bands'] = freq_bands(4)
     return sd
-
-
-def gen_light_xyz(env_h: int, env_w: int, env_r: float):
-    """Light-probe geometry; restates lib/utils/relight_utils.py:423-465 (lat/long cell centres)."""
-    lat_half = math.pi / env_h / 2
-    lng_half = 2 * math.pi / env_w / 2
-    lats = torch.linspace(math.pi / 2 - lat_half, -math.pi / 2 + lat_half, env_h)
-    lngs = torch.linspace(math.pi - lng_half, -math.pi + lng_half, env_w)
-    lngs, lats = torch.meshgrid(lngs, lats, indexing='xy')  # (eH, eW)
-    z = env_r * torch.sin(lats)
-    x = env_r * torch.cos(lats) * torch.cos(lngs)
-    y = env_r * torch.cos(lats) * torch.sin(lngs)
-    xyz = torch.stack((x, y, z), dim=-1)
-    sin_colat = torch.sin(math.pi / 2 - lats)
-    area = 4 * math.pi * sin_colat / torch.sum(sin_colat)
-    return xyz, area
 
 
 def _rodrigues(rvec: np.ndarray) -> np.ndarray:
@@ -295,10 +280,11 @@ def make_skeleton(seed: int = 0):
 
 
 def make_batch(H: int, W: int, seed: int = 0, posed: bool = True, n_novel_lights: int = 0,
-               crop: int = 0, skin_noise: float = 2.0) -> dotdict:
-    """Full §8b batch on CPU. ``crop``>0 keeps only a centred crop x crop window of pixels."""
+               crop: int = 0, skin_noise: float = 2.0, cam_dist: float = 2.0) -> dotdict:
+    """Full §8b batch on CPU. ``crop``>0 keeps only a centred crop x crop window of pixels.  ``cam_dist``: distance of the camera from
+    the body's centre (2 m, the body then covers ~8 % of the frame; 0.96 m: ~35 %, a frame-filling subject)."""
     b = make_body(seed, posed, skin_noise=skin_noise)
-    K, R, T = make_camera(H, W)
+    K, R, T = make_camera(H, W, origin=(0.0, 0.0, -float(cam_dist)))
     ro, rd, near, far, mask = rays_within_bounds(H, W, K, R, T, b.wbounds[0].numpy().astype(np.float64))
     if crop:
         win = np.zeros((H, W), dtype=bool)
@@ -358,4 +344,6 @@ def to_device(batch, device):
             out[k] = to_device(v, device)
         else:
             out[k] = v
+    if 'wbounds_host' in out and isinstance(out.get('wbounds', None), torch.Tensor):
+        out['wbounds_host_version'] = out['wbounds']._version      # the mirror is valid for THIS state of the device tensor (Renderer._grow_bounds)
     return out
