@@ -27,6 +27,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from relightableavatar_amd import synthetic, shard          # noqa: E402
 from relightableavatar_amd.pipeline import FramePipeline    # noqa: E402
+from relightableavatar_amd.base_utils import dotdict        # noqa: E402
 from relightableavatar_amd.config import make_cfg           # noqa: E402
 from relightableavatar_amd.networks import make_network     # noqa: E402
 from relightableavatar_amd.renderer import make_renderer    # noqa: E402
@@ -243,6 +244,7 @@ def main():
     ap.add_argument('--k4-batch', type=int, default=0, help='cfg.k4_batch_slots: full queries per forward+backward launch pair (0 = library default)')
     ap.add_argument('--soak', type=float, default=3.0, help='seconds of untimed frames BEFORE the W warm-up steps: the chip is power-limited on this path (DESIGN.md section 4), so the clock of a cold 0.7 s burst is not the sustained one')
     ap.add_argument('--frames-in-flight', type=int, default=3, help='frames kept in flight on as many HIP streams (relightableavatar_amd/pipeline.py): the latency-bound small-kernel phase of frame f + 1 runs beside the light-visibility stage of frame f, the stages themselves are serialised by a gate.  1 = strictly sequential frames')
+    ap.add_argument('--animate', action='store_true', help='every step renders a DIFFERENT frame of an animation: bone poses -> body state on the device (N3, ra_pose_frame) -> rays + box culling on the device (N2, ra_gen_rays) -> set_frame -> render, all inside the timed region and all asynchronous (the rays of a frame are generated one pipeline turn ahead; their count is read back behind an event)')
     ap.add_argument('--coverage', type=float, default=0.0, help='fraction of the frame the body covers: moves the camera in (0 = SURVEY.md 8d camera at 2 m, ~8 %% hit pixels; 0.35 = a frame-filling subject, camera at 0.96 m)')
     ap.add_argument('--no-sequential', action='store_true', help='skip the strictly sequential leg (ms_per_step_sequential: one frame at a time, host sync after each, as the reference loop run.py:43-49)')
     ap.add_argument('--trace-precision', type=int, default=1, choices=[0, 1, 2], help='cfg.trace_precision: 1 = the surface trace in compensated arithmetic (default), 0 = plain 16-bit operands everywhere (round 3), 2 = compensated everywhere')
@@ -323,7 +325,64 @@ def main():
             return rend_r.render(shard.shard_batch(base, rk, nw, cfg.render_chunk_size, pl, args.ground))
         return shard.render_sharded(rend_r, base, ('rgb_map', 'acc_map'), rank, world, plan=pl)
 
+    anim = None
+    if args.animate:
+        import numpy as np
+        if args.mode not in ('relight', 'sphere_tracing') or args.ground:
+            raise SystemExit('bench.py --animate: relight / sphere_tracing without the ground pass')
+        sk = synthetic.make_skeleton(0)
+        e0 = engs[0]
+        Tn = torch.from_numpy
+        tv_d, w_d = Tn(sk.tverts).to(dev), Tn(sk.weights).to(dev)
+        eye = np.tile(np.eye(4, dtype=np.float32), (sk.poses.shape[0], 1, 1))
+        zero3 = np.zeros(3, np.float32)
+        # the big-pose bone transforms: the same device routine posed with the big pose
+        big_A = e0.pose_frame(sk.big_poses, sk.tjoints, sk.parents, tv_d, w_d, eye, sk.faces, zero3, zero3).A.cpu().numpy()
+        n_anim = 48
+        ph = np.arange(sk.poses.size, dtype=np.float32).reshape(sk.poses.shape)
+        seq = [dict(poses=(sk.poses + 0.06 * np.sin(0.37 * f + ph)).astype(np.float32),
+                    Rh=(sk.Rh + np.array([0.0, 0.05 * np.sin(0.21 * f), 0.0], np.float32)).astype(np.float32),
+                    Th=(sk.Th + np.array([0.01 * np.sin(0.3 * f), 0.0, 0.01 * np.cos(0.3 * f)], np.float32)).astype(np.float32)) for f in range(n_anim)]
+        Kc, Rc, Tc = synthetic.make_camera(H, H, origin=(0.0, 0.0, -cam_dist))
+        from relightableavatar_amd.data_utils import DeviceFrameLoader
+        loader = DeviceFrameLoader(H, H, Kc, Rc, Tc, sk.tjoints, sk.parents, tv_d, w_d, big_A, sk.faces, mask_to_host=nw > 1)
+        anim = dotdict(ahead=[None] * D, wait=0.0, rays=0, cached=None)
+
+        def issue(eng, f):
+            """N3 + N2 of animation frame f on the current stream: body state, then the rays against its box — nothing waits"""
+            q = seq[f % n_anim]
+            return loader.issue(eng, q['poses'], q['Rh'], q['Th'])
+
+        def frame_animate(net_r, rend_r):
+            f = frame_no[0]
+            r = pipe.networks.index(net_r)       # the replica this frame runs on: its stream carries the frame issued ahead for it
+            eng = net_r.engine()
+            if anim.cached is not None:          # the comparison leg: the same frames, posed and culled BEFORE the loop (a loader that is never the bottleneck)
+                b = dotdict(anim.cached[f % n_anim])
+                b.wbounds = b.wbounds.clone()    # the renderer grows the box in place
+                b.wbounds_host, b.wbounds_host_version = b.wbounds_host.clone(), b.wbounds._version
+                if args.emulate_world > 1 or nw > 1:
+                    raise SystemExit('bench.py --animate: the pre-posed comparison leg is single-GPU')
+                return shard.render_sharded(rend_r, b, ('rgb_map', 'acc_map'), rank, world, plan=None)
+            pend = anim.ahead[r] or issue(eng, f)
+            t_w = time.perf_counter()
+            b = loader.batch(pend)               # an event: the kernels that made these rays were queued a pipeline turn ago
+            anim.wait += time.perf_counter() - t_w
+            P_f = b.ray_o.shape[1]
+            anim.rays += P_f
+            pl = shard.make_plan(P_f, nw, b, dev, mask=b.get('mask_host', None), render_chunk_size=cfg.render_chunk_size, use_cache=False) if nw > 1 else None
+            if args.emulate_world > 1:
+                out = rend_r.render(shard.shard_batch(b, rk, nw, cfg.render_chunk_size, pl))
+            else:
+                out = shard.render_sharded(rend_r, b, ('rgb_map', 'acc_map'), rank, world, plan=pl)
+            anim.ahead[r] = issue(eng, f + D)    # this replica's next frame: posed and culled behind this one, read a turn later
+            return out
+
     def step():
+        if anim is not None:
+            p = pipe.submit(fn=frame_animate)
+            frame_no[0] += 1
+            return p
         # queued on the next replica's stream (frames-in-flight 1: the current stream); the timed region ends with a device-wide sync
         p = pipe.submit(fn=frame)
         frame_no[0] += 1
@@ -356,12 +415,16 @@ def main():
         e.reset_counters()
         e.enable_timing(True)
     sync()
+    frame_start = frame_no[0]
+    if anim is not None:
+        anim.wait, anim.rays = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     t_host = time.perf_counter() - t0           # all steps queued: the host's share (the GPU is the bound while this stays below dt)
     sync()
     dt = time.perf_counter() - t0
+    t_wait = anim.wait if anim is not None else 0.0
     for e in engs:
         e.enable_timing(False)
     # the strictly sequential loop beside it: one frame at a time, the host waits for each (the reference's loop, run.py:43-49) — this is
@@ -377,12 +440,28 @@ def main():
             torch.cuda.synchronize(dev)
         sync()
         dt_seq = (time.perf_counter() - t1) / n_seq
+    dt_static = None
+    if anim is not None:
+        rays_per_frame_anim = anim.rays / max(args.steps, 1)
+    if anim is not None and nw == 1:          # the same frames through the same pipeline with N3 + N2 done BEFORE the loop: what posing / culling inside it costs
+        sync()
+        anim.cached = [loader.batch(issue(e0, f)) for f in range(n_anim)]
+        sync()
+        frame_no[0] = 0
+        for _ in range(D + 2):
+            step()
+        sync()
+        frame_no[0] = frame_start % n_anim          # the same stretch of the pose cycle as the timed region
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt_static = (time.perf_counter() - t2) / args.steps
     my_ms = dt / args.steps * 1e3
     tt = torch.tensor([dt, dt_seq or 0.0], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, dt_seq = float(tt[0].item()), (float(tt[1].item()) if dt_seq is not None else None)
-    from relightableavatar_amd.base_utils import dotdict
     cnt = dotdict()
     for c_e in cnt_snapshot:                        # every replica counted its own frames (snapshot taken before the sequential leg)
         for k, v in c_e.items():
@@ -460,7 +539,15 @@ def main():
         line['config']['fine_queries_compensated_per_frame'] = int(cnt.get('n_fine_sdf_comp', 0) / args.steps)
         if args.emulate_world > 1:
             line['config']['emulate_world'], line['config']['emulate_rank'] = args.emulate_world, args.emulate_rank
-        line['host_enqueue_ms_per_step'] = t_host / args.steps * 1e3
+        line['host_enqueue_ms_per_step'] = (t_host - t_wait) / args.steps * 1e3
+        if anim is not None:
+            line['host_wait_ms_per_step'] = t_wait / args.steps * 1e3         # back-pressure: waiting for the count of rays generated one pipeline turn earlier
+            line['config']['animate'] = (f'{n_anim}-frame pose cycle: per step ra_pose_frame (N3: bone transforms, LBS, normals, bounds on the device) + '
+                                         f'ra_gen_rays against the new box (N2) + set_frame + render; rays of frame f generated {D} steps ahead')
+            line['config']['rays_in_bbox'] = int(rays_per_frame_anim)
+            if dt_static is not None:
+                line['ms_per_step_frames_posed_before_the_loop'] = dt_static * 1e3          # the same frames, N3 + N2 outside the loop
+                line['animate_over_preposed'] = dt / args.steps / dt_static
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ref = cpu_baseline(cfg, H, args.skin_noise, cam_dist=cam_dist)
             if args.mode in ('relight', 'sphere_tracing', 'anisdf') and not args.ground and args.emulate_world <= 1:

@@ -303,10 +303,14 @@ int ra_blend_ground(ra_ctx* ctx, const float* ground, const float* human, const 
  * K, R: 9 doubles row-major, T: 3 doubles (host); bounds: 6 floats (host: min xyz, max xyz = batch.wbounds).
  * Device outputs with capacity H*W rays: ray_o, ray_d (n,3) f32; near, far (n) f32 — the in-box rays in row-major
  * pixel order, exactly the reference's boolean-mask order; mask_at_box: H*W uint8.  *n_rays receives the count
- * (synchronises the stream); n_rays = NULL: no read-back, no synchronisation (the caller knows the count, e.g. H*W for an unbounded box).  Directions are computed in fp64 and rounded once (the reference computes them in the
+ * (synchronises the stream); n_rays = NULL: no read-back, no synchronisation (the caller knows the count, e.g. H*W for an unbounded box).
+ * bounds_dev (6 device floats, takes precedence over the host `bounds`, which may then be NULL): the box of a frame whose body state
+ * is still being computed on the stream (ra_pose_frame's wbounds) — no host round trip between N3 and N2.  n_rays_dev (device int,
+ * nullable) receives the count too: an animation loop copies it to pinned memory behind an event and reads it a pipeline turn later
+ * (relightableavatar_amd/engine.py gen_rays_async), so generating the rays of frame f + 1 never waits for frame f.  Directions are computed in fp64 and rounded once (the reference computes them in the
  * camera's dtype and casts to float32); near/far follow the reference's float32 arithmetic operation by operation. */
-int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
-                void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream);
+int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, const double* T, const float* bounds, const float* bounds_dev,
+                void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, int* n_rays_dev, void* stream);
 
 /* ---- N3: per-frame body state on the device -----------------------------------------------------
  * replaces lib/datasets/base_dataset.py:308-397 (get_lbs_params with cfg.use_geometry, get_blend), which runs on the CPU
@@ -316,7 +320,11 @@ int ra_gen_rays(ra_ctx* ctx, int H, int W, const double* K, const double* R, con
  * Host inputs: poses, tjoints (J,3) f32, parents (J) int32 (topological order, parents[0] unused), big_A (J,16) f32,
  * Rh, Th (3) f32, faces (F,3) int32 (its vertex -> corner list is cached by content hash).
  * Device inputs: tverts (N,3), weights (N,J).  Device outputs (any may be NULL): A (J,16), joints (J,3), tpose (N,3),
- * pverts (N,3), wverts (N,3), pnorm (N,3), R (9), pbounds (6), wbounds (6). */
+ * pverts (N,3), wverts (N,3), pnorm (N,3), R (9), pbounds (6), wbounds (6).
+ * ASYNCHRONOUS: the host inputs are copied into a pinned staging ring of the context before the call returns (the caller may reuse its
+ * arrays at once), uploaded with one asynchronous copy, and the bone transforms (Rodrigues + the chain of 4 x 4 products, float64) run
+ * on the device; nothing waits for the stream except the first call with a new `faces` array (its vertex -> corner list is built on the
+ * host and uploaded synchronously, once per mesh). */
 typedef struct ra_pose_in {
     const float *poses, *tjoints, *big_A, *Rh, *Th;
     const int* parents;
@@ -325,7 +333,10 @@ typedef struct ra_pose_in {
     const void *tverts, *weights;
     float bounds_padding;           /* get_bounds(padding=0.05) */
 } ra_pose_in;
-typedef struct ra_pose_out { void *A, *joints, *tpose, *pverts, *wverts, *pnorm, *R, *pbounds, *wbounds; } ra_pose_out;
+typedef struct ra_pose_out {
+    void *A, *joints, *tpose, *pverts, *wverts, *pnorm, *R, *pbounds, *wbounds;
+    void *poses, *Th;               /* device copies of the uploaded poses (J,3) and Th (3): the batch keys `poses` / `Th` without a second upload */
+} ra_pose_out;
 int ra_pose_frame(ra_ctx* ctx, const ra_pose_in* in, const ra_pose_out* out, void* stream);
 
 /* The reference grows batch.wbounds IN PLACE by cfg.env_lvis.bbox_margin once per render chunk (sphere_tracing_renderer.py:1020-1022,

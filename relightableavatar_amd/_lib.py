@@ -71,7 +71,7 @@ class ra_pose_in(C.Structure):
                 ('tverts', C.c_void_p), ('weights', C.c_void_p), ('bounds_padding', C.c_float)]
 
 
-POSE_OUT_KEYS = ('A', 'joints', 'tpose', 'pverts', 'wverts', 'pnorm', 'R', 'pbounds', 'wbounds')
+POSE_OUT_KEYS = ('A', 'joints', 'tpose', 'pverts', 'wverts', 'pnorm', 'R', 'pbounds', 'wbounds', 'poses', 'Th')
 
 
 class ra_pose_out(C.Structure):
@@ -126,7 +126,8 @@ SYMBOLS = {
     'ra_shift_envmap': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'ra_add_light_probe': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     'ra_map_to_image': (C.c_int, [C.c_void_p, C.POINTER(ra_image_params)] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'ra_gen_rays': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.c_void_p]),
+    'ra_gen_rays': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_float), C.c_void_p] + [C.c_void_p] * 5 +
+                    [C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
     'ra_debug_mlp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_full': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_aabb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),

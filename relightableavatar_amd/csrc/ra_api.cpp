@@ -88,6 +88,8 @@ int ra_ctx_destroy(ra_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : c->scratch) kv.second.release();
     for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (int k = 0; k < PinRing::n; ++k) if (c->pin.ev[k]) hipEventDestroy(c->pin.ev[k]);
+    if (c->pin.base) hipHostFree(c->pin.base);
     delete c;
     return 0;
 }
@@ -862,19 +864,29 @@ int ra_set_knn_mode(ra_ctx* c, int use_bvh) {
     return 0;
 }
 
-// Rodrigues as data_utils.py:1004-1023 (smplx.lbs.batch_rodrigues): angle = |r + 1e-8|, R = I + sin K + (1 - cos) K^2, float32 out
-static void rodrigues_smplx(const float* r, double R[9]) {
-    const double x = (double)r[0] + 1e-8, y = (double)r[1] + 1e-8, z = (double)r[2] + 1e-8;
-    const double angle = std::sqrt(x * x + y * y + z * z);
-    const double d[3] = {r[0] / angle, r[1] / angle, r[2] / angle};
-    const double K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
-    const double sn = std::sin(angle), cs = std::cos(angle);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double kk = 0;
-            for (int k = 0; k < 3; ++k) kk += K[3 * i + k] * K[3 * k + j];
-            R[3 * i + j] = (double)(float)((i == j ? 1.0 : 0.0) + sn * K[3 * i + j] + (1.0 - cs) * kk);
+// pinned staging ring of the context (ra_ctx.hpp PinRing)
+static char* pin_acquire(ra_ctx* c, size_t bytes, int* slot) {
+    PinRing& r = c->pin;
+    if (bytes > r.slot_bytes) {
+        if (r.base) {
+            for (int k = 0; k < PinRing::n; ++k) if (r.used[k]) { hipEventSynchronize(r.ev[k]); r.used[k] = false; }
+            hipHostFree(r.base);
+            r.base = nullptr;
         }
+        const size_t sb = (bytes + 4095) & ~(size_t)4095;
+        if (hipHostMalloc((void**)&r.base, sb * PinRing::n, hipHostMallocDefault) != hipSuccess) { r.base = nullptr; r.slot_bytes = 0; return nullptr; }
+        r.slot_bytes = sb;
+        for (int k = 0; k < PinRing::n; ++k) if (!r.ev[k]) hipEventCreateWithFlags(&r.ev[k], hipEventDisableTiming);
+    }
+    const int k = r.next;
+    r.next = (k + 1) % PinRing::n;
+    if (r.used[k]) hipEventSynchronize(r.ev[k]);        // only when the host is PinRing::n frames ahead of this stream
+    *slot = k;
+    return r.base + (size_t)k * r.slot_bytes;
+}
+static void pin_release(ra_ctx* c, int slot, hipStream_t s) {
+    hipEventRecord(c->pin.ev[slot], s);
+    c->pin.used[slot] = true;
 }
 
 int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void* stream) {
@@ -885,74 +897,42 @@ int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void*
     RA_CHECK(!out->pnorm || (in->faces && F > 0), "ra_pose_frame: vertex normals need faces");
     hipStream_t s = (hipStream_t)stream;
     RA_HIP(hipSetDevice(c->device));
-    // ---- bone transforms on the host in fp64 (get_rigid_transformation_and_joints, data_utils.py:1026-1069): 52 4x4 products
-    std::vector<double> T((size_t)J * 16), chain((size_t)J * 16);
-    for (int j = 0; j < J; ++j) {
-        double R[9];
-        rodrigues_smplx(in->poses + 3 * j, R);
-        RA_CHECK(j == 0 || (in->parents[j] >= 0 && in->parents[j] < j), "ra_pose_frame: parents must be in topological order");
-        double* t = &T[(size_t)j * 16];
-        for (int r = 0; r < 3; ++r) {
-            for (int k = 0; k < 3; ++k) t[4 * r + k] = R[3 * r + k];
-            t[4 * r + 3] = (double)in->tjoints[3 * j + r] - (j ? (double)in->tjoints[3 * in->parents[j] + r] : 0.0);
-        }
-        t[12] = t[13] = t[14] = 0.0; t[15] = 1.0;
-        double* o = &chain[(size_t)j * 16];
-        if (j == 0) { for (int e = 0; e < 16; ++e) o[e] = t[e]; continue; }
-        const double* p = &chain[(size_t)in->parents[j] * 16];
-        for (int r = 0; r < 4; ++r)
-            for (int k = 0; k < 4; ++k) { double a = 0; for (int m = 0; m < 4; ++m) a += p[4 * r + m] * t[4 * m + k]; o[4 * r + k] = a; }
-    }
-    std::vector<float> A((size_t)J * 16), joints((size_t)J * 3);
-    for (int j = 0; j < J; ++j) {
-        double* o = &chain[(size_t)j * 16];
-        for (int r = 0; r < 3; ++r) joints[3 * j + r] = (float)o[4 * r + 3];
-        for (int r = 0; r < 4; ++r) {
-            double rot = 0;
-            for (int k = 0; k < 3; ++k) rot += o[4 * r + k] * (double)in->tjoints[3 * j + k];
-            o[4 * r + 3] -= rot;          // transforms[..., 3] -= transforms @ [joint, 0]
-        }
-        for (int e = 0; e < 16; ++e) A[(size_t)j * 16 + e] = (float)o[e];
-    }
-    // global rotation: cv2.Rodrigues(Rh)
-    float Rg[9];
-    {
-        const double r[3] = {in->Rh[0], in->Rh[1], in->Rh[2]};
-        const double th = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-        double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (th >= 1e-12) {
-            const double k[3] = {r[0] / th, r[1] / th, r[2] / th};
-            const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) {
-                    double kk = 0;
-                    for (int m = 0; m < 3; ++m) kk += K[3 * i + m] * K[3 * m + j];
-                    Rd[3 * i + j] = (i == j ? 1.0 : 0.0) + std::sin(th) * K[3 * i + j] + (1.0 - std::cos(th)) * kk;
-                }
-        }
-        for (int e = 0; e < 9; ++e) Rg[e] = (float)Rd[e];
-    }
+    for (int j = 1; j < J; ++j) RA_CHECK(in->parents[j] >= 0 && in->parents[j] < j, "ra_pose_frame: parents must be in topological order");
+    // ---- the frame's small host inputs: ONE pinned block, ONE asynchronous upload; the bone transforms themselves (52 Rodrigues
+    // rotations + the chain of 4 x 4 products, float64) run on the device behind it.  Nothing here waits for the stream: with frames
+    // in flight an animated sequence poses frame f + 1 while frame f renders (round 3 computed the chain on the host and ended in a
+    // hipStreamSynchronize: a full host stall per animated frame).
+    const size_t n_in = (size_t)J * (3 + 3 + 16 + 1) + 6;
     int err = 0;
+    float* dIn = c->buf<float>("pf_in", n_in, &err);
     float* dA = c->buf<float>("pf_A", (size_t)J * 16, &err);
-    float* dB = c->buf<float>("pf_bigA", (size_t)J * 16, &err);
+    float* dJ = c->buf<float>("pf_J", (size_t)J * 3, &err);
     float* dR = c->buf<float>("pf_R", 12, &err);
     float* dP = c->buf<float>("pf_p", (size_t)N * 3, &err);
     float* dW = c->buf<float>("pf_w", (size_t)N * 3, &err);
     RA_CHECK(!err, "ra_pose_frame: out of device memory");
-    float RT[12];
-    for (int e = 0; e < 9; ++e) RT[e] = Rg[e];
-    for (int e = 0; e < 3; ++e) RT[9 + e] = in->Th[e];
-    RA_HIP(hipMemcpyAsync(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice, s));
-    RA_HIP(hipMemcpyAsync(dB, in->big_A, (size_t)J * 64, hipMemcpyHostToDevice, s));
-    RA_HIP(hipMemcpyAsync(dR, RT, sizeof(RT), hipMemcpyHostToDevice, s));
-    RA_HIP(hipStreamSynchronize(s));        // the host vectors go out of scope
+    {
+        int slot = 0;
+        float* st = reinterpret_cast<float*>(pin_acquire(c, n_in * sizeof(float), &slot));
+        RA_CHECK(st, "ra_pose_frame: no pinned host memory for the staging ring");
+        std::memcpy(st, in->poses, (size_t)J * 12);
+        std::memcpy(st + 3 * J, in->tjoints, (size_t)J * 12);
+        std::memcpy(st + 6 * J, in->big_A, (size_t)J * 64);
+        std::memcpy(st + 22 * J, in->Rh, 12);
+        std::memcpy(st + 22 * J + 3, in->Th, 12);
+        std::memcpy(st + 22 * J + 6, in->parents, (size_t)J * 4);
+        RA_HIP(hipMemcpyAsync(dIn, st, n_in * sizeof(float), hipMemcpyHostToDevice, s));
+        pin_release(c, slot, s);
+    }
+    launch_bone_transforms(dIn, J, dA, dJ, dR, s);
+    const float* dB = dIn + 6 * J;             // big_A as uploaded
     float* pv = out->pverts ? (float*)out->pverts : dP;
     float* wv = out->wverts ? (float*)out->wverts : dW;
     launch_lbs_verts((const float*)in->tverts, (const float*)in->weights, dA, dB, dR, dR + 9, N, J, (float*)out->tpose, pv, wv, s);
     if (out->pnorm) {
         // incident corners per vertex in index_add order, cached per (faces pointer, count)
         unsigned long long fh = 1469598103934665603ull;          // FNV-1a over the face indices: the cache key is the CONTENT
-        for (int k = 0; k < 3 * F; ++k) { fh ^= (unsigned)in->faces[k]; fh *= 1099511628211ull; }
+        for (int k = 0; k < 3 * F; ++k) { fh ^= (unsigned)in->faces[k]; fh *= 1099511628211ull; }         // 40 k steps: ~30 us of host time per frame
         if (c->adj_hash != fh || c->adj_n_faces != F || c->adj_n_verts != N) {
             std::vector<int> start(N + 1, 0), adj((size_t)F * 3);
             const int order[3] = {1, 2, 0};
@@ -978,12 +958,9 @@ int ra_pose_frame(ra_ctx* c, const ra_pose_in* in, const ra_pose_out* out, void*
     if (out->wbounds) launch_bounds(wv, N, in->bounds_padding, (float*)out->wbounds, s);
     if (out->A) RA_HIP(hipMemcpyAsync(out->A, dA, (size_t)J * 64, hipMemcpyDeviceToDevice, s));
     if (out->R) RA_HIP(hipMemcpyAsync(out->R, dR, 36, hipMemcpyDeviceToDevice, s));
-    if (out->joints) {
-        float* dJ = c->buf<float>("pf_J", (size_t)J * 3, &err);
-        RA_CHECK(!err, "ra_pose_frame: out of device memory");
-        RA_HIP(hipMemcpy(dJ, joints.data(), joints.size() * 4, hipMemcpyHostToDevice));
-        RA_HIP(hipMemcpyAsync(out->joints, dJ, (size_t)J * 12, hipMemcpyDeviceToDevice, s));
-    }
+    if (out->joints) RA_HIP(hipMemcpyAsync(out->joints, dJ, (size_t)J * 12, hipMemcpyDeviceToDevice, s));
+    if (out->poses) RA_HIP(hipMemcpyAsync(out->poses, dIn, (size_t)J * 12, hipMemcpyDeviceToDevice, s));
+    if (out->Th) RA_HIP(hipMemcpyAsync(out->Th, dIn + 22 * J + 3, 12, hipMemcpyDeviceToDevice, s));
     RA_HIP(hipGetLastError());
     return 0;
 }
@@ -1078,11 +1055,11 @@ static void inv3x3(const double* m, double* o) {
     o[6] = (d * h - e * g) / det; o[7] = (b * g - a * h) / det; o[8] = (a * e - b * d) / det;
 }
 
-int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const double* T, const float* bounds,
-                void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, void* stream) {
+int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const double* T, const float* bounds, const float* bounds_dev,
+                void* ray_o, void* ray_d, void* near, void* far, void* mask_at_box, int* n_rays, int* n_rays_dev, void* stream) {
     RA_CHECK(c, "ra_gen_rays: null ctx");
     RA_CHECK(H > 0 && W > 0 && (long long)H * W < (1ll << 30), "ra_gen_rays: bad image size");
-    RA_CHECK(K && R && T && bounds && ray_o && ray_d && near && far && mask_at_box, "ra_gen_rays: null argument");
+    RA_CHECK(K && R && T && (bounds || bounds_dev) && ray_o && ray_d && near && far && mask_at_box, "ra_gen_rays: null argument");
     hipStream_t s = (hipStream_t)stream;
     RA_HIP(hipSetDevice(c->device));
     RayCam cam;
@@ -1091,10 +1068,11 @@ int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const
     for (int k = 0; k < 3; ++k) {
         cam.T[k] = T[k];
         cam.o[k] = -(R[k] * T[0] + R[3 + k] * T[1] + R[6 + k] * T[2]);      // -R^T T
-        cam.bmin[k] = bounds[k];
-        cam.bmax[k] = bounds[3 + k];
+        cam.bmin[k] = bounds ? bounds[k] : 0.f;
+        cam.bmax[k] = bounds ? bounds[3 + k] : 0.f;
     }
     cam.H = H; cam.W = W;
+    cam.bdev = bounds_dev;
     const int n = H * W;
     int err = 0;
     const size_t tb = gen_rays_temp_bytes(n);
@@ -1104,6 +1082,7 @@ int ra_gen_rays(ra_ctx* c, int H, int W, const double* K, const double* R, const
     int* count_dev = pix + n;
     RA_CHECK(launch_gen_rays(cam, (unsigned char*)mask_at_box, pix, count_dev, temp, tb, (float*)ray_o, (float*)ray_d, (float*)near,
                              (float*)far, s) == 0, "ra_gen_rays: device selection failed");
+    if (n_rays_dev) RA_HIP(hipMemcpyAsync(n_rays_dev, count_dev, sizeof(int), hipMemcpyDeviceToDevice, s));     // for a caller that reads it back later
     if (n_rays) {           // the count on the host costs a synchronisation; a caller that knows it (an unbounded box: H * W) passes NULL
         RA_HIP(hipMemcpyAsync(n_rays, count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
         RA_HIP(hipStreamSynchronize(s));

@@ -36,8 +36,20 @@ struct ra_gate {
     bool armed = false;
 };
 
+// Pinned host staging for small per-frame inputs (bone poses): a slot is filled by the host, copied H2D asynchronously and may be refilled
+// once its event has passed — the host never waits for the stream unless it runs more than `n` frames ahead.
+struct PinRing {
+    static constexpr int n = 8;
+    char* base = nullptr;
+    size_t slot_bytes = 0;
+    int next = 0;
+    hipEvent_t ev[n] = {};
+    bool used[n] = {};
+};
+
 struct ra_ctx {
     int device = 0;
+    PinRing pin;
     ra_gate* gate = nullptr;
     ra_config cfg{};
     bool have_cfg = false, have_weights = false, have_frame = false;

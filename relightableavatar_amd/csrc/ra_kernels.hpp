@@ -168,7 +168,7 @@ void launch_bigpose_compose(const float* mats, const float* d2, int n, float ble
 void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s);
 
 // N2: ray generation + AABB culling (ra_trace.hip)
-struct RayCam { double Kinv[9]; double R[9]; double T[3]; double o[3]; float bmin[3]; float bmax[3]; int H, W; };
+struct RayCam { double Kinv[9]; double R[9]; double T[3]; double o[3]; float bmin[3]; float bmax[3]; int H, W; const float* bdev; };   // bdev: the box as 6 device floats (takes precedence)
 size_t gen_rays_temp_bytes(int n_pixels);
 int launch_gen_rays(const RayCam& cam, unsigned char* mask, int* pix_idx, int* count_dev, void* temp, size_t temp_bytes,
                     float* ray_o, float* ray_d, float* near, float* far, hipStream_t s);
@@ -214,6 +214,7 @@ void launch_blend_ground(const float* ground, const float* human, const long lon
                          hipStream_t s);
 
 // N3: per-frame body state (ra_trace.hip)
+void launch_bone_transforms(const float* staged, int J, float* A, float* joints, float* RT, hipStream_t s);
 void launch_lbs_verts(const float* tverts, const float* weights, const float* A, const float* big_A, const float* R, const float* Th,
                       int n_verts, int n_bones, float* tpose, float* pverts, float* wverts, hipStream_t s);
 void launch_vert_normals(const float* verts, const int* faces, const int* adj_start, const int* adj, int n_verts, float* normals, hipStream_t s);

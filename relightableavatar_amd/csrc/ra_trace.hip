@@ -1081,6 +1081,91 @@ __global__ __launch_bounds__(1024) void bounds_kernel(const float* __restrict__ 
     }
 }
 
+// Bone transforms of one frame on the device, in float64 like the reference's numpy twin (get_rigid_transformation_and_joints,
+// data_utils.py:1004-1069 / smplx.lbs.batch_rigid_transform): per joint a Rodrigues rotation (angle = |r + 1e-8|, entries rounded to
+// float32 as batch_rodrigues returns them), the chain of 4 x 4 products along the kinematic tree (parents in topological order), then
+// transforms[:, :3, 3] -= transforms[:, :3, :3] @ joint.  One wave: the chain is 51 dependent products whatever the width; lane e < 16
+// owns element e of the running product.  Also the global rotation cv2.Rodrigues(Rh) and Th -> RT (12 floats).
+// in: [poses 3J | tjoints 3J | big_A 16J | Rh 3 | Th 3 | parents J (int bits)], the block ra_pose_frame stages.
+__global__ __launch_bounds__(64) void bone_transforms_kernel(const float* __restrict__ in, int J, float* __restrict__ A, float* __restrict__ joints,
+                                                             float* __restrict__ RT) {
+#pragma clang fp contract(off)                        // operation by operation as the host code it replaces: no fused multiply-adds
+    extern __shared__ double sh[];                    // T[J][16] then chain[J][16]
+    double* Tm = sh;
+    double* chain = sh + (size_t)J * 16;
+    const float* poses = in;
+    const float* tj = in + 3 * J;
+    const float* Rh = in + 3 * J + 3 * J + 16 * J;
+    const float* Th = Rh + 3;
+    const int* parents = reinterpret_cast<const int*>(Th + 3);
+    const int lane = threadIdx.x;
+    for (int j = lane; j < J; j += 64) {
+        const float* r = poses + 3 * j;
+        const double x = (double)r[0] + 1e-8, y = (double)r[1] + 1e-8, z = (double)r[2] + 1e-8;
+        const double angle = sqrt(x * x + y * y + z * z);
+        const double d[3] = {r[0] / angle, r[1] / angle, r[2] / angle};
+        const double K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+        const double sn = sin(angle), cs = cos(angle);
+        double* t = Tm + (size_t)j * 16;
+        const int par = parents[j];
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) {
+                double kk = 0;
+                for (int k = 0; k < 3; ++k) kk += K[3 * a + k] * K[3 * k + b];
+                t[4 * a + b] = (double)(float)((a == b ? 1.0 : 0.0) + sn * K[3 * a + b] + (1.0 - cs) * kk);
+            }
+            t[4 * a + 3] = (double)tj[3 * j + a] - (j ? (double)tj[3 * par + a] : 0.0);
+        }
+        t[12] = t[13] = t[14] = 0.0; t[15] = 1.0;
+    }
+    __syncthreads();
+    if (lane < 16) chain[lane] = Tm[lane];
+    __syncthreads();
+    for (int j = 1; j < J; ++j) {
+        if (lane < 16) {
+            const double* pm = chain + (size_t)parents[j] * 16;
+            const double* t = Tm + (size_t)j * 16;
+            const int r = lane >> 2, k = lane & 3;
+            double a = 0;
+            for (int m = 0; m < 4; ++m) a += pm[4 * r + m] * t[4 * m + k];
+            chain[(size_t)j * 16 + lane] = a;
+        }
+        __syncthreads();
+    }
+    for (int j = lane; j < J; j += 64) {
+        double* o = chain + (size_t)j * 16;
+        for (int r = 0; r < 3; ++r) joints[3 * j + r] = (float)o[4 * r + 3];
+        for (int r = 0; r < 4; ++r) {
+            double rot = 0;
+            for (int k = 0; k < 3; ++k) rot += o[4 * r + k] * (double)tj[3 * j + k];
+            o[4 * r + 3] -= rot;          // transforms[..., 3] -= transforms @ [joint, 0]
+        }
+        for (int e = 0; e < 16; ++e) A[(size_t)j * 16 + e] = (float)o[e];
+    }
+    if (lane == 0) {                      // cv2.Rodrigues(Rh)
+        const double r[3] = {Rh[0], Rh[1], Rh[2]};
+        const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        double Rd[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (th >= 1e-12) {
+            const double k[3] = {r[0] / th, r[1] / th, r[2] / th};
+            const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
+            const double sn = sin(th), cs = cos(th);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double kk = 0;
+                    for (int m = 0; m < 3; ++m) kk += K[3 * i + m] * K[3 * m + j];
+                    Rd[3 * i + j] = (i == j ? 1.0 : 0.0) + sn * K[3 * i + j] + (1.0 - cs) * kk;
+                }
+        }
+        for (int e = 0; e < 9; ++e) RT[e] = (float)Rd[e];
+        for (int e = 0; e < 3; ++e) RT[9 + e] = Th[e];
+    }
+}
+
+void launch_bone_transforms(const float* staged, int J, float* A, float* joints, float* RT, hipStream_t s) {
+    hipLaunchKernelGGL(bone_transforms_kernel, dim3(1), dim3(64), (size_t)J * 32 * sizeof(double), s, staged, J, A, joints, RT);
+}
+
 void launch_lbs_verts(const float* tverts, const float* weights, const float* A, const float* big_A, const float* R, const float* Th,
                       int n_verts, int n_bones, float* tpose, float* pverts, float* wverts, hipStream_t s) {
     if (n_verts <= 0) return;
@@ -1176,7 +1261,8 @@ __device__ __forceinline__ bool pixel_ray(const RayCam& c, int pix, float o[3], 
         float v = d[k] / nd;
         if (v < 1e-5f && v > -1e-10f) v = 1e-5f;
         if (v > -1e-5f && v < 1e-10f) v = -1e-5f;
-        const float t0 = (c.bmin[k] - o[k]) / v, t1 = (c.bmax[k] - o[k]) / v;
+        const float lo = c.bdev ? c.bdev[k] : c.bmin[k], hi = c.bdev ? c.bdev[3 + k] : c.bmax[k];     // the box may still be on its way (N3's bounds kernel)
+        const float t0 = (lo - o[k]) / v, t1 = (hi - o[k]) / v;
         t_near = fmaxf(t_near, fminf(t0, t1));
         t_far = fminf(t_far, fmaxf(t0, t1));
     }

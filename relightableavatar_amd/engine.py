@@ -21,6 +21,28 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+class RaysPending:
+    """rays generated on the device whose count has not been read yet (Engine.gen_rays_async)"""
+
+    def __init__(self, bufs, host, mask_host, event, H, W, keep):
+        self._bufs, self._host, self._mask_host, self._event, self.H, self.W, self._keep = bufs, host, mask_host, event, H, W, keep
+
+    def ready(self):
+        return self._event.query()
+
+    def result(self):
+        """ray_o, ray_d (P,3), near, far (P,), mask_at_box (H,W) bool on the device; wbounds_host (1,2,3) and — if requested —
+        mask_host (H*W,) bool on the host.  Waits for the generating kernels only (an event), not for the stream."""
+        self._event.synchronize()
+        P = int(self._host[:1].view(torch.int32).item())
+        ro, rd, near, far, mask = self._bufs
+        out = dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(self.H, self.W).bool(),
+                      wbounds_host=self._host[1:7].clone().reshape(1, 2, 3))
+        if self._mask_host is not None:
+            out.mask_host = self._mask_host.bool()
+        return out
+
+
 class Engine:
     def __init__(self, cfg, device=None, relight=False):
         if not torch.cuda.is_available():
@@ -274,11 +296,22 @@ class Engine:
         K, R (3,3), T (3,) or (3,1): anything numpy can read; bounds (2,3).  Returns the reference's
         get_rays_within_bounds outputs as device tensors: ray_o, ray_d (P,3), near, far (P,), mask_at_box (H,W) bool.
         count: the number of in-box rays if the caller knows it (H * W for an unbounded box): skips the read-back and its synchronisation."""
+        bufs, cnt = self._gen_rays(H, W, K, R, T, bounds, host_count=count is None)
+        P = cnt if count is None else int(count)
+        ro, rd, near, far, mask = bufs
+        return dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(int(H), int(W)).bool())
+
+    def _gen_rays(self, H, W, K, R, T, bounds, host_count, count_dev=None):
         import numpy as np
         Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
         Rd = np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(9))
         Td = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(3))
-        bd = np.ascontiguousarray(np.asarray(bounds.detach().cpu() if isinstance(bounds, torch.Tensor) else bounds, dtype=np.float32).reshape(6))
+        on_dev = isinstance(bounds, torch.Tensor) and bounds.is_cuda
+        if on_dev:           # a box that is still being computed on the stream (pose_frame's wbounds): read on the device, no round trip
+            bdev = _f32(bounds.reshape(6), self.device)
+            bd = None
+        else:
+            bd = np.ascontiguousarray(np.asarray(bounds.detach().cpu() if isinstance(bounds, torch.Tensor) else bounds, dtype=np.float32).reshape(6))
         n = int(H) * int(W)
         d = self.device
         ro, rd = torch.empty(n, 3, device=d), torch.empty(n, 3, device=d)
@@ -286,15 +319,37 @@ class Engine:
         mask = torch.empty(n, device=d, dtype=torch.uint8)
         cnt = C.c_int(0)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-        check(self.lib.ra_gen_rays(self.ctx, int(H), int(W), dp(Kd), dp(Rd), dp(Td), bd.ctypes.data_as(C.POINTER(C.c_float)),
-                                   _ptr(ro), _ptr(rd), _ptr(near), _ptr(far), _ptr(mask), C.byref(cnt) if count is None else None, self.stream), 'ra_gen_rays')
-        P = cnt.value if count is None else int(count)
-        return dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(int(H), int(W)).bool())
+        check(self.lib.ra_gen_rays(self.ctx, int(H), int(W), dp(Kd), dp(Rd), dp(Td), None if bd is None else bd.ctypes.data_as(C.POINTER(C.c_float)),
+                                   _ptr(bdev) if on_dev else None, _ptr(ro), _ptr(rd), _ptr(near), _ptr(far), _ptr(mask),
+                                   C.byref(cnt) if host_count else None, None if count_dev is None else _ptr(count_dev), self.stream), 'ra_gen_rays')
+        return (ro, rd, near, far, mask), cnt.value
+
+    def gen_rays_async(self, H, W, K, R, T, bounds, mask_to_host=False):
+        """N2 for an animation loop: the rays of a frame whose box (`bounds`: a device tensor, e.g. pose_frame's wbounds) may still be on its
+        way.  Nothing waits: the ray buffers have the frame's capacity (H * W), the in-box count and the box travel to pinned host memory
+        behind an event, and `.result()` — called a pipeline turn later, when the kernels are long done — trims the buffers.  `mask_to_host`
+        also brings mask_at_box to the host (the shard plan of an N-rank job is host work: shard.make_plan)."""
+        n = int(H) * int(W)
+        d = self.device
+        count_dev = torch.empty(1, device=d, dtype=torch.int32)
+        bufs, _ = self._gen_rays(H, W, K, R, T, bounds, host_count=False, count_dev=count_dev)
+        bdev = _f32(bounds.reshape(6), d) if isinstance(bounds, torch.Tensor) else torch.as_tensor(bounds, dtype=torch.float32, device=d).reshape(6)
+        host = torch.empty(8, dtype=torch.float32, pin_memory=True)             # [count (int bits) | 6 box floats]
+        host[:1].view(torch.int32).copy_(count_dev, non_blocking=True)
+        host[1:7].copy_(bdev, non_blocking=True)
+        mask_host = None
+        if mask_to_host:
+            mask_host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            mask_host.copy_(bufs[4], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(d))
+        return RaysPending(bufs, host, mask_host, ev, int(H), int(W), (count_dev, bdev))
 
     def pose_frame(self, poses, tjoints, parents, tverts, weights, big_A, faces, Rh, Th, padding=0.05):
         """N3: per-frame body state on the device (base_dataset.py:308-397).  Small inputs (poses, tjoints (J,3), parents (J),
         big_A (J,4,4), Rh, Th, faces (F,3)) are read from host memory; tverts (N,3) and weights (N,J) are device tensors
-        (moved if needed).  Returns device tensors A (J,4,4), joints, tverts (T pose), pverts, wverts, pnorm, R, pbounds, wbounds."""
+        (moved if needed).  Returns device tensors A (J,4,4), joints, tverts (T pose), pverts, wverts, pnorm, R, pbounds, wbounds, and the
+        device copies of poses (J,3) / Th (3).  Asynchronous: nothing waits for the stream (the host inputs are staged in pinned memory)."""
         import numpy as np
         h32 = lambda a: np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
         hp, hj, hb, hr, ht = h32(poses).reshape(-1, 3), h32(tjoints).reshape(-1, 3), h32(big_A).reshape(-1, 16), h32(Rh).reshape(3), h32(Th).reshape(3)
@@ -307,13 +362,14 @@ class Engine:
         J, N = hp.shape[0], tv.shape[0]
         o = dotdict(A=torch.empty(J, 4, 4, device=d), joints=torch.empty(J, 3, device=d), tverts=torch.empty(N, 3, device=d),
                     pverts=torch.empty(N, 3, device=d), wverts=torch.empty(N, 3, device=d), pnorm=torch.empty(N, 3, device=d),
-                    R=torch.empty(3, 3, device=d), pbounds=torch.empty(2, 3, device=d), wbounds=torch.empty(2, 3, device=d))
+                    R=torch.empty(3, 3, device=d), pbounds=torch.empty(2, 3, device=d), wbounds=torch.empty(2, 3, device=d),
+                    poses=torch.empty(J, 3, device=d), Th=torch.empty(3, device=d))
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         pin = ra_pose_in(poses=fp(hp), tjoints=fp(hj), big_A=fp(hb), Rh=fp(hr), Th=fp(ht), parents=par.ctypes.data_as(C.POINTER(C.c_int)),
                          faces=fc.ctypes.data_as(C.POINTER(C.c_int)), n_bones=J, n_faces=fc.shape[0], n_verts=N, tverts=_ptr(tv), weights=_ptr(w),
                          bounds_padding=float(padding))
         pout = ra_pose_out(A=_ptr(o.A), joints=_ptr(o.joints), tpose=_ptr(o.tverts), pverts=_ptr(o.pverts), wverts=_ptr(o.wverts),
-                           pnorm=_ptr(o.pnorm), R=_ptr(o.R), pbounds=_ptr(o.pbounds), wbounds=_ptr(o.wbounds))
+                           pnorm=_ptr(o.pnorm), R=_ptr(o.R), pbounds=_ptr(o.pbounds), wbounds=_ptr(o.wbounds), poses=_ptr(o.poses), Th=_ptr(o.Th))
         check(self.lib.ra_pose_frame(self.ctx, C.byref(pin), C.byref(pout), self.stream), 'ra_pose_frame')
         return o
 

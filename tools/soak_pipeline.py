@@ -37,3 +37,52 @@ for mode, kw in (('relight', {}), ('relight', GROUND), ('novel_light', dict(GROU
         torch.cuda.synchronize()
     print(mode, sorted(kw.keys()), f'{2 * N} frames, differing from sequential rendering:', bad, flush=True)
     assert bad == 0
+
+# ---- an ANIMATED sequence through the device-side loader (N3 + N2, relightableavatar_amd/data_utils.py): every frame a different pose, its
+# rays generated a pipeline turn ahead, against the same frames posed, culled and rendered strictly one after the other
+import numpy as np
+from relightableavatar_amd.data_utils import DeviceFrameLoader
+cfg = make_cfg('relight')
+sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+sk = synthetic.make_skeleton(0)
+H = 256
+K, R, Tc = synthetic.make_camera(H, H)
+tv, w = torch.from_numpy(sk.tverts).to(dev), torch.from_numpy(sk.weights).to(dev)
+net = make_network(cfg); net.load_state_dict(sd); net = net.to(dev).eval()
+eng0 = net.engine()
+eye = np.tile(np.eye(4, dtype=np.float32), (52, 1, 1))
+big_A = eng0.pose_frame(sk.big_poses, sk.tjoints, sk.parents, tv, w, eye, sk.faces, np.zeros(3, np.float32), np.zeros(3, np.float32)).A.cpu().numpy()
+loader = DeviceFrameLoader(H, H, K, R, Tc, sk.tjoints, sk.parents, tv, w, big_A, sk.faces)
+ph = np.arange(sk.poses.size, dtype=np.float32).reshape(sk.poses.shape)
+NA = 12
+seq = [((sk.poses + 0.06 * np.sin(0.37 * f + ph)).astype(np.float32), sk.Rh, (sk.Th + np.float32(0.01 * np.sin(0.3 * f))).astype(np.float32)) for f in range(NA)]
+serial = make_renderer(cfg, net)
+want = []
+for q in seq:
+    out = serial.render(loader.batch(loader.issue(eng0, *q)))
+    torch.cuda.synchronize()
+    want.append({k: out[k].clone() for k in ('rgb_map', 'acc_map')})
+bad = 0
+for depth in (2, 3):
+    pipe = FramePipeline(cfg, sd, dev, depth=depth)
+    ahead = [None] * depth
+    fno = [0]
+
+    def frame(net_r, rend_r):
+        f = fno[0]
+        r = f % depth
+        eng = net_r.engine()
+        pend = ahead[r] or loader.issue(eng, *seq[f % NA])
+        out = rend_r.render(loader.batch(pend))
+        ahead[r] = loader.issue(eng, *seq[(f + depth) % NA])
+        fno[0] += 1
+        return out
+    pend = [pipe.submit(fn=frame) for _ in range(N)]
+    for k, p in enumerate(pend):
+        out = p.result()
+        for key in ('rgb_map', 'acc_map'):
+            if out[key].shape != want[k % NA][key].shape or not torch.equal(out[key], want[k % NA][key]):
+                bad += 1
+    torch.cuda.synchronize()
+print('animated relight (DeviceFrameLoader, poses / rays issued a turn ahead)', f'{2 * N} frames, differing from sequential rendering:', bad, flush=True)
+assert bad == 0
