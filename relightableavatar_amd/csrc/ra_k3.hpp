@@ -23,6 +23,7 @@
 //     5 VALU ops per element; the scale lives in the weights fed by the unscaled encoding and in the biases.
 //   reference: lib/networks/deform/base_network.py:34-42,78-87,374-382; lib/utils/net_utils.py:1263-1273,1337-1352
 #include "ra_stream.hpp"
+#include "ra_k3_pe.hpp"
 
 #ifdef RA_TIMESTAMPS
 // Instrumented variant (tools/build_variant.sh ... "-DRA_TIMESTAMPS", tools/k3_timestamps.py): wave 0 of every workgroup records
@@ -36,40 +37,6 @@ extern "C" int ra_k3_read_timestamps(long long* out) { return (int)hipMemcpyFrom
 #endif
 
 namespace {
-
-// encoding B fragments of one point (lane half h): see pe_chan_resd / pe_chan_sdf in ra_pack.cpp
-template <typename E, int L, bool LO>
-__device__ __forceinline__ void pe_frags(u32x4 (&Bp)[4], const float (&x)[3], int h) {
-    float rev[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rev[c] = x[c] * INV_2PI;
-    float v[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        if (q < 3 * L) {
-            const float a = rev[q % 3] * (float)(1 << (q / 3));
-            const float sv = __builtin_amdgcn_sinf(a), cv = __builtin_amdgcn_cosf(a);
-            v[q] = h ? cv : sv;
-        } else if (!LO) {
-            v[q] = (q == 3 * L) ? (h ? x[1] : x[0]) : ((q == 3 * L + 1) ? (h ? 0.f : x[2]) : 0.f);
-        } else {
-            const int r = q - 3 * L;
-            if (r < 3) {
-                const float hi = (float)(E)x[r];
-                v[q] = h ? x[r] - hi : hi;
-            } else if (r < 6) {
-                const float sv = __builtin_amdgcn_sinf(rev[r - 3]), cv = __builtin_amdgcn_cosf(rev[r - 3]);
-                v[q] = h ? cv - (float)(E)cv : sv - (float)(E)sv;
-            } else {
-                v[q] = 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) Bp[ks][w] = pack2<E>(v[8 * ks + 2 * w], v[8 * ks + 2 * w + 1]);
-}
 
 // one network: L0 (encoding) .. L7, then the <= 32-row head; returns the head accumulator (bias included)
 template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO, typename PipeT>
@@ -269,5 +236,8 @@ static void launch_k3(const GeoNet& net, const void* sarena, const void* sarena_
 #endif
     if (nw == 2) launch_nw<E, 2>(net, sarena_pairs, barena, fr, io, max_slots, stream);
     else if (nw == 4) launch_nw<E, 4>(net, sarena_pairs, barena, fr, io, max_slots, stream);
+#ifdef RA_K3_WIDE64
+    else if (Tr<E>::is_f16) launch_mlp_sdf_stream64_f16(net, sarena, barena, fr, io, max_slots, stream);
+#endif
     else launch_nw<E, 8>(net, sarena, barena, fr, io, max_slots, stream);
 }

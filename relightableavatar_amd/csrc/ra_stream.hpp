@@ -307,6 +307,100 @@ __device__ __forceinline__ void layer_pairs(PipeT& P, f32x16& a0, f32x16& a1, f3
     row_blocks<E, NW, 2, (6 * KS) % 16, KS, ACT, true, false, false>(P, b0, b1, a0, a1, Bm, Bp, Bo[8], Bo[9], Bo[10], Bo[11], bias + 192, h);
 }
 
+// ---- 64 points per wave: one A fragment feeds two MFMAs (EXPERIMENT, not in the product build: tools/build_w64.sh) -----------------
+// Round-3 verdict, item 2.  Result (round 4, MI355X, 5.12 M points, bit-identical distances): 8.44 ms against 8.29 ms for the two-wave
+// kernel (-1.7 %) in the best form — VGPR-form accumulators (-mllvm -amdgpu-mfma-vgpr-form=1), outputs pinned in AGPRs; the compiler's
+// default (accumulators in AGPRs, one v_accvgpr_read per element) -9 %.  The LDS operand reads, DMA pieces and barriers per point do
+// halve (ds_read 1.27 -> 0.63 per MFMA), but the B fragments of two column sets do not fit the 256 arch VGPRs beside the accumulators,
+// so every packed output costs a v_accvgpr_write (+0.54 VALU per MFMA): what the LDS saves the register file spends.
+// A wave owns TWO column sets of 32 points; every A fragment read from LDS is multiplied with both sets' B fragments, so the LDS operand
+// reads, the weight DMA and the stage barriers per POINT halve.  One wave per SIMD (the B fragments of two column sets are 256 registers):
+// the two column sets' MFMA chains are independent, which gives the lone wave the instruction-level parallelism a second wave would.
+// PINA: keep the packed outputs in AGPRs (v_accvgpr_write once, MFMA reads them as srcB from there): the arch VGPR file cannot hold
+// two ping-pong B sets for 64 points beside the accumulators.
+#ifndef RA_W64_PINA
+#define RA_W64_PINA 1
+#endif
+
+__device__ __forceinline__ unsigned pin_b(unsigned w) {
+#if RA_W64_PINA
+    asm volatile("" : "+a"(w));
+#endif
+    return w;
+}
+// the pending outputs go to dst[c][I0], dst[c][I0 + 1] (dst may BE Bm: the first row block of a layer completes its own inputs).
+// The epilogue is scheduled per K-STEP (two MFMAs, the elements of the two column sets alternating), as row_block does for one column set.
+// Spreading it per MFMA instead (VALU work between the two MFMAs of a k-step, as row_blocks does for its pairs) measured 5.8 % slower than
+// the two-wave kernel against 1.7 % for this form (tools/ab_w64.sh).
+template <typename E, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, int I0, typename PipeT, int KH = (KS == 4 ? 0 : 16), int ELAST = 13>
+__device__ __forceinline__ void row_block2(PipeT& P, f32x16 (&acc)[2], const f32x16 (&accPrev)[2], u32x4 (&Bm)[2][16], const u32x4 (&Bp)[2][4],
+                                           u32x4 (&dst)[2][16], const float* bias_rb, int h) {
+    init_acc(acc[0], bias_rb, h);
+    acc[1] = acc[0];
+    float ta[32];
+    constexpr int PF = PipeT::PF;
+    static_for<0, KS>([&](auto ks_) {
+        constexpr int ks = decltype(ks_)::value;
+        const X8<E> a = P.af[(FM0 + ks) % PF];
+        static_for<0, 2>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            const u32x4 bw = ks < KH ? Bm[c][ks & 15] : Bp[c][(ks - KH) & 3];
+            acc[c] = Tr<E>::mfma(a, __builtin_bit_cast(X8<E>, bw), acc[c]);
+        });
+        if constexpr (!(TAIL && ks + PF >= KS)) P.template fetch<(FM0 + ks + PF) % 16>();
+        if constexpr (PENDING) {
+            static_for<0, 32>([&](auto e_) {
+                constexpr int e2 = decltype(e_)::value;
+                constexpr int c = e2 & 1, e = e2 >> 1;          // the two column sets' elements alternate
+                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
+                constexpr int DEPTH = SP ? 3 : 0;
+                constexpr int LAST = (KS == 4) ? 3 : (EARLY ? ELAST : KS - 1);
+                constexpr int s0 = (KS == 4) ? 0 : (e * (LAST - DEPTH + 1)) / 16;
+                if constexpr (SP && KS != 4) {
+                    if constexpr (s0 == ks) ta[e2] = __builtin_amdgcn_exp2f(accPrev[c][e]);
+                    if constexpr (s0 + 1 == ks) ta[e2] = 1.f + ta[e2];
+                    if constexpr (s0 + 2 == ks) ta[e2] = __builtin_amdgcn_logf(ta[e2]);
+                    if constexpr (s0 + 3 == ks) ta[e2] = sp_finish(ta[e2], accPrev[c][e]);
+                } else if constexpr (SP) {
+                    if constexpr (ks == 0) ta[e2] = __builtin_amdgcn_exp2f(accPrev[c][e]);
+                    if constexpr (ks == 1) ta[e2] = 1.f + ta[e2];
+                    if constexpr (ks == 2) ta[e2] = __builtin_amdgcn_logf(ta[e2]);
+                    if constexpr (ks == 3) ta[e2] = sp_finish(ta[e2], accPrev[c][e]);
+                } else {
+                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e2] = Tr<E>::is_f16 ? accPrev[c][e] : max0(accPrev[c][e]);
+                }
+                constexpr int sdone = (KS == 4) ? (SP ? 3 : e / 4) : s0 + DEPTH;
+                if constexpr ((e & 1) && sdone == ks) {
+                    unsigned w = pack2<E>(ta[e2 - 2], ta[e2]);          // elements e - 1 and e of column set c
+                    if constexpr (!SP && Tr<E>::is_f16) {
+                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                        h2_t v = __builtin_bit_cast(h2_t, w);
+                        v = __builtin_elementwise_max(v, h2_t{(_Float16)0, (_Float16)0});
+                        w = __builtin_bit_cast(unsigned, v);
+                    }
+                    w = pin_b(w);
+                    if constexpr (e < 8) dst[c][I0][e >> 1] = w; else dst[c][I0 + 1][(e >> 1) & 3] = w;
+                }
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <typename E, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT, int NRB = 8, int KH = (KS == 4 ? 0 : 16), int PRB = 8>
+__device__ __forceinline__ void layer2(PipeT& P, f32x16 (&accA)[2], f32x16 (&accB)[2], u32x4 (&Bm)[2][16], const u32x4 (&Bp)[2][4], u32x4 (&Bo)[2][16],
+                                       const float* bias, int h) {
+    row_block2<E, 0, KS, ACT_IN, PEND_IN, true, false, 2 * PRB - 2, PipeT, KH, 2 * PRB - 3>(P, accA, accB, Bm, Bp, Bm, bias, h);
+    row_block2<E, (1 * KS) % 16, KS, ACT, true, false, false, 0, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 32, h);
+    row_block2<E, (2 * KS) % 16, KS, ACT, true, false, false, 2, PipeT, KH>(P, accA, accB, Bm, Bp, Bo, bias + 64, h);
+    row_block2<E, (3 * KS) % 16, KS, ACT, true, false, false, 4, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 96, h);
+    row_block2<E, (4 * KS) % 16, KS, ACT, true, false, false, 6, PipeT, KH>(P, accA, accB, Bm, Bp, Bo, bias + 128, h);
+    row_block2<E, (5 * KS) % 16, KS, ACT, true, false, false, 8, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 160, h);
+    row_block2<E, (6 * KS) % 16, KS, ACT, true, false, false, 10, PipeT, KH>(P, accA, accB, Bm, Bp, Bo, bias + 192, h);
+    if constexpr (NRB == 8)
+        row_block2<E, (7 * KS) % 16, KS, ACT, true, false, false, 12, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 224, h);
+}
+
 // ---- compensated row blocks (K3C, ra_k3c.hpp): near-fp32 products from f16 MFMAs ---------------------------------------------
 // Both operands are carried as hi + lo pairs of IEEE halves (x = hi + lo exactly to 22 bits; the lo parts of small values are f16
 // subnormals, which the matrix pipe multiplies exactly) and a k-step is three MFMAs into ONE fp32 accumulator:

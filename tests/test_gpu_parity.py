@@ -218,9 +218,9 @@ def test_bvh_equals_brute_force(relight):
 
 def test_bvh_equals_brute_force_on_other_mesh_sizes(relight):
     """the box structure on meshes that are not SMPL-sized: a handful of vertices (one super box, padded leaves), counts that are
-    not multiples of the 32-point leaf or the 8-leaf super box (missing leaves are inverted boxes), a mesh too large for the LDS
-    copy of the 16-way variant (9 500 vertices: it must fall back to the scalar-cache path), and one beyond the builder's limit
-    (16 384: brute force) — large and small launches, always the same neighbours and distances as the O(N) scan"""
+    not multiples of the 32-point leaf or the 8-leaf super box (missing leaves are inverted boxes), a larger mesh (9 500 vertices) and one
+    beyond the builder's limit (16 384: brute force) — large and small launches (one wave per 64 queries / the split-wave variants),
+    always the same neighbours and distances as the O(N) scan"""
     from relightableavatar_amd.base_utils import dotdict
     _, _, dev, body, eng = relight
     g = torch.Generator().manual_seed(11)
@@ -234,7 +234,7 @@ def test_bvh_equals_brute_force_on_other_mesh_sizes(relight):
                 v = body[k][0]
                 v = torch.cat([v + (0.003 * j if k in ('pverts', 'tverts') else 0.0) for j in range(rep)])[:n]      # copies shifted by 3 mm
                 b[k] = v[None].contiguous()
-            for q in (70000, 20000, 3000):          # one wave per 64 queries / 8 waves / 16 waves (LDS copy when the mesh fits)
+            for q in (70000, 20000, 3000):          # one wave per 64 queries / 8 waves / 16 waves per 64 queries
                 eng.set_knn_mode(True)
                 eng.set_frame(b, force=True)
                 a = eng.debug_hdq(x[:q].contiguous(), 0.125)
@@ -247,6 +247,32 @@ def test_bvh_equals_brute_force_on_other_mesh_sizes(relight):
     finally:
         eng.set_knn_mode(True)
         eng.set_frame(body, force=True)
+
+
+def test_hinted_search_equals_brute_force_in_whole_frames():
+    """advisor (round 3): the HINT variants of the coarse kernel (a tracing loop's queries start from the neighbours of the iteration before;
+    dedup insert; split-wave merge with hints) are claimed exact but no test compared them bit for bit — debug_hdq never hints.  The O(N)
+    scan (`set_knn_mode(False)`, kernel <false, 1>) is never hinted: a relit frame with the ground pass and a bare sphere trace must be
+    IDENTICAL in every map with the box structure + hints and with the brute-force scan."""
+    from relightableavatar_amd.renderer import make_renderer
+    kw = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0], vis_specular_map=True)
+    outs, traces = [], []
+    for bvh in (True, False):
+        cfg, net, dev = build('relight', **kw)
+        eng = net.engine()
+        eng.set_knn_mode(bvh)
+        batch = synthetic.to_device(synthetic.make_batch(96, 96, seed=0, posed=True), dev)
+        out = make_renderer(cfg, net).render(batch)
+        outs.append({k: out[k].clone() for k in ('rgb_map', 'acc_map', 'surf_map', 'norm_map', 'shade_map', 'spec_map', 'albedo_map', 'depth_map')})
+        b2 = synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True), dev)
+        eng.set_frame(b2, force=True)
+        p = eng.trace_params(cfg.sphere_tracing, cfg.dist_th, False)
+        traces.append(eng.sphere_trace(b2.ray_o[0], b2.ray_d[0], b2.near[0], b2.far[0], p))      # ra_sphere_trace: hinted from its second iteration on
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num())     # depth = (surf_x - o_x) / d_x is NaN where d_x = 0 (quirk 4)
+    for k in outs[0]:
+        assert same(outs[0][k], outs[1][k]), k
+    for a, b in zip(traces[0], traces[1]):
+        assert same(a, b)
 
 
 def test_hdq_sdf(ops, relight):

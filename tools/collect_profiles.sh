@@ -9,7 +9,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
-RN=${RA_ROUND:-r03}
+RN=${RA_ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${RN}_bench.json 2> $OUT/bench.err
@@ -18,7 +18,13 @@ python3 $R/bench.py --mode sphere_tracing --steps 20 --warmup 3 --no-cpu-baselin
 python3 $R/bench.py --mode anisdf --steps 10 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
 python3 $R/bench.py --ground --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
 python3 $R/bench.py --mode novel_light --size 1024 --probes 8 --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/${RN}_bench_other_shapes.jsonl 2>> $OUT/bench.err
-python3 $R/bench.py --skin-noise 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_skin_noise0.json 2>> $OUT/bench.err        # the body the contract is asserted on, with its PSNR
+python3 $R/bench.py --skin-noise 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_skin_noise0.json 2>> $OUT/bench.err        # the smooth body, with its PSNR
+python3 $R/bench.py --coverage 0.35 --steps 10 --warmup 2 > $OUT/${RN}_bench_coverage35.json 2>> $OUT/bench.err          # a frame-filling subject (camera at 0.96 m), with its PSNR
+python3 $R/bench.py --trace-precision 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_trace_precision0.json 2>> $OUT/bench.err  # round 3's arithmetic (plain f16 surface trace): what the compensated tier costs and buys
+: > $OUT/${RN}_bench_animate.jsonl
+python3 $R/bench.py --animate --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_bench_animate.jsonl 2>> $OUT/bench.err   # N3 + N2 inside the timed region
+python3 $R/bench.py --animate --frames-in-flight 1 --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_bench_animate.jsonl 2>> $OUT/bench.err
+python3 $R/bench.py --animate --mode sphere_tracing --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_bench_animate.jsonl 2>> $OUT/bench.err
 # sequential frames (one in flight) next to the default two: the whole frame and one rank's share of 2 / 4 / 8
 : > $OUT/${RN}_frames_in_flight.jsonl
 for d in 1 2 3 4; do python3 $R/bench.py --frames-in-flight $d --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_frames_in_flight.jsonl 2>> $OUT/bench.err; done
@@ -54,8 +60,8 @@ done
 python3 - <<'P'
 import csv, glob, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof'
-rn = os.environ.get('RA_ROUND', 'r03')
-fams = (('mlp_sdf_stream_kernelIDF16_Li8E', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream_kernel<_Float16, 8>', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
+rn = os.environ.get('RA_ROUND', 'r04')
+fams = (('mlp_sdf_comp', 'mlp_sdf_comp_kernel'), ('mlp_sdf_stream_kernelIDF16_Li8E', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream_kernel<_Float16, 8>', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
         ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'))
 for pat, name in (('/pmc[0-9]*/', 'relight512'), ('/pmcv[0-9]*/', 'anisdf512')):      # one summary per workload
     agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
