@@ -469,7 +469,9 @@ def main():
     # the dominant kernel: the full query on the volume path, else the 8-wave distance query (the launches that fill the chip; kind 2) —
     # a frame without such launches (sphere tracing at 512 x 512, a small rank share) reports all distance-query launches (kind 0)
     wide = args.mode != 'anisdf' and cnt.get('n_fine_sdf_wide', 0) > 0
-    kind = 1 if args.mode == 'anisdf' else (2 if wide else 0)
+    # ... and a sphere-tracing frame whose distance queries all ran in the compensated tier reports that kernel (kind 4)
+    comp_only = args.mode != 'anisdf' and not wide and cnt.get('n_fine_sdf_comp', 0) > 0 and cnt.get('n_fine_sdf_comp', 0) >= 0.9 * cnt.get('n_fine_sdf', 0)
+    kind = 1 if args.mode == 'anisdf' else (2 if wide else (4 if comp_only else 0))
     mlp_ms, mlp_launches = 0.0, 0
     for e in engs:
         ms_e, n_e = e.kernel_time(kind)
@@ -485,8 +487,8 @@ def main():
         dist.all_gather(per_rank, mine)
     if rank == 0:
         ms = dt / args.steps * 1e3
-        kname = 'mlp_sdf_stream_kernel<f16|bf16, 8>' if wide else 'mlp_sdf_stream_kernel'
-        units, f_unit = (cnt.n_fine_sdf_wide if wide else cnt.n_fine_sdf), F_SDF
+        kname = 'mlp_sdf_stream_kernel<f16|bf16, 8>' if wide else ('mlp_sdf_comp_kernel (compensated: 3 MFMAs per algorithmic one)' if comp_only else 'mlp_sdf_stream_kernel')
+        units, f_unit = (cnt.n_fine_sdf_wide if wide else (cnt.n_fine_sdf_comp if comp_only else cnt.n_fine_sdf)), F_SDF
         if args.mode == 'anisdf':           # the volume path has no distance-only queries: its dominant kernel is the full query
             # the full query = two kernels per launch (forward with tape, reverse-mode backward + colour net); the timer brackets both
             kname, units, f_unit = 'mlp_fwd_tape_kernel+mlp_bwd_heads_kernel', cnt.n_fine_full, F_FULL_ANISDF

@@ -308,6 +308,8 @@ def sample_rays(batch: dotdict, n_target: int):
     ray gets the pixel it has in the whole frame up to the per-chunk box growth of the shadow rays).  Returns (batch, P, stride)."""
     P = batch.ray_o.shape[1]
     stride = max(1, P // max(1, n_target))
+    if stride % 2 == 0:
+        stride += 1          # an even stride can divide the image width: every sample would then sit in the same pixel column
     for k in ('ray_o', 'ray_d', 'near', 'far'):
         batch[k] = batch[k][:, ::stride].contiguous()
     return batch, P, stride
