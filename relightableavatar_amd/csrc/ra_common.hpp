@@ -123,8 +123,9 @@ void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const voi
 void launch_mlp_sdf_stream64_f16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
 
 // K3C (ra_k3c.hpp): the same query in compensated arithmetic (f16 hi + lo operand pairs, three MFMAs per k-step) on the split stream
-// sarena_c; one wave per SIMD: 2 waves (64-point tiles) for launches of at most 16 Ki points, else 4 (128-point tiles)
-inline int k3c_waves(int max_slots) { return max_slots <= 256 * 64 ? 2 : 4; }
+// sarena_c, 16 points per wave: 2 waves per workgroup (32-point tiles) for launches of at most 8 Ki points, 4 (64-point tiles) up to
+// 16 Ki — one wave per SIMD, a launch spreads over as many CUs as it has tiles — else 8 (128-point tiles, two waves per SIMD)
+inline int k3c_waves(int max_slots) { return max_slots <= 256 * 32 ? 2 : (max_slots <= 256 * 64 ? 4 : 8); }
 void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
 
 // K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list

@@ -8,20 +8,22 @@
 // shadow queries stay on plain f16 (K3).  Arithmetic: ra_stream.hpp row_block_c — operands as f16 hi + lo pairs, three MFMAs per
 // k-step, fp32 accumulate: 1.3e-7 rms from a float64 evaluation, the same as fp32 arithmetic itself (1.2e-7).
 //
-//   * weights: the `split` stream (ra_pack.cpp): every A fragment twice, [hi | lo]: 3904 fragments (4 MB) per tile;
+//   * tile shape v_mfma_f32_16x16x32_f16: 16 points per wave, 16 row blocks of 16 rows per layer, k-steps of 32 (ra_stream.hpp row_block_16);
+//   * weights: the split stream (ra_pack.cpp add16): every A fragment twice, [hi | lo]: 3872 fragments (4 MB) per tile;
 //   * activations: fp32 in the accumulators, bias / activation in fp32, then hi = f16(a), lo = f16(a - hi) — two B fragment sets;
 //   * encoding: the argument of every sin / cos is reduced in two-constant arithmetic (x 2^k is exact; k = rint(a c_hi),
 //     t = fma(a, c_hi, -k) + a c_lo) before v_sin / v_cos — the plain kernel's a * (1 / 2 pi) loses 1.5e-5 rad at 2^9 x, invisible
 //     behind an f16 rounding, not here;
-//   * one wave per SIMD (4 or 2 waves per workgroup, 128 / 64 points per tile): the two B sets are 256 registers.
+//   * 8 waves per workgroup (two per SIMD, 128 points per tile) on launches above 16 Ki points, 4 or 2 (one per SIMD, 64 / 32 points) below:
+//     the smaller the launch, the more SIMDs share it.
 //   reference: lib/networks/deform/base_network.py:34-42,78-87,374-382; lib/utils/net_utils.py:1263-1273,1337-1352;
 //   lib/networks/embedder.py:26-37; hit test and sign-change interpolation that consume the result: sphere_tracing_renderer.py:176-197
 #include "ra_stream.hpp"
 
 namespace {
 
-constexpr int STC_FRAGS = 2 * ST_FRAGS;          // 3904
-constexpr int STC_STAGES = STC_FRAGS / 16;       // 244
+constexpr int STC_FRAGS = 3872;                  // per net: 64 + 3 x 256 + 320 + 3 x 256 + 16 (a 16-row head), x 2 nets
+constexpr int STC_STAGES = STC_FRAGS / 16;       // 242
 constexpr float INV_2PI_HI = 0.15915494f;        // fp32(1 / 2 pi)
 constexpr float INV_2PI_LO = 3.0934362e-09f;     // 1 / 2 pi - INV_2PI_HI (cancels the rounding of the first constant)
 
@@ -34,10 +36,12 @@ __device__ __forceinline__ void sincos_rev(float a, float& sv, float& cv) {
     cv = __builtin_amdgcn_cosf(t);
 }
 
-// encoding B fragments (hi and lo) of one point, lane half h; slot -> channel as pe_chan_resd / pe_chan_sdf (ra_pack.cpp).
-// SDFNET: the slots the plain kernel uses for its own hi + lo columns (q >= 24, lane half 1 / q >= 27) carry zeros here.
+// encoding B fragments (hi and lo, two k-steps of 32) of one point for lane group g: slot (g, j) of k-step p is slot q = 8 (2 p + (g >> 1)) + j
+// of lane half h = g & 1 of the 32x32 layout, whose slot -> channel map is pe_chan_resd / pe_chan_sdf (ra_pack.cpp).
+// SDFNET: the slots the plain kernel uses for its own hi + lo columns (q >= 24 with h = 1, q >= 27) carry zeros here.
 template <int L, bool SDFNET>
-__device__ __forceinline__ void pe_frags_c(u32x4 (&BpH)[4], u32x4 (&BpL)[4], const float (&x)[3], int h) {
+__device__ __forceinline__ void pe_frags_16(u32x4 (&BpH)[2], u32x4 (&BpL)[2], const float (&x)[3], int g) {
+    const int h = g & 1, up = g >> 1;
     float v[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
@@ -53,42 +57,43 @@ __device__ __forceinline__ void pe_frags_c(u32x4 (&BpH)[4], u32x4 (&BpL)[4], con
         }
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float a = v[8 * ks + 2 * w], b = v[8 * ks + 2 * w + 1];
+            const int q0 = 8 * (2 * p) + 2 * w, q1 = 8 * (2 * p + 1) + 2 * w;
+            const float a = up ? v[q1] : v[q0], b = up ? v[q1 + 1] : v[q0 + 1];
             f16x2 hv;
             hv[0] = (f16)a; hv[1] = (f16)b;
-            BpH[ks][w] = __builtin_bit_cast(unsigned, hv);
-            BpL[ks][w] = pack2<f16>(a - (float)hv[0], b - (float)hv[1]);
+            BpH[p][w] = __builtin_bit_cast(unsigned, hv);
+            BpL[p][w] = pack2<f16>(a - (float)hv[0], b - (float)hv[1]);
         }
 }
 
-// one network: L0 (encoding) .. L7, then the head row block; returns the head accumulator (bias included)
-template <int NW, bool LAST, int ACT, int PEL, bool SDFNET, typename PipeT>
-__device__ __forceinline__ f32x16 run_net_c(PipeT& P, const float (&x)[3], const float* bias, int h) {
-    u32x4 B0h[16], B0l[16], B1h[16], B1l[16], Bph[4], Bpl[4];
-    f32x16 accA, accB;
-    pe_frags_c<PEL, SDFNET>(Bph, Bpl, x, h);
-    layer_c<NW, 4, ACT, ACT, false>(P, accA, accB, B0h, B0l /* unused */, Bph, Bpl, B0h, B0l, bias, h);
-    layer_c<NW, 16, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 256, h);
-    layer_c<NW, 16, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 512, h);
-    layer_c<NW, 16, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 768, h);
-    layer_c<NW, 20, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 1024, h);
-    layer_c<NW, 16, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 1280, h);
-    layer_c<NW, 16, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 1536, h);
-    layer_c<NW, 16, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 1792, h);
-    row_block_c<NW, 0, 16, ACT, true, true, LAST, PipeT>(P, accA, accB, B1h, B1l, Bph, Bpl, B1h[14], B1h[15], B1l[14], B1l[15], bias + 2048, h);
+// one network: L0 (encoding) .. L7, then the 16-row head; returns the head accumulator (bias included): rows 4 g + i of lane group g
+template <bool LAST, int ACT, int PEL, bool SDFNET, typename PipeT>
+__device__ __forceinline__ f32x4 run_net_16(PipeT& P, const float (&x)[3], const float* bias, int g) {
+    u32x4 B0h[8], B0l[8], B1h[8], B1l[8], Bph[2], Bpl[2];
+    f32x4 accA, accB;
+    pe_frags_16<PEL, SDFNET>(Bph, Bpl, x, g);
+    layer_16<2, ACT, ACT, false>(P, accA, accB, B0h, B0l /* unused */, Bph, Bpl, B0h, B0l, bias, g);
+    layer_16<8, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 256, g);
+    layer_16<8, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 512, g);
+    layer_16<8, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 768, g);
+    layer_16<10, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 1024, g);
+    layer_16<8, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 1280, g);
+    layer_16<8, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 1536, g);
+    layer_16<8, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 1792, g);
+    row_block_16<0, 8, ACT, true, true, LAST, 7, 1, PipeT>(P, accA, accB, B1h, B1l, Bph, Bpl, B1h, B1l, bias + 2048, g);
     return accA;
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void mlp_sdf_comp_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba, FrameState fr, MlpIO io) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_comp_kernel(GeoNet net, const void* __restrict__ stream, const float* __restrict__ ba, FrameState fr, MlpIO io) {
     typedef f16 E;
     __shared__ __attribute__((aligned(16))) StSmem<E> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, c = lane & 31;
-    constexpr int ST_TM = 32 * NW;     // points per workgroup tile
+    const int g = lane >> 4, c = lane & 15;
+    constexpr int ST_TM = 16 * NW;     // points per workgroup tile
     // bias table as in K3: resd rows (L0 / L4 carry the per-frame pose condition), resd head, scaled sdf rows, sdf head
     for (int i = tid; i < BIAS_ROWS * 256; i += 64 * NW) {
         const int row = i >> 8, r = i & 255;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_sdf_comp_kernel(GeoNet net, co
     for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int s = tile * ST_TM + wave * 32 + c;
+        const int s = tile * ST_TM + wave * 16 + c;           // the four lane groups of a column hold the same point
         float x[3] = {0.f, 0.f, 0.f};
         int pidx = 0;
         float smpl = 0.f;
@@ -133,16 +138,16 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_sdf_comp_kernel(GeoNet net, co
         }
         static_for<0, 8>([&](auto f_) { P.template fetch<decltype(f_)::value>(); });      // the tile's first PF fragments
         // ---- residual deformation net (ReLU); head: resd = tanh(z) * resd_limit, cpts = bpts + resd
-        const f32x16 hr = run_net_c<NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h);
+        const f32x4 hr = run_net_16<false, ACT_RELU, 10, false>(P, x, sm.bias, g);
         float cp[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float r = tanhf(hr[k]) * io.resd_limit;           // valid in lanes h = 0 (rows 0..2)
+            const float r = tanhf(hr[k]) * io.resd_limit;           // valid in lane group 0 (rows 0..2)
             cp[k] = x[k] + __shfl(r, c);
         }
         // ---- signed distance net (softplus, scaled domain); head row 0 = sdf
-        const f32x16 hs = run_net_c<NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h);
-        if (h == 0 && s < count) {
+        const f32x4 hs = run_net_16<true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, g);
+        if (g == 0 && s < count) {
             float d = hs[0] * SP_INV;                                 // head accumulates beta*log2(e) * sdf
             if (io.smooth) {                                          // HDQ blend (base_network.py:374-382)
                 const float r = fminf(fmaxf(fabsf(d) / io.dist_th, 0.f), 1.f);
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_sdf_comp_kernel(GeoNet net, co
 
 template <int NW>
 void launch_c_nw(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
-    const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
+    const int tiles = (max_slots + 16 * NW - 1) / (16 * NW);
     const int grid = tiles < 256 ? tiles : 256;     // one workgroup per CU (the weight ring fills its LDS), persistent over tiles
     hipLaunchKernelGGL((mlp_sdf_comp_kernel<NW>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena_c, barena, fr, io);
 }

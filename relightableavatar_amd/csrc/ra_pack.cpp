@@ -88,6 +88,40 @@ struct StreamBuilder {
                 }
             }
     }
+    // ---- fragments for v_mfma_f32_16x16x32 (K3C, ra_k3c.hpp): a row block is 16 output rows, a k-step 32 inputs.
+    // lane = (row m = lane & 15, k group kg = lane >> 4), slot j < 8.  Hidden k-step ks: the D fragments of row blocks 2 ks and 2 ks + 1 of
+    // the previous layer (lane group g holds rows 16 rb + 4 g + i) packed side by side ARE this B fragment, so
+    //     slot (kg, j)  <->  feature 32 ks + 16 (j >> 2) + 4 kg + (j & 3);
+    // encoding k-step p (0 | 1): slot (kg, j) is slot q = 8 (2 p + (kg >> 1)) + j of lane half h = kg & 1 of the 32x32 layout (pe_chan_*).
+    static int hidden_feature16(int ks, int kg, int j) { return 32 * ks + 16 * (j >> 2) + 4 * kg + (j & 3); }
+    template <typename ChanFn>
+    void frag16(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale, int part) {      // ks < 8: hidden, else encoding k-step ks - 8
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int row = rb * 16 + (lane & 15), kg = lane >> 4;
+                float v = 0.f;
+                if (ks < 8) {
+                    const int col = hidden_feature16(ks, kg, j);
+                    if (row < Mh->rows && col < Mh->cols) v = Mh->at(row, col);
+                } else {
+                    const int col = chan(8 * (2 * (ks - 8) + (kg >> 1)) + j, kg & 1);
+                    if (row < Mp->rows && col >= 0 && col < Mp->cols) v = Mp->at(row, col) * pe_scale;
+                }
+                const uint16_t hi = cv(v);
+                if (part != 2) { w.push_back(hi); continue; }
+                _Float16 hf;
+                std::memcpy(&hf, &hi, 2);
+                w.push_back(cv(v - (float)hf));
+            }
+    }
+    template <typename ChanFn>
+    void add16(const Mat* Mh, const Mat* Mp, ChanFn chan, int rows_pad, float pe_scale) {       // always [hi | lo] pairs
+        for (int rb = 0; rb < rows_pad / 16; ++rb)
+            for (int ks = Mh ? 0 : 8; ks < (Mp ? 10 : 8); ++ks) {
+                frag16(Mh, Mp, chan, rb, ks, pe_scale, 1);
+                frag16(Mh, Mp, chan, rb, ks, pe_scale, 2);
+            }
+    }
     template <typename ChanFn>
     // hks: hidden k-steps emitted (16 = all 256 inputs; the trimmed stream drops the k-steps of inputs that do not exist)
     void add(const Mat* Mh, const Mat* Mp, ChanFn chan, int rows_pad, float pe_scale, int hks = 16) {
@@ -367,16 +401,16 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         for (int l = 0; l < 8; ++l) Sp.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
         Sp.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
         H.sarena_pairs = Sp.w;
-        // K3C: the (untrimmed) stream with every fragment as an IEEE-half [hi | lo] pair, whatever the operand type of the plain kernels.
-        // The SDF net's own hi + lo input columns (with_lo) are fed zeros by K3C: its whole encoding is split.
+        // K3C: every fragment as an IEEE-half [hi | lo] pair, whatever the operand type of the plain kernels, in the 16x16x32 layout
+        // (16 row blocks of 16 rows per layer, 8 hidden + 2 encoding k-steps of 32).  The SDF net's own hi + lo input columns (with_lo)
+        // are fed zeros by K3C: its whole encoding is split.
         StreamBuilder Sc;
         Sc.half = true;
-        Sc.split = true;
-        for (int i = 0; i < 8; ++i) Sc.add(i == 0 ? nullptr : &Rm[i], i == 0 ? &Rm[0] : (i == 4 ? &Rpe4 : nullptr), pe_chan_resd, 256, 1.f);
-        Sc.add(&Rhead, nullptr, pe_chan_resd, 32, 1.f);
-        for (int l = 0; l < 8; ++l) Sc.add(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
-        Sc.add(&Shead, nullptr, pe_chan_sdf, 32, 1.f);
-        if (Sc.w.size() != (size_t)3904 * 512) { err = "internal: split weight stream has " + std::to_string(Sc.w.size() / 512) + " fragments, expected 3904"; return 1; }
+        for (int i = 0; i < 8; ++i) Sc.add16(i == 0 ? nullptr : &Rm[i], i == 0 ? &Rm[0] : (i == 4 ? &Rpe4 : nullptr), pe_chan_resd, 256, 1.f);
+        Sc.add16(&Rhead, nullptr, pe_chan_resd, 16, 1.f);
+        for (int l = 0; l < 8; ++l) Sc.add16(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
+        Sc.add16(&Shead, nullptr, pe_chan_sdf, 16, 1.f);
+        if (Sc.w.size() != (size_t)3872 * 512) { err = "internal: split weight stream has " + std::to_string(Sc.w.size() / 512) + " fragments, expected 3872"; return 1; }
         H.sarena_c = Sc.w;
     }
     {   // K4 (reverse mode) streams, same fragment order / K permutation as the K3 stream.

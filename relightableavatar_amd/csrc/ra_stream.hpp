@@ -103,6 +103,7 @@ template <typename E, int NW, int STAGES = ST_STAGES, int PF_ = ST_PF>
 struct Pipe {
     static constexpr int FPW = 16 / NW;
     static constexpr int PF = PF_;
+    static constexpr bool LONE = NW < 8;      // one wave per SIMD
     const char* g;          // weight stream (uniform)
     unsigned voff;          // per lane: wave * FPW * 1024 + lane * 16
     const char* ring;       // LDS ring (generic pointer), + lane * 16
@@ -401,54 +402,59 @@ __device__ __forceinline__ void layer2(PipeT& P, f32x16 (&accA)[2], f32x16 (&acc
         row_block2<E, (7 * KS) % 16, KS, ACT, true, false, false, 12, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 224, h);
 }
 
-// ---- compensated row blocks (K3C, ra_k3c.hpp): near-fp32 products from f16 MFMAs ---------------------------------------------
+// ---- compensated row blocks (K3C, ra_k3c.hpp): near-fp32 products from f16 MFMAs -----------------------------------------------
 // Both operands are carried as hi + lo pairs of IEEE halves (x = hi + lo exactly to 22 bits; the lo parts of small values are f16
 // subnormals, which the matrix pipe multiplies exactly) and a k-step is three MFMAs into ONE fp32 accumulator:
 //     acc += Ah Bl;  acc += Al Bh;  acc += Ah Bh                       (Al Bl, 2^-22 of the product, is dropped)
-// The weight stream holds every fragment twice, [hi | lo] per k-step (ra_pack.cpp StreamBuilder::split), so a 16-fragment stage is
-// 8 k-steps; the pending epilogue of the previous row block (activation in fp32, then hi = f16(a), lo = f16(a - hi)) is spread
-// over the 3 KS MFMA slots.  Everything else — K permutation, D fragment == next B fragment, LDS-DMA ring — is ra_stream.hpp's.
-// One wave per SIMD (the B fragments alone are 256 registers): K3C serves the surface trace, whose launches never fill the chip.
-// ONE accumulator chain per row block: keeping the two small products in an accumulator of their own (independent MFMA neighbours, the
-// small terms never see the main sum's rounding) measured 165 against 150 us per 128-point tile — the extra AGPR reads and adds of the
-// fold cost more than the shorter chain gains, and the accuracy is fp32's either way.
+// The weight stream holds every fragment twice, [hi | lo] per k-step (ra_pack.cpp StreamBuilder::add16); the pending epilogue of the
+// previous row block (activation in fp32, then hi = f16(a), lo = f16(a - hi)) is spread over the 3 KS MFMA slots.
+//
+// Tile shape: v_mfma_f32_16x16x32_f16 — a wave owns 16 points, a row block is 16 output rows (16 per layer), a k-step 32 inputs (8 per
+// hidden layer).  K3C serves the surface trace, whose launches never fill the chip: with 16 points per wave a wave's chain of dependent
+// MFMAs is half as long as with the 32x32x16 tile of the plain kernel (16 against 32 cycles each, the same count), the two B fragment
+// sets (hi, lo; in, out) are 128 registers instead of 256, so two waves share a SIMD, and a small launch spreads over twice as many SIMDs.
+// (The first K3C used the 32x32x16 tile, one wave per SIMD: 150 us per 128-point tile)
+// D fragment: lane (point n = lane & 15, row group g = lane >> 4) holds rows 16 rb + 4 g + i; the packed D fragments of row blocks 2 m and
+// 2 m + 1 side by side are the next layer's B fragment of k-step m (ra_pack.cpp hidden_feature16).
+// One accumulator chain: a second chain for the two small products measured slower on the 32x32 tile (extra AGPR traffic, same accuracy).
 #ifndef RA_K3C_E0
 #define RA_K3C_E0 2          // MFMA slots before the pending epilogue first touches the previous accumulator (its last MFMA is still in the pipe)
 #endif
+__device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-template <int NW, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, typename PipeT, int KH = (KS == 4 ? 0 : 16), int ELAST = 41>
-__device__ __forceinline__ void row_block_c(PipeT& P, f32x16& acc, const f32x16& accPrev, u32x4 (&BmH)[16], u32x4 (&BmL)[16], const u32x4 (&BpH)[4],
-                                            const u32x4 (&BpL)[4], u32x4& o0h, u32x4& o1h, u32x4& o0l, u32x4& o1l, const float* bias_rb, int h) {
+// One row block: 3 KS MFMAs (fragments FM0.. of the stage, [hi | lo] per k-step) into `acc`, interleaved with the pending epilogue of
+// `accPrev` (activation ACT_PREV), whose four values per lane go to registers 2 DH, 2 DH + 1 of fragment DI of dstH / dstL.
+// KH hidden k-steps (from BmH / BmL), then KS - KH encoding k-steps (BpH / BpL).  ELAST: with EARLY, the last slot that may still write.
+template <int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, int DI, int DH, typename PipeT, int KH = (KS == 2 ? 0 : 8), int ELAST = 20>
+__device__ __forceinline__ void row_block_16(PipeT& P, f32x4& acc, const f32x4& accPrev, u32x4 (&BmH)[8], u32x4 (&BmL)[8], const u32x4 (&BpH)[2],
+                                             const u32x4 (&BpL)[2], u32x4 (&dstH)[8], u32x4 (&dstL)[8], const float* bias_rb, int g) {
     typedef f16 E;
-    // (the four bias reads are consumed at once, so every row block starts with an `s_waitcnt lgkmcnt(0)` that also drains the eight
-    // A fragments read ahead: without the bias — a timing experiment — a 128-point tile takes 143 instead of 150 us; a third accumulator
-    // per wave to load the next block's bias early was not built for 5 %)
-    init_acc(acc, bias_rb, h);
-    float ta[16];
+    acc = *reinterpret_cast<const f32x4*>(bias_rb + 4 * g);          // rows 16 rb + 4 g + i start at their bias
+    float ta[4];
     constexpr int NS = 3 * KS, PF = PipeT::PF, PFK = PF / 2;       // PF fragments = PFK k-steps read ahead
     static_for<0, NS>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
         constexpr int ks = i / 3, m = i % 3;
-        const u32x4 bh = ks < KH ? BmH[ks & 15] : BpH[(ks - KH) & 3];
-        const u32x4 bl = ks < KH ? BmL[ks & 15] : BpL[(ks - KH) & 3];
+        const u32x4 bh = ks < KH ? BmH[ks & 7] : BpH[(ks - KH) & 1];
+        const u32x4 bl = ks < KH ? BmL[ks & 7] : BpL[(ks - KH) & 1];
         constexpr int fh = (FM0 + 2 * ks) % PF, fl = (FM0 + 2 * ks + 1) % PF;
-        if constexpr (m == 0) acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bl), acc);
-        if constexpr (m == 1) acc = Tr<E>::mfma(P.af[fl], __builtin_bit_cast(X8<E>, bh), acc);
-        if constexpr (m == 2) acc = Tr<E>::mfma(P.af[fh], __builtin_bit_cast(X8<E>, bh), acc);
+        if constexpr (m == 0) acc = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc);
+        if constexpr (m == 1) acc = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc);
         if constexpr (m == 2) {
+            acc = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc);
             if constexpr (!(TAIL && ks + PFK >= KS)) {
                 P.template fetch<(FM0 + 2 * (ks + PFK)) % 16>();            // hi first: position 0 of a stage turns the ring
                 P.template fetch<(FM0 + 2 * (ks + PFK) + 1) % 16>();
             }
         }
         if constexpr (PENDING) {
-            static_for<0, 16>([&](auto e_) {
+            static_for<0, 4>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
                 constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
                 constexpr int DA = SP ? 3 : 0;                       // slots until the activation's value exists
                 constexpr int LAST = EARLY ? ELAST : NS - 1;         // last slot that may still write the outputs
                 constexpr int E0 = NS >= 24 ? RA_K3C_E0 : 0;
-                constexpr int s0 = E0 + (e * (LAST - E0 - (DA + 2) + 1)) / 16;
+                constexpr int s0 = E0 + (e * (LAST - E0 - (DA + 2) + 1)) / 4;
                 if constexpr (SP) {
                     if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
                     if constexpr (s0 + 1 == i) ta[e] = 1.f + ta[e];
@@ -460,35 +466,29 @@ __device__ __forceinline__ void row_block_c(PipeT& P, f32x16& acc, const f32x16&
                 if constexpr ((e & 1) && s0 + DA + 1 == i) {          // hi halves of the pair (e - 1, e); ta keeps the residuals
                     f16x2 hv;
                     hv[0] = (f16)ta[e - 1]; hv[1] = (f16)ta[e];
-                    const unsigned w = __builtin_bit_cast(unsigned, hv);
-                    if constexpr (e < 8) o0h[e >> 1] = w; else o1h[(e >> 1) & 3] = w;
+                    dstH[DI][2 * DH + (e >> 1)] = __builtin_bit_cast(unsigned, hv);
                     ta[e - 1] -= (float)hv[0];
                     ta[e] -= (float)hv[1];
                 }
-                if constexpr ((e & 1) && s0 + DA + 2 == i) {
-                    const unsigned w = pack2<E>(ta[e - 1], ta[e]);
-                    if constexpr (e < 8) o0l[e >> 1] = w; else o1l[(e >> 1) & 3] = w;
-                }
+                if constexpr ((e & 1) && s0 + DA + 2 == i) dstL[DI][2 * DH + (e >> 1)] = pack2<E>(ta[e - 1], ta[e]);
             });
         }
-        __builtin_amdgcn_sched_barrier(0);        // a lone wave per SIMD: keep the reads PF fragments ahead (see row_blocks)
+        if (PipeT::LONE) __builtin_amdgcn_sched_barrier(0);        // a lone wave per SIMD: keep the reads PF fragments ahead (see row_blocks)
     });
 }
 
-// a 256-row layer of compensated row blocks; on entry accB holds the pending last row block of the previous layer (if PEND_IN:
-// destination Bm[14], Bm[15]), on exit this layer's last row block is pending in accB
-template <int NW, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
-__device__ __forceinline__ void layer_c(PipeT& P, f32x16& accA, f32x16& accB, u32x4 (&BmH)[16], u32x4 (&BmL)[16], const u32x4 (&BpH)[4], const u32x4 (&BpL)[4],
-                                        u32x4 (&BoH)[16], u32x4 (&BoL)[16], const float* bias, int h) {
-    constexpr int KH = KS == 4 ? 0 : 16, F = 2 * KS;     // fragments per row block
-    row_block_c<NW, 0, KS, ACT_IN, PEND_IN, true, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BmH[14], BmH[15], BmL[14], BmL[15], bias, h);
-    row_block_c<NW, (1 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[0], BoH[1], BoL[0], BoL[1], bias + 32, h);
-    row_block_c<NW, (2 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH[2], BoH[3], BoL[2], BoL[3], bias + 64, h);
-    row_block_c<NW, (3 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[4], BoH[5], BoL[4], BoL[5], bias + 96, h);
-    row_block_c<NW, (4 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH[6], BoH[7], BoL[6], BoL[7], bias + 128, h);
-    row_block_c<NW, (5 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[8], BoH[9], BoL[8], BoL[9], bias + 160, h);
-    row_block_c<NW, (6 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH[10], BoH[11], BoL[10], BoL[11], bias + 192, h);
-    row_block_c<NW, (7 * F) % 16, KS, ACT, true, false, false, PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH[12], BoH[13], BoL[12], BoL[13], bias + 224, h);
+// a 256-row layer = 16 compensated row blocks; on entry accB holds the pending last row block of the previous layer (if PEND_IN: it
+// completes this layer's own input fragment 7), on exit this layer's row block 15 is pending in accB
+template <int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
+__device__ __forceinline__ void layer_16(PipeT& P, f32x4& accA, f32x4& accB, u32x4 (&BmH)[8], u32x4 (&BmL)[8], const u32x4 (&BpH)[2], const u32x4 (&BpL)[2],
+                                         u32x4 (&BoH)[8], u32x4 (&BoL)[8], const float* bias, int g) {
+    constexpr int KH = KS == 2 ? 0 : 8, F = 2 * KS;     // fragments per row block
+    row_block_16<0, KS, ACT_IN, PEND_IN, true, false, 7, 1, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BmH, BmL, bias, g);
+    static_for<1, 16>([&](auto rb_) {
+        constexpr int rb = decltype(rb_)::value;
+        if constexpr (rb & 1) row_block_16<(rb * F) % 16, KS, ACT, true, false, false, ((rb - 1) >> 1), ((rb - 1) & 1), PipeT, KH>(P, accB, accA, BmH, BmL, BpH, BpL, BoH, BoL, bias + 16 * rb, g);
+        else row_block_16<(rb * F) % 16, KS, ACT, true, false, false, ((rb - 1) >> 1), ((rb - 1) & 1), PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BoH, BoL, bias + 16 * rb, g);
+    });
 }
 
 }  // namespace
