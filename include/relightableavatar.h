@@ -180,6 +180,15 @@ typedef struct ra_sphere_params {
     int   relighting;          /* cfg.relighting                                         */
     int   no_visibility, local_visibility;
     int   premultiply;         /* alpha_output_ (sphere_tracing_renderer.py:454-460,1113) */
+    /* Several of the reference's render chunks in ONE call (the reference's chunks bound ITS memory; rays are independent): ray r of this
+     * call belongs to chunk j with box_start[j] <= r < box_start[j + 1] and its shadow rays are clipped against boxes[6 j .. 6 j + 5] — the
+     * box the reference's in-place growth (:1020-1022) had reached at that chunk, computed by the caller with the same float arithmetic.
+     * Nothing else of render_human depends on the box, so the pixels are those of chunk-by-chunk rendering, bit for bit, and a frame of
+     * several chunks runs ONE 16-iteration surface loop instead of one per chunk.  n_boxes <= 1: every ray uses `bbox`.  At most 32 boxes;
+     * box_start[0] = 0, box_start[n_boxes] = P, ascending (host arrays). */
+    int   n_boxes;
+    const float* boxes;
+    const int*   box_start;
 } ra_sphere_params;
 
 /* sphere_tracing_renderer.Renderer.get_pixel_value -> render_human (:551-784, :981-1039) for one

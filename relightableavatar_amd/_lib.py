@@ -48,7 +48,8 @@ class ra_render_out(C.Structure):
 class ra_sphere_params(C.Structure):
     _fields_ = [('surface', ra_trace_params), ('shadow', ra_trace_params), ('shadow_near_offset', C.c_float),
                 ('dist_th', C.c_float), ('surf_sample_range', C.c_float), ('n_samples', C.c_int), ('relighting', C.c_int),
-                ('no_visibility', C.c_int), ('local_visibility', C.c_int), ('premultiply', C.c_int)]
+                ('no_visibility', C.c_int), ('local_visibility', C.c_int), ('premultiply', C.c_int),
+                ('n_boxes', C.c_int), ('boxes', C.POINTER(C.c_float)), ('box_start', C.POINTER(C.c_int))]
 
 
 class ra_ground_params(C.Structure):

@@ -51,6 +51,7 @@ def default_cfg() -> dotdict:
     c.bg_brightness = 0.0
     c.render_chunk_size = 8192
     c.volume_chunk_rays = 65536  # not in the reference: rays per volume-path launch sequence on a 288 GB device (the image does not depend on it); 0 = render_chunk_size
+    c.sphere_chunk_rays = 262144  # not in the reference: rays per launch sequence of the sphere-tracing renderers (consecutive render chunks merged, the shadow rays of every ray clipped against its own chunk's box: the image does not depend on it; a 1024 x 1024 frame runs ONE 16-iteration surface loop instead of three); 0 = render_chunk_size
     c.ground_chunk_rays = 262144  # not in the reference: pixels per launch sequence of the ground-plane pass (consecutive render chunks merged, every pixel clipped against its own chunk's box: the image does not depend on it); 0 = render_chunk_size
     c.network_chunk_size = 262144
     c.fix_material = 0           # xuzhen_12v_geo.yaml:25

@@ -470,7 +470,8 @@ int ra_sphere_trace(ra_ctx* c, const float* ray_o, const float* ray_d, const flo
 static int light_visibility_stage(ra_ctx* c, const float* surf, const float* norm_slots, const float* acc, const int* hit_idx,
                                   const int* hit_count, int P, const float* bbox, float near_offset, const ra_trace_params& shadow,
                                   int no_visibility, int local_visibility, float** lvis_out, float** ldot_out, hipStream_t s,
-                                  int n_boxes = 0, const float* boxes = nullptr, const int* box_start = nullptr, const int* pix_nn = nullptr) {
+                                  int n_boxes = 0, const float* boxes = nullptr, const int* box_start = nullptr, const int* pix_nn = nullptr,
+                                  const int* perm = nullptr) {
     int err = 0;
     const int L = c->n_lights;
     const size_t NR = (size_t)P * L;
@@ -485,6 +486,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         g.box_start[j] = box_start[j];
     }
     if (g.n_boxes) g.box_start[g.n_boxes] = box_start[g.n_boxes];
+    g.perm = g.n_boxes ? perm : nullptr;
     g.near_offset = near_offset; g.L = L; g.no_visibility = no_visibility; g.local_visibility = local_visibility;
     g.lvis = lvis; g.ldot = ldot;
     const bool traced = !(no_visibility || local_visibility);
@@ -543,7 +545,12 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     const bool relit = p->relighting != 0;
     RA_CHECK(!relit || (c->cfg.relight && probe && bbox && c->n_lights > 0), "ra_render_sphere_chunk: relighting needs the relight network, a probe and a bbox");
     RA_CHECK(p->n_samples >= 1 && p->n_samples <= 16, "ra_render_sphere_chunk: n_samples out of range");
-    RA_CHECK(!relit || (long long)P * c->n_lights < (1ll << 31), "ra_render_sphere_chunk: chunk too large (rays x lights must fit an int): lower cfg.render_chunk_size");
+    RA_CHECK(!relit || (long long)P * c->n_lights < (1ll << 31), "ra_render_sphere_chunk: chunk too large (rays x lights must fit an int): lower cfg.render_chunk_size / cfg.sphere_chunk_rays");
+    if (p->n_boxes > 1) {
+        RA_CHECK(p->n_boxes <= RA_MAX_BOXES && p->boxes && p->box_start && bbox, "ra_render_sphere_chunk: at most 32 boxes per call, with their tables");
+        RA_CHECK(p->box_start[0] == 0 && p->box_start[p->n_boxes] == P, "ra_render_sphere_chunk: box_start must run from 0 to P");
+        for (int j = 0; j < p->n_boxes; ++j) RA_CHECK(p->box_start[j] <= p->box_start[j + 1], "ra_render_sphere_chunk: box_start must ascend");
+    }
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     const int S = p->n_samples, C = c->cfg.relight ? 17 : 16, L = c->n_lights;
@@ -621,7 +628,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     float *lvis = nullptr, *ldot = nullptr, *shade = nullptr, *spec = nullptr;
     if (relit) {
         if (light_visibility_stage(c, surf, m.norm, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow,
-                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s, 0, nullptr, nullptr, rs.nn_hint)) return 1;
+                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s, p->n_boxes, p->boxes, p->box_start, rs.nn_hint, perm)) return 1;
         m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
         shade = c->buf<float>("mp_shade", (size_t)P * 3, &err);
         spec = c->buf<float>("mp_spec", (size_t)P * 3, &err);

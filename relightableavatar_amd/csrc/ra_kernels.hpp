@@ -106,6 +106,7 @@ struct ShadowGen {
     int n_boxes;
     float boxes[RA_MAX_BOXES][6];
     int box_start[RA_MAX_BOXES + 1];
+    const int* perm;      // nullable: the rays were re-ordered (Morton sort) — ray r is the caller's ray perm[r], which is what box_start counts
     float near_offset;
     int L;
     int no_visibility, local_visibility;

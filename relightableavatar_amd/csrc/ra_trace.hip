@@ -327,8 +327,9 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
     if (hv) {
         r = g.hit_idx[h];
         if (g.n_boxes > 1) {                        // the box of the render chunk this ray belongs to (kernel arguments: scalar loads)
+            const int rc = g.perm ? g.perm[r] : r;          // position in the caller's ray order
             int j = 0;
-            for (int k = 1; k < g.n_boxes; ++k) j += r >= g.box_start[k];
+            for (int k = 1; k < g.n_boxes; ++k) j += rc >= g.box_start[k];
 #pragma unroll
             for (int k = 0; k < 6; ++k) box[k] = g.boxes[j][k];
         }

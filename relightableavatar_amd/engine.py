@@ -188,12 +188,19 @@ class Engine:
                                 surf_sample_range=c.surf_sample_range, n_samples=c.n_samples, relighting=int(c.relighting),
                                 no_visibility=int(c.no_visibility), local_visibility=int(c.local_visibility), premultiply=1)
 
-    def render_sphere_chunk(self, ray_o, ray_d, near, far, bbox6, probe, params, outs: dict):
-        """ray tensors: contiguous fp32 device views (P,3)/(P,); outs: name -> tensor view or missing."""
+    def render_sphere_chunk(self, ray_o, ray_d, near, far, bbox6, probe, params, outs: dict, boxes=None, box_start=None):
+        """ray tensors: contiguous fp32 device views (P,3)/(P,); outs: name -> tensor view or missing.
+        boxes / box_start: several of the reference's chunks in this one call, the shadow rays of ray r clipped against the box of its own chunk."""
         P = ray_o.shape[0]
         ro = ra_render_out(**{k: _ptr(outs.get(k)) for k in _lib.RENDER_OUT_KEYS})
         bb = (C.c_float * 6)(*[float(v) for v in bbox6]) if bbox6 is not None else None
         ph, pw = (probe.shape[0], probe.shape[1]) if probe is not None else (0, 0)
+        if boxes is not None and len(boxes) > 1:
+            flat = (C.c_float * (6 * len(boxes)))(*[float(v) for b in boxes for v in b])
+            starts = (C.c_int * (len(boxes) + 1))(*[int(v) for v in box_start])
+            params.n_boxes, params.boxes, params.box_start = len(boxes), C.cast(flat, C.POINTER(C.c_float)), C.cast(starts, C.POINTER(C.c_int))
+        else:
+            params.n_boxes, params.boxes, params.box_start = 0, None, None
         check(self.lib.ra_render_sphere_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(near), _ptr(far), P, bb, _ptr(probe), ph, pw,
                                               C.byref(params), C.byref(ro), self.stream), 'ra_render_sphere_chunk')
 

@@ -92,13 +92,29 @@ class Renderer(nn.Module):
         for k in names:
             w = width.get(k, 3)
             full[k] = torch.empty((P, w) if w else (P,), device=dev)      # every ray of every map is written by the chunks (zeros for misses)
+        # The reference's chunks bound ITS memory; rays are independent and only the shadow rays' clip depends on the box.  Consecutive chunks
+        # are rendered by ONE launch sequence of up to cfg.sphere_chunk_rays rays (0: chunk exactly as the reference), the shadow rays of
+        # every ray clipped against the box its own chunk had reached (the in-place growth, once per chunk incl. empty ones, is data
+        # independent): identical pixels, and a frame of several chunks runs one 16-iteration surface loop instead of one per chunk.
+        limit = int(cfg.get('sphere_chunk_rays', 0))
+        group = []                                  # (a, b, box) of the chunks waiting for a launch
+
+        def flush():
+            if group:
+                a0, b1 = group[0][0], group[-1][1]
+                eng.render_sphere_chunk(ray_o[a0:b1], ray_d[a0:b1], near[a0:b1], far[a0:b1], group[0][2], probe, params,
+                                        {k: v[a0:b1] for k, v in full.items()},
+                                        boxes=[g[2] for g in group], box_start=[g[0] - a0 for g in group] + [b1 - a0])
+                group.clear()
         for a, b in (batch.get('render_chunks', None) or chunks(P, cfg.render_chunk_size)):      # render_chunks: a shard's view of the frame's chunks (shard.py)
             # quirk (sphere_tracing_renderer.py:1020-1022): the box grows IN PLACE on the batch every chunk
             bbox6 = self._grow_bounds(batch)
             if b <= a:
                 continue
-            eng.render_sphere_chunk(ray_o[a:b], ray_d[a:b], near[a:b], far[a:b], bbox6, probe, params,
-                                    {k: v[a:b] for k, v in full.items()})
+            if group and (a != group[-1][1] or len(group) == 32 or b - group[0][0] > limit):
+                flush()
+            group.append((a, b, bbox6))
+        flush()
         ret = lazydict()
         if want_raw:
             # per-hit arrays in ascending ray order (the reference's order is topk(sorted=False)'s, implementation-defined).  Their

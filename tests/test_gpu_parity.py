@@ -806,6 +806,30 @@ def test_merged_ground_chunks_are_exact():
     assert float(outs[0]['shade_map'].abs().sum()) > 0
 
 
+def test_merged_sphere_chunks_are_exact():
+    """cfg.sphere_chunk_rays: consecutive render chunks of the sphere-tracing renderer share ONE launch sequence (one 16-iteration surface
+    loop for the frame), the shadow rays of every ray clipped against the box the reference's in-place growth had reached at ITS chunk
+    (sphere_tracing_renderer.py:1020-1022) — bit-identical to chunking exactly as the reference does (sphere_chunk_rays = 0); here four
+    chunks of 700 rays and therefore four boxes, whole frame / groups of two / one by one, and one shard of two"""
+    from relightableavatar_amd import shard
+    from relightableavatar_amd.renderer import make_renderer
+    outs, parts = [], []
+    for merged in (262144, 1500, 0):
+        cfg, net, dev = build('relight', render_chunk_size=700, sphere_chunk_rays=merged, vis_specular_map=True)
+        base = synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True), dev)
+        assert 2100 < base.ray_o.shape[1] <= 2800
+        rend = make_renderer(cfg, net)
+        out = rend.render(base)
+        outs.append({k: out[k].cpu() for k in ('rgb_map', 'acc_map', 'shade_map', 'spec_map', 'surf_map', 'norm_map', 'albedo_map')})
+        b2 = synthetic.to_device(synthetic.make_batch(128, 128, seed=0, posed=True), dev)
+        parts.append(rend.render(shard.shard_batch(b2, 1, 2, cfg.render_chunk_size)).rgb_map.cpu())      # a shard walks the frame's chunks, some nearly empty
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[2][k]), k
+        assert torch.equal(outs[1][k], outs[2][k]), k
+    assert torch.equal(parts[0], parts[2]) and torch.equal(parts[1], parts[2])
+    assert float(outs[0]['shade_map'].abs().sum()) > 0
+
+
 def test_frames_in_flight_are_bit_identical():
     """relightableavatar_amd/pipeline.py: frames rendered two at a time on two HIP streams (contexts sharing a gate that serialises
     their light-visibility stages) equal the frames rendered one after the other, bit for bit — alternating poses, so that a frame

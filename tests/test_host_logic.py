@@ -352,3 +352,27 @@ def test_gather_of_the_novel_light_and_ground_payloads_gloo_world2(extra):
     assert line['gather']['channels'] == C and line['gather']['bytes_received_per_rank'] >= (96 * 96 if '--ground' in extra else sum(line['per_rank']['rays_per_frame'])) * C * 4
     assert 0 <= line['gather']['pad_fraction'] < 0.1
     assert 'ms_per_step_sequential' in line
+
+
+def test_ctypes_structs_match_the_header():
+    """the ctypes mirrors of the C ABI's structs must have the header's layout: a field missing on the Python side makes the library read
+    past the struct (found the hard way: ra_sphere_params.n_boxes).  Sizes and last-field offsets are compared with a C compiler's."""
+    import ctypes as C
+    import shutil
+    import tempfile
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    structs = {'ra_config': 'trace_precision', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
+               'ra_sphere_params': 'box_start', 'ra_ground_params': 'box_start', 'ra_ground_out': 'ldot', 'ra_pose_in': 'bounds_padding',
+               'ra_pose_out': 'Th', 'ra_image_params': 'tbounds', 'ra_counters': 'n_fine_sdf_comp'}
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "relightableavatar.h"\nint main(){\n' + \
+          ''.join(f'printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {f}));\n' for n, f in structs.items()) + 'return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(src)
+        subprocess.run(['gcc', '-I', os.path.join(REPO, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')], check=True)
+        out = subprocess.run([os.path.join(d, 't')], capture_output=True, text=True, check=True).stdout
+    for line in out.strip().splitlines():
+        name, size, off = line.split()
+        cls = getattr(_lib, name)
+        assert C.sizeof(cls) == int(size), (name, C.sizeof(cls), size)
+        assert getattr(cls, structs[name]).offset == int(off), (name, structs[name])
