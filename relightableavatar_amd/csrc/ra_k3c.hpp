@@ -73,7 +73,7 @@ __device__ __forceinline__ void pe_frags_16(u32x4 (&BpH)[2], u32x4 (&BpL)[2], co
 template <bool LAST, int ACT, int PEL, bool SDFNET, typename PipeT>
 __device__ __forceinline__ f32x4 run_net_16(PipeT& P, const float (&x)[3], const float* bias, int g) {
     u32x4 B0h[8], B0l[8], B1h[8], B1l[8], Bph[2], Bpl[2];
-    f32x4 accA, accB;
+    Acc16 accA, accB;
     pe_frags_16<PEL, SDFNET>(Bph, Bpl, x, g);
     layer_16<2, ACT, ACT, false>(P, accA, accB, B0h, B0l /* unused */, Bph, Bpl, B0h, B0l, bias, g);
     layer_16<8, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 256, g);
@@ -84,7 +84,10 @@ __device__ __forceinline__ f32x4 run_net_16(PipeT& P, const float (&x)[3], const
     layer_16<8, ACT, ACT, true>(P, accA, accB, B1h, B1l, Bph, Bpl, B0h, B0l, bias + 1536, g);
     layer_16<8, ACT, ACT, true>(P, accA, accB, B0h, B0l, Bph, Bpl, B1h, B1l, bias + 1792, g);
     row_block_16<0, 8, ACT, true, true, LAST, 7, 1, PipeT>(P, accA, accB, B1h, B1l, Bph, Bpl, B1h, B1l, bias + 2048, g);
-    return accA;
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = accA.val(e);
+    return out;
 }
 
 template <int NW>

@@ -416,7 +416,9 @@ __device__ __forceinline__ void layer2(PipeT& P, f32x16 (&accA)[2], f32x16 (&acc
 // (The first K3C used the 32x32x16 tile, one wave per SIMD: 150 us per 128-point tile)
 // D fragment: lane (point n = lane & 15, row group g = lane >> 4) holds rows 16 rb + 4 g + i; the packed D fragments of row blocks 2 m and
 // 2 m + 1 side by side are the next layer's B fragment of k-step m (ra_pack.cpp hidden_feature16).
-// One accumulator chain: a second chain for the two small products measured slower on the 32x32 tile (extra AGPR traffic, same accuracy).
+// One accumulator chain: a second chain for the two small products (RA_K3C_CHAINS=2) measured slower on both tiles — 165 against 150 us on
+// the 32x32 tile (extra AGPR traffic), 106 against 98 us for 2 400 points on this one — so the chain of dependent MFMAs is not what bounds a
+// lone wave here; the ~5 non-MFMA instructions it has to issue per 16-cycle MFMA are (5808 MFMAs in 98 us = 37 cycles each).
 #ifndef RA_K3C_E0
 #define RA_K3C_E0 2          // MFMA slots before the pending epilogue first touches the previous accumulator (its last MFMA is still in the pipe)
 #endif
@@ -425,11 +427,28 @@ __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f3
 // One row block: 3 KS MFMAs (fragments FM0.. of the stage, [hi | lo] per k-step) into `acc`, interleaved with the pending epilogue of
 // `accPrev` (activation ACT_PREV), whose four values per lane go to registers 2 DH, 2 DH + 1 of fragment DI of dstH / dstL.
 // KH hidden k-steps (from BmH / BmL), then KS - KH encoding k-steps (BpH / BpL).  ELAST: with EARLY, the last slot that may still write.
+#ifndef RA_K3C_CHAINS
+#define RA_K3C_CHAINS 1      // accumulator chains per row block: 1 = all three products into one accumulator; 2 = the two small products apart
+#endif
+struct Acc16 {               // m = bias + sum Ah Bh (+ the small products with one chain); s = sum (Ah Bl + Al Bh)
+    f32x4 m;
+#if RA_K3C_CHAINS >= 2
+    f32x4 s;
+#endif
+    __device__ __forceinline__ float val(int e) const {
+#if RA_K3C_CHAINS >= 2
+        return m[e] + s[e];
+#else
+        return m[e];
+#endif
+    }
+};
+
 template <int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, int DI, int DH, typename PipeT, int KH = (KS == 2 ? 0 : 8), int ELAST = 20>
-__device__ __forceinline__ void row_block_16(PipeT& P, f32x4& acc, const f32x4& accPrev, u32x4 (&BmH)[8], u32x4 (&BmL)[8], const u32x4 (&BpH)[2],
+__device__ __forceinline__ void row_block_16(PipeT& P, Acc16& acc, const Acc16& accPrev, u32x4 (&BmH)[8], u32x4 (&BmL)[8], const u32x4 (&BpH)[2],
                                              const u32x4 (&BpL)[2], u32x4 (&dstH)[8], u32x4 (&dstL)[8], const float* bias_rb, int g) {
     typedef f16 E;
-    acc = *reinterpret_cast<const f32x4*>(bias_rb + 4 * g);          // rows 16 rb + 4 g + i start at their bias
+    acc.m = *reinterpret_cast<const f32x4*>(bias_rb + 4 * g);          // rows 16 rb + 4 g + i start at their bias
     float ta[4];
     constexpr int NS = 3 * KS, PF = PipeT::PF, PFK = PF / 2;       // PF fragments = PFK k-steps read ahead
     static_for<0, NS>([&](auto i_) {
@@ -438,10 +457,20 @@ __device__ __forceinline__ void row_block_16(PipeT& P, f32x4& acc, const f32x4& 
         const u32x4 bh = ks < KH ? BmH[ks & 7] : BpH[(ks - KH) & 1];
         const u32x4 bl = ks < KH ? BmL[ks & 7] : BpL[(ks - KH) & 1];
         constexpr int fh = (FM0 + 2 * ks) % PF, fl = (FM0 + 2 * ks + 1) % PF;
-        if constexpr (m == 0) acc = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc);
-        if constexpr (m == 1) acc = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc);
+#if RA_K3C_CHAINS >= 2
+        // small, main, small: neighbouring MFMAs are independent except (ks, m = 2) -> (ks + 1, m = 0)
+        if constexpr (m == 0) {
+            if constexpr (ks == 0) { const f32x4 z = {}; acc.s = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), z); }
+            else acc.s = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc.s);
+        }
+        if constexpr (m == 1) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc.m);
+        if constexpr (m == 2) acc.s = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc.s);
+#else
+        if constexpr (m == 0) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc.m);
+        if constexpr (m == 1) acc.m = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc.m);
+        if constexpr (m == 2) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc.m);
+#endif
         if constexpr (m == 2) {
-            acc = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc);
             if constexpr (!(TAIL && ks + PFK >= KS)) {
                 P.template fetch<(FM0 + 2 * (ks + PFK)) % 16>();            // hi first: position 0 of a stage turns the ring
                 P.template fetch<(FM0 + 2 * (ks + PFK) + 1) % 16>();
@@ -456,12 +485,12 @@ __device__ __forceinline__ void row_block_16(PipeT& P, f32x4& acc, const f32x4& 
                 constexpr int E0 = NS >= 24 ? RA_K3C_E0 : 0;
                 constexpr int s0 = E0 + (e * (LAST - E0 - (DA + 2) + 1)) / 4;
                 if constexpr (SP) {
-                    if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(accPrev[e]);
+                    if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(accPrev.val(e));
                     if constexpr (s0 + 1 == i) ta[e] = 1.f + ta[e];
                     if constexpr (s0 + 2 == i) ta[e] = __builtin_amdgcn_logf(ta[e]);
-                    if constexpr (s0 + 3 == i) ta[e] = sp_finish(ta[e], accPrev[e]);
+                    if constexpr (s0 + 3 == i) ta[e] = sp_finish(ta[e], accPrev.val(e));
                 } else {
-                    if constexpr (s0 == i) ta[e] = max0(accPrev[e]);
+                    if constexpr (s0 == i) ta[e] = max0(accPrev.val(e));
                 }
                 if constexpr ((e & 1) && s0 + DA + 1 == i) {          // hi halves of the pair (e - 1, e); ta keeps the residuals
                     f16x2 hv;
@@ -480,7 +509,7 @@ __device__ __forceinline__ void row_block_16(PipeT& P, f32x4& acc, const f32x4& 
 // a 256-row layer = 16 compensated row blocks; on entry accB holds the pending last row block of the previous layer (if PEND_IN: it
 // completes this layer's own input fragment 7), on exit this layer's row block 15 is pending in accB
 template <int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT>
-__device__ __forceinline__ void layer_16(PipeT& P, f32x4& accA, f32x4& accB, u32x4 (&BmH)[8], u32x4 (&BmL)[8], const u32x4 (&BpH)[2], const u32x4 (&BpL)[2],
+__device__ __forceinline__ void layer_16(PipeT& P, Acc16& accA, Acc16& accB, u32x4 (&BmH)[8], u32x4 (&BmL)[8], const u32x4 (&BpH)[2], const u32x4 (&BpL)[2],
                                          u32x4 (&BoH)[8], u32x4 (&BoL)[8], const float* bias, int g) {
     constexpr int KH = KS == 2 ? 0 : 8, F = 2 * KS;     // fragments per row block
     row_block_16<0, KS, ACT_IN, PEND_IN, true, false, 7, 1, PipeT, KH>(P, accA, accB, BmH, BmL, BpH, BpL, BmH, BmL, bias, g);
