@@ -5,7 +5,7 @@
 // of that size flips the cycle's phase on ~1 % of the pixels (4 mm surface jumps, up to 0.1 rgb) — SURVEY.md:409's max |err| <= 1e-2
 // cannot be met.  fp32 itself IS stable there (a differently associated fp32 oracle agrees to 89-110 dB), and compensating ONLY the
 // surface trace's distance queries (2 % of a relit frame's fine queries) brings whole frames to 67 dB / max 6e-3 while the 15 M
-// shadow queries stay on plain f16 (K3).  Arithmetic: ra_stream.hpp row_block_c — operands as f16 hi + lo pairs, three MFMAs per
+// shadow queries stay on plain f16 (K3).  Arithmetic: ra_stream.hpp row_block_16 — operands as f16 hi + lo pairs, three MFMAs per
 // k-step, fp32 accumulate: 1.3e-7 rms from a float64 evaluation, the same as fp32 arithmetic itself (1.2e-7).
 //
 //   * tile shape v_mfma_f32_16x16x32_f16: 16 points per wave, 16 row blocks of 16 rows per layer, k-steps of 32 (ra_stream.hpp row_block_16);

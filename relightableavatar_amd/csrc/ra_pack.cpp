@@ -65,17 +65,9 @@ struct StreamBuilder {
     static int hidden_feature(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
     // rows_pad/32 row blocks; per row block: 16 hidden k-steps of Mh (may be null) then 4 PE k-steps of Mp (may be null)
     bool pairs = false;         // interleave the fragments of row blocks (2p, 2p + 1) k-step by k-step (K3's latency variants, ra_stream.hpp row_blocks)
-    bool split = false;         // K3C (ra_k3c.hpp): every fragment twice, [hi | lo] with lo = cv(v - hi): compensated products
-    // part: 0 = the value rounded once; 1 = hi (the same); 2 = lo, the rounded residual of the first rounding
     template <typename ChanFn>
-    void frag(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale, int part = 0) {       // ks < 16: hidden k-step, else encoding k-step ks - 16
-        auto put = [&](float v) {
-            const uint16_t hi = cv(v);
-            if (part != 2) { w.push_back(hi); return; }
-            _Float16 hf;
-            std::memcpy(&hf, &hi, 2);                  // split streams are IEEE half (ra_pack_weights builds them with half = true)
-            w.push_back(cv(v - (float)hf));
-        };
+    void frag(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale) {       // ks < 16: hidden k-step, else encoding k-step ks - 16
+        auto put = [&](float v) { w.push_back(cv(v)); };
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
                 const int row = rb * 32 + (lane & 31);
@@ -95,6 +87,7 @@ struct StreamBuilder {
     // encoding k-step p (0 | 1): slot (kg, j) is slot q = 8 (2 p + (kg >> 1)) + j of lane half h = kg & 1 of the 32x32 layout (pe_chan_*).
     static int hidden_feature16(int ks, int kg, int j) { return 32 * ks + 16 * (j >> 2) + 4 * kg + (j & 3); }
     template <typename ChanFn>
+    // part 1 = hi: the value rounded to IEEE half; part 2 = lo: the rounded residual of that rounding (compensated products)
     void frag16(const Mat* Mh, const Mat* Mp, ChanFn chan, int rb, int ks, float pe_scale, int part) {      // ks < 8: hidden, else encoding k-step ks - 8
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
@@ -129,10 +122,7 @@ struct StreamBuilder {
         for (int rb0 = 0; rb0 < nb; rb0 += group)
             for (int ks = Mh ? 0 : 16; ks < (Mp ? 20 : 16); ++ks) {
                 if (ks >= hks && ks < 16) continue;
-                for (int g = 0; g < group; ++g) {
-                    if (split) { frag(Mh, Mp, chan, rb0 + g, ks, pe_scale, 1); frag(Mh, Mp, chan, rb0 + g, ks, pe_scale, 2); }
-                    else frag(Mh, Mp, chan, rb0 + g, ks, pe_scale);
-                }
+                for (int g = 0; g < group; ++g) frag(Mh, Mp, chan, rb0 + g, ks, pe_scale);
             }
     }
 };
