@@ -156,13 +156,39 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
 #ifdef RA_TIMESTAMPS
     int tiles_done = 0;
 #endif
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Whole rounds of 256-point tiles first (tile = round * grid + workgroup).  The LAST round is usually partly filled: with the plain
+    // deal its tiles keep a few CUs busy for a full tile time (107 us with two waves per SIMD) while the others idle.  When at most a quarter
+    // of the workgroups would get a tile, the 8-wave kernel SPREADS the remaining points over all of them instead: each takes 32 * wact
+    // consecutive points on its first wact <= 2 waves — one wave per SIMD, a tile then takes ~65 us — and its other waves only keep the
+    // weight stream and the stage barriers going (Pipe::sync_stage).  Which wave computes a point does not change its arithmetic.
+    // Measured on one box (tools/bench_mlp.py): 470 400 points 0.894 -> 0.852 ms; with three active waves (tried) it is a wash.
+    const int G = gridDim.x;
+    const int full = ntiles / G, remt = ntiles - full * G;
+#ifdef RA_K3_NOSPREAD
+    const bool spread = false;
+#else
+    const bool spread = NW == 8 && full >= 1 && remt > 0 && 4 * remt <= G;
+#endif
+    int wact = NW, tail_start = 0;
+    if (spread) {
+        const int base = full * G * ST_TM;
+        wact = (count - base + 32 * G - 1) / (32 * G);          // 1 .. 2
+        tail_start = base + (int)blockIdx.x * 32 * wact;
+    }
+    const int n_it = full + ((spread ? tail_start < count : (int)blockIdx.x < remt) ? 1 : 0);
+    for (int it = 0; it < n_it; ++it) {
+        const bool spread_tile = spread && it == full;
 #ifdef RA_TIMESTAMPS
-        ts = (wave == 0 && lane == 0 && tile == (int)blockIdx.x) ? ra_k3_ts + blockIdx.x * 48 : nullptr;
+        ts = (wave == 0 && lane == 0 && it == 0) ? ra_k3_ts + blockIdx.x * 48 : nullptr;
         RA_STAMP(ts, 0);
         if (ts) ts += 1;
 #endif
-        const int s = tile * ST_TM + wave * 32 + c;
+        if (spread_tile && wave >= wact) {          // wave-uniform: this wave has no points in the spread tile
+            for (int st = 0; st < STAGES; ++st) P.sync_stage();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            continue;
+        }
+        const int s = spread_tile ? tail_start + wave * 32 + c : (it * G + (int)blockIdx.x) * ST_TM + wave * 32 + c;
         float x[3] = {0.f, 0.f, 0.f};
         int pidx = 0;
         float smpl = 0.f;

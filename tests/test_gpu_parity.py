@@ -957,6 +957,14 @@ def test_streamed_k3_tile_boundaries(relight):
     big = eng.hdq_sdf(x_all, 0.125, False)                       # 70 000 points: 8 waves
     for n in (1000, 16384, 30000, 65536):                         # 2 waves up to 16 384, 4 waves up to 65 536
         assert torch.equal(eng.hdq_sdf(x_all[:n].contiguous(), 0.125, False), big[:n]), n
+    # the 8-wave kernel spreads a partly filled LAST round of tiles over all workgroups (32 * w points each on w <= 4 waves, the other
+    # waves only keep the weight stream going): 70 000 points = one round + 18 tiles -> spread with w = 1; 140 000 = two rounds + 35
+    # tiles -> w = 2; 110 000 = one round + 174 tiles -> more than half the workgroups, plain deal.  Always the same bits per point.
+    assert torch.equal(eng.hdq_sdf(x_all[65536:].contiguous(), 0.125, False), big[65536:])
+    twice = torch.cat([x_all, x_all]).contiguous()
+    for n in (140000, 110000, 131072 + 1, 131072 + 32 * 256 + 1):
+        got = eng.hdq_sdf(twice[:n].contiguous(), 0.125, False)
+        assert torch.equal(got[:70000], big) and torch.equal(got[70000:], big[:n - 70000]), n
 
 
 @pytest.mark.parametrize('mode', ['relight', 'anisdf'])
