@@ -123,9 +123,14 @@ void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const voi
 void launch_mlp_sdf_stream64_f16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
 
 // K3C (ra_k3c.hpp): the same query in compensated arithmetic (f16 hi + lo operand pairs, three MFMAs per k-step) on the split stream
-// sarena_c, 16 points per wave: 2 waves per workgroup (32-point tiles) for launches of at most 8 Ki points, 4 (64-point tiles) up to
-// 16 Ki — one wave per SIMD, a launch spreads over as many CUs as it has tiles — else 8 (128-point tiles, two waves per SIMD)
-inline int k3c_waves(int max_slots) { return max_slots <= 256 * 32 ? 2 : (max_slots <= 256 * 64 ? 4 : 8); }
+// sarena_c, 16 points per wave: 4 waves per workgroup (64-point tiles, one wave per SIMD) for launches of at most 16 Ki points, else 8
+// (128-point tiles, two waves per SIMD).
+// K3CC (ra_k3cc.hpp): launches of at most k3c_coop_max points — an upper bound; the surface loop fills about half of it, one round of 256
+// tiles — give every 16-point tile to FOUR cooperating waves (a quarter of each layer's row blocks per wave, private register-resident
+// weight streams): 102 -> 56 us per launch.  All variants are bit-identical.
+inline int k3c_waves(int max_slots) { return max_slots <= 256 * 64 ? 4 : 8; }
+constexpr int k3c_coop_max = 256 * 32;
+void launch_mlp_sdf_coop(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
 void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
 
 // K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list

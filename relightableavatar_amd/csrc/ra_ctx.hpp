@@ -11,7 +11,7 @@ struct HostNets {
     std::vector<uint16_t> sarena;      // K3 weight stream (consumption order, 1952 fragments of 1 KB), every layer padded; host only (prefix of fwd_arena)
     std::vector<uint16_t> sarena_trim; // the 8-wave K3's stream: sarena without the fragments that only hold padding (1920)
     std::vector<uint16_t> sarena_pairs;  // the same with the row blocks of every layer interleaved in pairs (K3 latency variants)
-    std::vector<uint16_t> sarena_c;    // K3C: every fragment as an IEEE-half [hi | lo] pair in the 16x16x32 layout (3872 fragments)
+    std::vector<uint16_t> sarena_c;    // K3C: every fragment as an IEEE-half [hi | lo] pair in the 16x16x32 layout (3872 fragments), then K3CC's four per-wave streams (4 x 992)
     std::vector<uint16_t> fwd_arena;   // K4 forward stream: sarena + the 256 feature rows (2080 fragments)
     std::vector<uint16_t> bwd_arena;   // K4 backward stream: transposed geometry layers, then the material / colour head
     int bwd_geo_frags = 0, bwd_frags = 0;

@@ -14,8 +14,8 @@
 //   * encoding: the argument of every sin / cos is reduced in two-constant arithmetic (x 2^k is exact; k = rint(a c_hi),
 //     t = fma(a, c_hi, -k) + a c_lo) before v_sin / v_cos — the plain kernel's a * (1 / 2 pi) loses 1.5e-5 rad at 2^9 x, invisible
 //     behind an f16 rounding, not here;
-//   * 8 waves per workgroup (two per SIMD, 128 points per tile) on launches above 16 Ki points, 4 or 2 (one per SIMD, 64 / 32 points) below:
-//     the smaller the launch, the more SIMDs share it.
+//   * 8 waves per workgroup (two per SIMD, 128 points per tile) on launches above 16 Ki points, 4 (one per SIMD, 64 points) down to 8 Ki;
+//     below that K3CC (ra_k3cc.hpp): four waves per 16-point tile.  The smaller the launch, the more SIMDs share it.
 //   reference: lib/networks/deform/base_network.py:34-42,78-87,374-382; lib/utils/net_utils.py:1263-1273,1337-1352;
 //   lib/networks/embedder.py:26-37; hit test and sign-change interpolation that consume the result: sphere_tracing_renderer.py:176-197
 #include "ra_stream.hpp"

@@ -401,6 +401,26 @@ int ra_pack_weights(ra_ctx* ctx, std::string& err) {
         for (int l = 0; l < 8; ++l) Sc.add16(l == 0 ? nullptr : &Sm[l], l == 0 ? &Sm[0] : (l == 4 ? &Spe4 : nullptr), pe_chan_sdf, 256, sp);
         Sc.add16(&Shead, nullptr, pe_chan_sdf, 16, 1.f);
         if (Sc.w.size() != (size_t)3872 * 512) { err = "internal: split weight stream has " + std::to_string(Sc.w.size() / 512) + " fragments, expected 3872"; return 1; }
+        // K3CC (ra_k3cc.hpp): four waves share a 16-point tile, wave w owns the row blocks 4 i + w of every layer and walks a PRIVATE
+        // stream: its 4 row blocks per layer in order, both heads in every wave's stream (each wave computes them itself).  Same
+        // fragments, permuted: 4 x 992 after the 3872 of the per-wave kernel.
+        {
+            static const int lay_off[8] = {0, 64, 320, 576, 832, 1152, 1408, 1664}, lay_f[8] = {4, 16, 16, 16, 20, 16, 16, 16};
+            std::vector<uint16_t>& A = Sc.w;
+            for (int w = 0; w < 4; ++w)
+                for (int netb = 0; netb < 3872; netb += 1936) {
+                    for (int l = 0; l < 8; ++l)
+                        for (int i = 0; i < 4; ++i) {
+                            const size_t src = (size_t)(netb + lay_off[l] + (4 * i + w) * lay_f[l]) * 512;
+                            const std::vector<uint16_t> rbk(A.begin() + src, A.begin() + src + (size_t)lay_f[l] * 512);
+                            A.insert(A.end(), rbk.begin(), rbk.end());
+                        }
+                    const size_t hsrc = (size_t)(netb + 1920) * 512;
+                    const std::vector<uint16_t> head(A.begin() + hsrc, A.begin() + hsrc + (size_t)16 * 512);
+                    A.insert(A.end(), head.begin(), head.end());
+                }
+            if (A.size() != (size_t)(3872 + 4 * 992) * 512) { err = "internal: cooperative weight stream has the wrong size"; return 1; }
+        }
         H.sarena_c = Sc.w;
     }
     {   // K4 (reverse mode) streams, same fragment order / K permutation as the K3 stream.

@@ -103,6 +103,7 @@ template <typename E, int NW, int STAGES = ST_STAGES, int PF_ = ST_PF>
 struct Pipe {
     static constexpr int FPW = 16 / NW;
     static constexpr int PF = PF_;
+    static constexpr int MOD = 16;            // fetch<FM>: FM = position in a 16-fragment stage
     static constexpr bool LONE = NW < 8;      // one wave per SIMD
     const char* g;          // weight stream (uniform)
     unsigned voff;          // per lane: wave * FPW * 1024 + lane * 16
@@ -146,6 +147,7 @@ struct Pipe {
         if (FM == 0) sync_stage();
         af[FM % PF] = *reinterpret_cast<const typename Tr<E>::x8*>(rd + FM * 1024);
     }
+    template <int FH, int FL> __device__ __forceinline__ void ready() {}       // (PipeReg, ra_k3cc.hpp: the wait for a k-step's fragments)
 };
 
 template <typename E> using X8 = typename Tr<E>::x8;
@@ -466,14 +468,15 @@ __device__ __forceinline__ void row_block_16(PipeT& P, Acc16& acc, const Acc16& 
         if constexpr (m == 1) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc.m);
         if constexpr (m == 2) acc.s = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc.s);
 #else
+        if constexpr (m == 0) P.template ready<fh, fl>();
         if constexpr (m == 0) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc.m);
         if constexpr (m == 1) acc.m = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc.m);
         if constexpr (m == 2) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc.m);
 #endif
         if constexpr (m == 2) {
             if constexpr (!(TAIL && ks + PFK >= KS)) {
-                P.template fetch<(FM0 + 2 * (ks + PFK)) % 16>();            // hi first: position 0 of a stage turns the ring
-                P.template fetch<(FM0 + 2 * (ks + PFK) + 1) % 16>();
+                P.template fetch<(FM0 + 2 * (ks + PFK)) % PipeT::MOD>();            // hi first: position 0 of a stage turns the ring
+                P.template fetch<(FM0 + 2 * (ks + PFK) + 1) % PipeT::MOD>();
             }
         }
         if constexpr (PENDING) {

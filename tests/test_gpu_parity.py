@@ -142,7 +142,7 @@ def test_compensated_distance_query_is_fp32_accurate(ops):
     """K3C (csrc/ra_k3c.hpp): the distance query with f16 hi + lo operand pairs (three MFMAs per k-step) — the tier the surface trace
     runs in (cfg.trace_precision >= 1).  Against the reference's own MLP outputs and against the fp32 oracle on 20 000 near-surface points it
     must be as accurate as fp32 arithmetic itself (the fp32 oracle is 1.2e-7 rms from a float64 evaluation; plain f16 operands: 5.9e-5),
-    and its two workgroup widths must agree bit for bit."""
+    and its workgroup widths and the cooperative small-launch variant must agree bit for bit."""
     from oracle import ra_oracle as O
     cfg, net, dev = build('relight', trace_precision=2)         # 2: every distance query in the compensated tier (validation setting)
     body = synthetic.make_body(0, posed=True)
@@ -161,8 +161,13 @@ def test_compensated_distance_query_is_fp32_accurate(ops):
     rms = lambda a, b: float((a - b).pow(2).mean().sqrt())
     print(f'compensated tier: HIP vs float64-accumulated oracle rms {rms(hip, f64):.2e} (fp32 oracle vs the same: {rms(f32, f64):.2e}), max {float((hip - f64).abs().max()):.2e}')
     assert rms(hip, f64) < 4e-7 and float((hip - f64).abs().max()) < 3e-6
-    narrow = eng.observed_sdf(bpts[:9000].to(dev)).cpu()        # 9 000 points: the 2-wave workgroups
+    narrow = eng.observed_sdf(bpts[:9000].to(dev)).cpu()        # 9 000 points: the 4-wave workgroups
     assert torch.equal(narrow, hip[:9000])
+    # at most 8 Ki points: K3CC (csrc/ra_k3cc.hpp), four waves sharing a 16-point tile, a quarter of every layer's row blocks each —
+    # the same operations on the same operands: bit-identical.  Ragged sizes; 5 000 and 8 192 points need a second round of tiles
+    for n in (1, 15, 16, 17, 300, 4096, 4097, 5000, 8192):
+        coop = eng.observed_sdf(bpts[:n].to(dev)).cpu()
+        assert torch.equal(coop, hip[:n]), n
     # the hierarchical query (coarse level + blend) on world points, ragged size
     x = (bpts * 1.02)[:12345]
     ref = O.hdq_sdf(O.OracleNet(sd, cfg), x, fr, 0.125, True)[:, 0]

@@ -376,3 +376,14 @@ def test_ctypes_structs_match_the_header():
         cls = getattr(_lib, name)
         assert C.sizeof(cls) == int(size), (name, C.sizeof(cls), size)
         assert getattr(cls, structs[name]).offset == int(off), (name, structs[name])
+
+
+def test_k3cc_fragment_registers_are_only_touched_by_name():
+    """K3CC (csrc/ra_k3cc.hpp) keeps 62 weight fragments in flight in AGPRs it addresses by name from inline assembly: the compiler must not
+    write an AGPR anywhere else in that kernel, and may read one only after the counted wait that makes its load a value
+    (tools/check_k3cc_isa.py compiles the kernel to gfx950 assembly with the product flags and checks exactly that)."""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import check_k3cc_isa
+    problems, stats = check_k3cc_isa.check()
+    assert not problems, problems[:5]
+    assert stats['agpr_reads'] == 8 * stats['waits']

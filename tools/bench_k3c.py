@@ -16,7 +16,7 @@ for tp in (2, 0):
     cfg = make_cfg('relight', trace_precision=tp)
     net = make_network(cfg); net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg)); net = net.to(dev).eval()
     eng = net.set_frame(body)
-    for n in (2400, 8000, 16384, 20800, 32768, 65536):
+    for n in [int(v) for v in os.environ.get("RA_K3C_SIZES", "2400,8000,16384,20800,32768,65536").split(",")]:
         x = bpts[:n].contiguous()
         for _ in range(3):
             out = eng.observed_sdf(x)
