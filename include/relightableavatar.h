@@ -241,7 +241,7 @@ int ra_reset_counters(ra_ctx* ctx, void* stream);
 int ra_get_mlp_time(ra_ctx* ctx, float* ms, int* n_launches, void* stream);
 /* the same for one kernel family: kind 0 = fused distance query (K3, every width), 1 = full query with normals / material / colour (K4),
  * 2 = the 8-wave distance query only (the launches that fill the chip: the frame's dominant kernel), 3 = the 2- / 4-wave distance query,
- * 4 = the compensated distance query (K3C; not part of kind 0) */
+ * 4 = the compensated distance query (K3C and its cooperative small-launch variant K3CC; not part of kind 0) */
 int ra_get_kernel_time(ra_ctx* ctx, int kind, float* ms, int* n_launches, void* stream);
 int ra_enable_timing(ra_ctx* ctx, int on);
 /* ---- frames in flight --------------------------------------------------------------------------------------------

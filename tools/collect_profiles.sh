@@ -61,7 +61,7 @@ python3 - <<'P'
 import csv, glob, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof'
 rn = os.environ.get('RA_ROUND', 'r04')
-fams = (('mlp_sdf_comp', 'mlp_sdf_comp_kernel'), ('mlp_sdf_stream_kernelIDF16_Li8E', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream_kernel<_Float16, 8>', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
+fams = (('mlp_sdf_coop', 'mlp_sdf_coop_kernel'), ('mlp_sdf_comp', 'mlp_sdf_comp_kernel'), ('mlp_sdf_stream_kernelIDF16_Li8E', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream_kernel<_Float16, 8>', 'mlp_sdf_stream_kernel_w8'), ('mlp_sdf_stream', 'mlp_sdf_stream_kernel'), ('hdq_coarse', 'hdq_coarse_kernel'), ('mlp_fwd_tape', 'mlp_fwd_tape_kernel'),
         ('mlp_bwd_heads', 'mlp_bwd_heads_kernel'))
 for pat, name in (('/pmc[0-9]*/', 'relight512'), ('/pmcv[0-9]*/', 'anisdf512')):      # one summary per workload
     agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
