@@ -68,6 +68,8 @@ typedef struct ra_config {
                                                  1.3e-7 rms from a float64 evaluation, as good as fp32 itself — the shadow rays stay on plain 16-bit
                                                  operands; 0: plain operands everywhere (round 3's behaviour); 2: compensated everywhere, also
                                                  ra_hdq_sdf / ra_observed_sdf and the shadow rays (validation; 3x the MFMA work) */
+    float clip_near, clip_far;                /* 0.02, 10.0: the volume renderer's near.clip(min=clip_near), far.clip(max=clip_far)
+                                                 (base_renderer.py:120-121; config.py clip_near / clip_far), applied by ra_render_volume_chunk */
 } ra_config;
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 
@@ -201,7 +203,8 @@ int ra_render_sphere_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, 
                            const ra_sphere_params* p, const ra_render_out* out, void* stream);
 
 /* base_renderer.Renderer.get_pixel_value (base_renderer.py:53-113): uniform samples,
- * Network.forward per sample, alpha compositing. near/far already clipped by the caller. */
+ * Network.forward per sample, alpha compositing.  near / far as the dataset delivers them: the renderer's clip
+ * (base_renderer.py:120-121) is applied here (ra_config.clip_near / clip_far).  Every array of `out` is written for every ray. */
 int ra_render_volume_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, const float* near_,
                            const float* far_, int P, int n_samples, float dist_th,
                            const ra_render_out* out, void* stream);

@@ -778,7 +778,7 @@ int ra_render_volume_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     float* vs = c->buf<float>("vl_v", N * 3, &err);
     float* raw = c->buf<float>("vl_raw", N * C, &err);
     if (err) return 1;
-    if (launch_sort_rays(ray_o, ray_d, near_, far_, P, nullptr, k0, k1, v0, perm, tmp, tb, so, sd, sn, sf, s)) { ra_set_error("ra_render_volume_chunk: radix sort failed"); return 1; }
+    if (launch_sort_rays(ray_o, ray_d, near_, far_, P, nullptr, k0, k1, v0, perm, tmp, tb, so, sd, sn, sf, s, c->cfg.clip_near, c->cfg.clip_far)) { ra_set_error("ra_render_volume_chunk: radix sort failed"); return 1; }
     launch_volume_samples(so, sd, sn, sf, P, S, xs, vs, s);
     if (forward_pass(c, xs, vs, (int)N, nullptr, dist_th, raw, s)) return 1;
     launch_volume_composite(raw, C, sn, sf, P, S, c->cfg.bg_brightness, *out, perm, s);

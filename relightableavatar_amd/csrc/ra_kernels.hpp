@@ -153,7 +153,7 @@ void launch_scatter_maps(const int* hit_idx, const int* hit_count, int P, int pr
 // Morton-sort the primary rays of a chunk by their entry point and gather them into so/sd/sn/sf; perm[i] = caller index of sorted ray i
 int launch_sort_rays(const float* ro, const float* rd, const float* nr, const float* fr, int P, const float* bbox_min, unsigned* keys_in,
                      unsigned* keys_out, int* vals_in, int* perm, void* temp, size_t temp_bytes, float* so, float* sd, float* sn, float* sf,
-                     hipStream_t s);
+                     hipStream_t s, float near_min = -3.0e38f, float far_max = 3.0e38f);
 void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s);
 
 // volume path

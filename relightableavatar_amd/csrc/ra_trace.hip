@@ -200,14 +200,14 @@ __global__ __launch_bounds__(1024) void entry_min_kernel(const float* __restrict
 
 __global__ void gather_rays_kernel(const int* __restrict__ perm, int P, const float* __restrict__ ro, const float* __restrict__ rd,
                                    const float* __restrict__ nr, const float* __restrict__ fr, float* __restrict__ so, float* __restrict__ sd,
-                                   float* __restrict__ sn, float* __restrict__ sf) {
+                                   float* __restrict__ sn, float* __restrict__ sf, float near_min, float far_max) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= P) return;
     const int r = perm[i];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { so[3 * i + c] = ro[3 * r + c]; sd[3 * i + c] = rd[3 * r + c]; }
-    sn[i] = nr[r];
-    sf[i] = fr[r];
+    sn[i] = fmaxf(nr[r], near_min);     // the volume renderer's near.clip(min=clip_near) / far.clip(max=clip_far) (base_renderer.py:120-121);
+    sf[i] = fminf(fr[r], far_max);      // -inf / +inf elsewhere
 }
 
 __global__ void surface_samples_kernel(const float* __restrict__ surf, const float* __restrict__ rd, const int* __restrict__ hit_idx,
@@ -1339,7 +1339,7 @@ void launch_scatter_maps(const int* hit_idx, const int* hit_count, int P, int pr
 
 int launch_sort_rays(const float* ro, const float* rd, const float* nr, const float* fr, int P, const float* bbox_min, unsigned* keys_in,
                      unsigned* keys_out, int* vals_in, int* perm, void* temp, size_t temp_bytes, float* so, float* sd, float* sn, float* sf,
-                     hipStream_t s) {
+                     hipStream_t s, float near_min, float far_max) {
     if (P <= 0) return 0;
     float* origin_dev = nullptr;
     if (!bbox_min) {            // no box from the caller: the grid starts at the lower corner of the entry points (device side)
@@ -1349,7 +1349,7 @@ int launch_sort_rays(const float* ro, const float* rd, const float* nr, const fl
     hipLaunchKernelGGL(ray_keys_kernel, grid_for(P), dim3(TPB), 0, s, ro, rd, nr, P, bbox_min ? bbox_min[0] : 0.f, bbox_min ? bbox_min[1] : 0.f,
                        bbox_min ? bbox_min[2] : 0.f, origin_dev, keys_in, vals_in);
     if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, perm, P, 0, 32, s) != hipSuccess) return 1;
-    hipLaunchKernelGGL(gather_rays_kernel, grid_for(P), dim3(TPB), 0, s, perm, P, ro, rd, nr, fr, so, sd, sn, sf);
+    hipLaunchKernelGGL(gather_rays_kernel, grid_for(P), dim3(TPB), 0, s, perm, P, ro, rd, nr, fr, so, sd, sn, sf, near_min, far_max);
     return 0;
 }
 

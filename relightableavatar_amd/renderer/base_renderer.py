@@ -22,12 +22,12 @@ class Renderer(nn.Module):
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
         ray_o, ray_d = f(batch.ray_o), f(batch.ray_d)
-        near = f(batch.near).clip(min=cfg.clip_near)      # base_renderer.py:120-121
-        far = f(batch.far).clip(max=cfg.clip_far)
+        near, far = f(batch.near), f(batch.far)           # clipped to [cfg.clip_near, .] / [., cfg.clip_far] by the library (base_renderer.py:120-121)
         P = ray_o.shape[0]
-        full = dotdict(rgb=torch.zeros(P, 3, device=dev), acc=torch.zeros(P, device=dev), depth=torch.zeros(P, device=dev),
-                       norm=torch.zeros(P, 3, device=dev), cpts=torch.zeros(P, 3, device=dev), bpts=torch.zeros(P, 3, device=dev),
-                       resd=torch.zeros(P, 3, device=dev))
+        # every output is written for every ray by the compositor: no zero fill, no torch kernel in the frame
+        full = dotdict(rgb=torch.empty(P, 3, device=dev), acc=torch.empty(P, device=dev), depth=torch.empty(P, device=dev),
+                       norm=torch.empty(P, 3, device=dev), cpts=torch.empty(P, 3, device=dev), bpts=torch.empty(P, 3, device=dev),
+                       resd=torch.empty(P, 3, device=dev))
         # the reference's render_chunk_size bounds its activation memory on a 24 GB card; rays are independent here (the pixels do
         # not depend on the chunking: test_full_size_properties_volume_config2), so launches are sized for the device instead:
         # 428 k full queries per 8192-ray chunk are 6.5 rounds of 256-point tiles over the 256 CUs, i.e. 7 % idle in the last one

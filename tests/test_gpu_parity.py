@@ -163,6 +163,18 @@ def test_compensated_distance_query_is_fp32_accurate(ops):
     assert rms(hip, f64) < 4e-7 and float((hip - f64).abs().max()) < 3e-6
     narrow = eng.observed_sdf(bpts[:9000].to(dev)).cpu()        # 9 000 points: the 4-wave workgroups
     assert torch.equal(narrow, hip[:9000])
+    # the same points behind a larger upper bound of the fine count (the launcher picks the kernel from the bound, the kernels read the
+    # count on the device): 13 k real fine points in a 40 k-point query -> 8-wave tiles, alone -> the 4-wave kernel; 2 k in 23 k / alone -> K3CC
+    big = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1) * (0.38 + 0.12 * torch.rand(20000, 1, generator=g)) * 1.02
+    far = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1) * 5.0
+    for n_near in (20000, 3000):
+        eng.reset_counters()
+        alone = eng.hdq_sdf(big[:n_near].to(dev), 0.125, True).cpu()
+        n_fine = eng.counters().n_fine_sdf_comp
+        eng.reset_counters()
+        mixed = eng.hdq_sdf(torch.cat([big[:n_near], far]).to(dev), 0.125, True).cpu()
+        assert eng.counters().n_fine_sdf_comp == n_fine > 0.5 * n_near       # the far points stop at the coarse level
+        assert torch.equal(mixed[:n_near], alone), n_near
     # at most 8 Ki points: K3CC (csrc/ra_k3cc.hpp), four waves sharing a 16-point tile, a quarter of every layer's row blocks each —
     # the same operations on the same operands: bit-identical.  Ragged sizes; 5 000 and 8 192 points need a second round of tiles
     for n in (1, 15, 16, 17, 300, 4096, 4097, 5000, 8192):

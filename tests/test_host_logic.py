@@ -362,7 +362,7 @@ def test_ctypes_structs_match_the_header():
     import tempfile
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
-    structs = {'ra_config': 'trace_precision', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
+    structs = {'ra_config': 'clip_far', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
                'ra_sphere_params': 'box_start', 'ra_ground_params': 'box_start', 'ra_ground_out': 'ldot', 'ra_pose_in': 'bounds_padding',
                'ra_pose_out': 'Th', 'ra_image_params': 'tbounds', 'ra_counters': 'n_fine_sdf_comp'}
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "relightableavatar.h"\nint main(){\n' + \
