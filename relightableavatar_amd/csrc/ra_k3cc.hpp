@@ -10,11 +10,13 @@
 //     62 fragment registers (248 of the lone wave's 512 registers; loads may target AGPRs and MFMAs read A operands from them), each
 //     refilled 31 k-steps ahead right after the MFMAs that consumed it.  62 KB in flight per wave instead of the 24 KB a quarter of the
 //     LDS can hold (first version, private LDS-DMA rings: 63 us per tile, 36 us without the stream — the stream's latency, 1.2-1.4 us per
-//     round trip, was all that mattered); no barrier, no hand-counted `vmcnt` (every load is the compiler's own), no LDS operand reads.
-//     The per-wave stream is 992 = 16 x 62 fragments long, so a fragment's register is its position mod 62 in every tile;
+//     round trip, was all that mattered); no barrier in the weight path, no LDS operand reads; one counted `s_waitcnt vmcnt(60)` per
+//     k-step (below: the registers are addressed by name from inline assembly).  The per-wave stream is 992 = 16 x 62 fragments long, so
+//     a fragment's register is its position mod 62 in every tile.  56 us per launch; 37 us without the loads, 51 us from a cache-hot 4 KB:
+//     what remains is the CU's vector-memory path (3.97 MB per tile at 64 B/clk = 27 us at best);
 //   * activations: the D fragments of a wave's row blocks — after bias / activation / hi + lo split exactly as in K3C — go to a 16 KB LDS
 //     array in the next layer's B-fragment layout (lane (c, g) of k-step ks holds features 32 ks + 16 (j >> 2) + 4 g + (j & 3): row block
-//     2 ks + (j >> 2), elements j & 3 — 8 bytes per row block and lane), one barrier, every wave reads all eight k-steps back;
+//     2 ks + (j >> 2), elements j & 3 — 8 bytes per row block and lane), two barriers per layer (array free / array complete), every wave reads all eight k-steps back;
 //   * both heads are computed by every wave (24 MFMAs each) instead of being broadcast.
 // Every output is the same chain of operations on the same operands as in K3C: bit-identical distances (test_compensated_distance_query...).
 // reference: as ra_k3c.hpp
