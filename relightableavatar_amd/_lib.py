@@ -157,6 +157,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RaError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                       f'(make -C relightableavatar_amd/csrc). There is no CPU fallback for the render path.')
+    # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64.  Loaded after ours, the process ends up with two HIP runtimes
+    # and ours sees no device ("no ROCm-capable device is detected" in ra_ctx_create when build() preceded the first torch import);
+    # loaded before, our library's libamdhip64.so.7 resolves to the copy that is already there.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)      # AttributeError if the header and the library disagree
