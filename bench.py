@@ -101,16 +101,20 @@ def psnr_vs_oracle(renderer, ref, H, skin_noise, dev, n_target=512, cam_dist=2.0
     bad = ref.get('fp32_unstable', None)
     bad = torch.zeros_like(per_ray, dtype=torch.bool) if bad is None else bad
     mse_s = float((e[0][~bad] ** 2).mean())
-    res = {'rgb': (float('inf') if mse_s == 0 else -10.0 * math.log10(mse_s)), 'rgb_all_rays': (float('inf') if mse == 0 else -10.0 * math.log10(mse)),
-           'max_abs': float(per_ray[~bad].max()), 'n_rays': int(rgb.shape[1]),
-           'rays_over_1e-2': int((per_ray[~bad] > 1e-2).sum()), 'fp32_unstable_rays': int(bad.sum()), 'max_abs_all_rays': float(per_ray.max()),
-           'rays_over_1e-2_all_rays': int((per_ray > 1e-2).sum()), 'fp32_unstable_source': ref.get('fp32_unstable_source', None),
+    db = lambda m: float('inf') if m == 0 else -10.0 * math.log10(m)
+    # schema 3 (round 5): `rgb`, `max_abs`, `rays_over_1e-2` are over ALL sampled rays (as in rounds 1-3); the *_fp32_stable keys beside
+    # them leave out the rays the reference's own fp32 arithmetic does not pin (round 4 printed those under the plain names)
+    res = {'schema': 3, 'rgb': db(mse), 'max_abs': float(per_ray.max()), 'rays_over_1e-2': int((per_ray > 1e-2).sum()),
+           'rgb_fp32_stable': db(mse_s), 'max_abs_fp32_stable': float(per_ray[~bad].max()), 'rays_over_1e-2_fp32_stable': int((per_ray[~bad] > 1e-2).sum()),
+           'n_rays': int(rgb.shape[1]), 'fp32_unstable_rays': int(bad.sum()), 'fp32_unstable_source': ref.get('fp32_unstable_source', None),
            'hit_rays': int(hit_ref.sum()), 'hit_mask_agreement': float((hit == hit_ref).float().mean()),
            'sample': f'every {stride}th in-box ray of the benchmarked {H}x{H} frame, skin_noise {skin_noise}',
-           'contract': 'SURVEY.md:409: rgb PSNR >= 50 dB and max |err| <= 1e-2 over every ray the reference\'s own fp32 arithmetic pins '
-                       '(`rgb`, `max_abs`, `rays_over_1e-2`; the same over all sampled rays beside them; a ray is fp32-unstable when 3e-7 noise on the traced distances moves its surface point by > 0.1 mm: '
-                       'tools/fp32_stability.py, DESIGN.md section 2).  The surface trace runs in compensated arithmetic (config.trace_precision 1).'}
-    res['contract_met'] = bool(res['rgb'] >= 50.0 and res['max_abs'] <= 1e-2)
+           'contract': 'SURVEY.md:409: rgb PSNR >= 50 dB and max |err| <= 1e-2, asserted over every ray the reference\'s own fp32 arithmetic pins '
+                       '(`*_fp32_stable`; `rgb`, `max_abs`, `rays_over_1e-2` are the same over ALL sampled rays; a ray is fp32-unstable when 3e-7 noise on the traced distances moves its surface point by > 0.1 mm: '
+                       'tools/fp32_stability.py, DESIGN.md section 2).  The surface trace runs in compensated arithmetic (config.trace_precision 1), '
+                       'amplified penumbra candidates of the shadow rays are re-evaluated in it (config.shadow_requery_tol).'}
+    res['contract_met'] = bool(res['rgb_fp32_stable'] >= 50.0 and res['max_abs_fp32_stable'] <= 1e-2)
+    res['contract_met_all_rays'] = bool(res['rgb'] >= 50.0 and res['max_abs'] <= 1e-2)
     return res
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 5
+#define RA_ABI_VERSION 6
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -70,7 +70,17 @@ typedef struct ra_config {
                                                  ra_hdq_sdf / ra_observed_sdf and the shadow rays (validation; 3x the MFMA work) */
     float clip_near, clip_far;                /* 0.02, 10.0: the volume renderer's near.clip(min=clip_near), far.clip(max=clip_far)
                                                  (base_renderer.py:120-121; config.py clip_near / clip_far), applied by ra_render_volume_chunk */
+    float shadow_requery_tol;                 /* 2e-3 (default): adaptive precision of the DFSS shadow rays under trace_precision 1.  A penumbra
+                                                 candidate is cls = d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): where the amplification
+                                                 sharp / (2 t) lifts the 6e-5 rms distance error of plain f16 operands over this tolerance AND the
+                                                 candidate can still lower the ray's visibility, the candidate is taken from a distance re-computed
+                                                 in compensated arithmetic (one extra K3C launch per light-visibility stage on the listed points,
+                                                 ra_counters.n_fine_sdf_comp) instead of the plain one.  0: off (round 4's behaviour) */
 } ra_config;
+/* A zero-initialised ra_config is NOT the default configuration (trace_precision 0 = plain operands, clip_far 0, ...): start from
+ * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2,
+ * clip_far <= clip_near (or NaN) and a negative / NaN shadow_requery_tol. */
+int ra_default_config(ra_config* out);
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 
 /* ---- weights: one call per state_dict entry (SURVEY.md section 8b "weights on disk") ------
@@ -258,6 +268,24 @@ typedef struct ra_gate ra_gate;
 int ra_gate_create(ra_gate** out, int device);
 int ra_gate_destroy(ra_gate* gate);
 int ra_set_gate(ra_ctx* ctx, ra_gate* gate);
+
+/* ---- multi-GPU: the deal of a frame's in-box rays to the ranks of one node (no counterpart in the reference,
+ * whose inference is single-process) ----------------------------------------------------------------------------------------------
+ * HOST function, no device work, no ctx: relightableavatar_amd/shard.py make_plan's per-frame part in one pass over the mask.
+ * mask: H x W bytes (batch.mask_at_box, row-major, non-zero = in box); P = number of in-box rays (= set bytes, checked); the in-box rays
+ * are the mask's pixels in row-major order (lib/utils/data_utils.py:925-938).  Pixels are dealt in 8 x 8 tiles: ground = 0 -> the tiles
+ * that hold in-box pixels round robin in raster order; ground != 0 -> fixed diagonal stripes (tile_y + tile_x) % world over the whole
+ * frame (the sharded ground-plane pass needs a rank's in-box pixels to be a subset of its frame pixels).
+ * Outputs (host, caller-allocated, e.g. inside one pinned staging block): owner[P] (nullable) rank of every ray; counts[world];
+ * *n_max = max(counts); order[P] = rays grouped by owner, ascending inside (rank r's shard is order[offs[r] : offs[r + 1]]);
+ * src[P]: item j of `order` is row src[j] = rank * n_max + position of the all_gather's (world * n_max)-row output, i.e.
+ * full[order] = gathered[src]; inds[P] (nullable; needs ground_pos[H * W] = position of every frame pixel in its owner's full-frame
+ * pixel list): ground_pos of the rays in `order` order.  edges[n_edges] (nullable): ascending ray indices (chunk boundaries of the
+ * unsharded ray list, chunkify's rule net_utils.py:323); chunk_pos[r * n_edges + e] = how many of rank r's rays lie before ray
+ * edges[e].  world <= 256. */
+int ra_shard_plan(const unsigned char* mask, int H, int W, int world, int ground, long long P, const long long* ground_pos,
+                  const long long* edges, int n_edges, unsigned char* owner, long long* order, long long* src, long long* inds,
+                  long long* counts, long long* chunk_pos, long long* n_max);
 
 /* 1 (default): exact 3-NN through the per-frame vertex BVH; 0: brute force over all vertices (validation path).
  * Takes effect at the next ra_set_frame. Both return identical neighbours. */

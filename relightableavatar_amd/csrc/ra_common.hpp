@@ -119,9 +119,6 @@ void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const void
 void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
                                 int max_slots, hipStream_t stream);
 
-// K3 with 64 points per wave (ra_k3w.hpp), f16 only: the trimmed stream of the 8-wave kernel, bit-identical distances
-void launch_mlp_sdf_stream64_f16(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
-
 // K3C (ra_k3c.hpp): the same query in compensated arithmetic (f16 hi + lo operand pairs, three MFMAs per k-step) on the split stream
 // sarena_c, 16 points per wave: 4 waves per workgroup (64-point tiles, one wave per SIMD) for launches of at most 16 Ki points, else 8
 // (128-point tiles, two waves per SIMD).

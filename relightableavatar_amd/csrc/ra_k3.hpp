@@ -149,8 +149,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     P.sstage = STAGES - 1;
     P.rd = P.ring;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RA_BAR2
+#pragma unroll
+    for (int st = 0; st < ST_AHEAD - 1; ++st) P.issue(st, st);
+#else
 #pragma unroll
     for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
+#endif
+#ifdef RA_K3_PRIO
+    // EXPERIMENT (round 5): static priority for the younger half of an 8-wave workgroup (MI355X_MICROARCH.md, "Static priority")
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(RA_K3_PRIO);
+#endif
 
     long long* ts = nullptr;
 #ifdef RA_TIMESTAMPS
@@ -262,8 +271,5 @@ static void launch_k3(const GeoNet& net, const void* sarena, const void* sarena_
 #endif
     if (nw == 2) launch_nw<E, 2>(net, sarena_pairs, barena, fr, io, max_slots, stream);
     else if (nw == 4) launch_nw<E, 4>(net, sarena_pairs, barena, fr, io, max_slots, stream);
-#ifdef RA_K3_WIDE64
-    else if (Tr<E>::is_f16) launch_mlp_sdf_stream64_f16(net, sarena, barena, fr, io, max_slots, stream);
-#endif
     else launch_nw<E, 8>(net, sarena, barena, fr, io, max_slots, stream);
 }

@@ -1,4 +1,4 @@
-// positional-encoding B fragments of the distance-query kernels (ra_k3.hpp, ra_k3w.hpp)
+// positional-encoding B fragments of the distance-query kernels (ra_k3.hpp)
 #pragma once
 #include "ra_stream.hpp"
 

@@ -126,6 +126,26 @@ struct Pipe {
     }
     // the next stage of the stream becomes readable; the ring slot two stages back is refilled ST_AHEAD stages ahead.
     // The stage position is run-time state (SGPRs), so the code below only depends on a fragment's position in its stage.
+#ifdef RA_BAR2
+    // EXPERIMENT (round 5, tools/ab_k3_variants.sh): one barrier per TWO stages.  At an even stage s the wave waits for its pieces of
+    // stages s and s + 1, the barrier makes both readable, and stages s + 5, s + 6 refill the slots of s - 3, s - 2 (s - 1 may still be
+    // read: its last ST_PF fragments are requested but not consumed).  Five stages in flight instead of six, half the barriers.
+    __device__ __forceinline__ void sync_stage() {
+        slot = (slot + 1) & (ST_RING - 1);
+        sstage = sstage + 1 == STAGES ? 0 : sstage + 1;
+        if ((sstage & 1) == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * 3) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int a5 = sstage + 5, a6 = sstage + 6;
+            a5 = a5 >= STAGES ? a5 - STAGES : a5;
+            a6 = a6 >= STAGES ? a6 - STAGES : a6;
+            issue(a5, (slot + 5) & (ST_RING - 1));
+            issue(a6, (slot + 6) & (ST_RING - 1));
+        }
+        rd = ring + slot * ST_STAGE_BYTES;
+    }
+#else
     __device__ __forceinline__ void sync_stage() {
 #ifdef RA_SYNC_DRAIN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // experiment: no counted wait
@@ -141,6 +161,7 @@ struct Pipe {
         issue(ahead, (slot + ST_AHEAD) & (ST_RING - 1));
         rd = ring + slot * ST_STAGE_BYTES;
     }
+#endif
     // FM: position of the fragment in its 16-fragment stage
     template <int FM>
     __device__ __forceinline__ void fetch() {
@@ -310,100 +331,6 @@ __device__ __forceinline__ void layer_pairs(PipeT& P, f32x16& a0, f32x16& a1, f3
     row_blocks<E, NW, 2, (6 * KS) % 16, KS, ACT, true, false, false>(P, b0, b1, a0, a1, Bm, Bp, Bo[8], Bo[9], Bo[10], Bo[11], bias + 192, h);
 }
 
-// ---- 64 points per wave: one A fragment feeds two MFMAs (EXPERIMENT, not in the product build: tools/build_w64.sh) -----------------
-// Round-3 verdict, item 2.  Result (round 4, MI355X, 5.12 M points, bit-identical distances): 8.44 ms against 8.29 ms for the two-wave
-// kernel (-1.7 %) in the best form — VGPR-form accumulators (-mllvm -amdgpu-mfma-vgpr-form=1), outputs pinned in AGPRs; the compiler's
-// default (accumulators in AGPRs, one v_accvgpr_read per element) -9 %.  The LDS operand reads, DMA pieces and barriers per point do
-// halve (ds_read 1.27 -> 0.63 per MFMA), but the B fragments of two column sets do not fit the 256 arch VGPRs beside the accumulators,
-// so every packed output costs a v_accvgpr_write (+0.54 VALU per MFMA): what the LDS saves the register file spends.
-// A wave owns TWO column sets of 32 points; every A fragment read from LDS is multiplied with both sets' B fragments, so the LDS operand
-// reads, the weight DMA and the stage barriers per POINT halve.  One wave per SIMD (the B fragments of two column sets are 256 registers):
-// the two column sets' MFMA chains are independent, which gives the lone wave the instruction-level parallelism a second wave would.
-// PINA: keep the packed outputs in AGPRs (v_accvgpr_write once, MFMA reads them as srcB from there): the arch VGPR file cannot hold
-// two ping-pong B sets for 64 points beside the accumulators.
-#ifndef RA_W64_PINA
-#define RA_W64_PINA 1
-#endif
-
-__device__ __forceinline__ unsigned pin_b(unsigned w) {
-#if RA_W64_PINA
-    asm volatile("" : "+a"(w));
-#endif
-    return w;
-}
-// the pending outputs go to dst[c][I0], dst[c][I0 + 1] (dst may BE Bm: the first row block of a layer completes its own inputs).
-// The epilogue is scheduled per K-STEP (two MFMAs, the elements of the two column sets alternating), as row_block does for one column set.
-// Spreading it per MFMA instead (VALU work between the two MFMAs of a k-step, as row_blocks does for its pairs) measured 5.8 % slower than
-// the two-wave kernel against 1.7 % for this form (tools/ab_w64.sh).
-template <typename E, int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, int I0, typename PipeT, int KH = (KS == 4 ? 0 : 16), int ELAST = 13>
-__device__ __forceinline__ void row_block2(PipeT& P, f32x16 (&acc)[2], const f32x16 (&accPrev)[2], u32x4 (&Bm)[2][16], const u32x4 (&Bp)[2][4],
-                                           u32x4 (&dst)[2][16], const float* bias_rb, int h) {
-    init_acc(acc[0], bias_rb, h);
-    acc[1] = acc[0];
-    float ta[32];
-    constexpr int PF = PipeT::PF;
-    static_for<0, KS>([&](auto ks_) {
-        constexpr int ks = decltype(ks_)::value;
-        const X8<E> a = P.af[(FM0 + ks) % PF];
-        static_for<0, 2>([&](auto c_) {
-            constexpr int c = decltype(c_)::value;
-            const u32x4 bw = ks < KH ? Bm[c][ks & 15] : Bp[c][(ks - KH) & 3];
-            acc[c] = Tr<E>::mfma(a, __builtin_bit_cast(X8<E>, bw), acc[c]);
-        });
-        if constexpr (!(TAIL && ks + PF >= KS)) P.template fetch<(FM0 + ks + PF) % 16>();
-        if constexpr (PENDING) {
-            static_for<0, 32>([&](auto e_) {
-                constexpr int e2 = decltype(e_)::value;
-                constexpr int c = e2 & 1, e = e2 >> 1;          // the two column sets' elements alternate
-                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
-                constexpr int DEPTH = SP ? 3 : 0;
-                constexpr int LAST = (KS == 4) ? 3 : (EARLY ? ELAST : KS - 1);
-                constexpr int s0 = (KS == 4) ? 0 : (e * (LAST - DEPTH + 1)) / 16;
-                if constexpr (SP && KS != 4) {
-                    if constexpr (s0 == ks) ta[e2] = __builtin_amdgcn_exp2f(accPrev[c][e]);
-                    if constexpr (s0 + 1 == ks) ta[e2] = 1.f + ta[e2];
-                    if constexpr (s0 + 2 == ks) ta[e2] = __builtin_amdgcn_logf(ta[e2]);
-                    if constexpr (s0 + 3 == ks) ta[e2] = sp_finish(ta[e2], accPrev[c][e]);
-                } else if constexpr (SP) {
-                    if constexpr (ks == 0) ta[e2] = __builtin_amdgcn_exp2f(accPrev[c][e]);
-                    if constexpr (ks == 1) ta[e2] = 1.f + ta[e2];
-                    if constexpr (ks == 2) ta[e2] = __builtin_amdgcn_logf(ta[e2]);
-                    if constexpr (ks == 3) ta[e2] = sp_finish(ta[e2], accPrev[c][e]);
-                } else {
-                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e2] = Tr<E>::is_f16 ? accPrev[c][e] : max0(accPrev[c][e]);
-                }
-                constexpr int sdone = (KS == 4) ? (SP ? 3 : e / 4) : s0 + DEPTH;
-                if constexpr ((e & 1) && sdone == ks) {
-                    unsigned w = pack2<E>(ta[e2 - 2], ta[e2]);          // elements e - 1 and e of column set c
-                    if constexpr (!SP && Tr<E>::is_f16) {
-                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                        h2_t v = __builtin_bit_cast(h2_t, w);
-                        v = __builtin_elementwise_max(v, h2_t{(_Float16)0, (_Float16)0});
-                        w = __builtin_bit_cast(unsigned, v);
-                    }
-                    w = pin_b(w);
-                    if constexpr (e < 8) dst[c][I0][e >> 1] = w; else dst[c][I0 + 1][(e >> 1) & 3] = w;
-                }
-            });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    });
-}
-
-template <typename E, int KS, int ACT, int ACT_IN, bool PEND_IN, typename PipeT, int NRB = 8, int KH = (KS == 4 ? 0 : 16), int PRB = 8>
-__device__ __forceinline__ void layer2(PipeT& P, f32x16 (&accA)[2], f32x16 (&accB)[2], u32x4 (&Bm)[2][16], const u32x4 (&Bp)[2][4], u32x4 (&Bo)[2][16],
-                                       const float* bias, int h) {
-    row_block2<E, 0, KS, ACT_IN, PEND_IN, true, false, 2 * PRB - 2, PipeT, KH, 2 * PRB - 3>(P, accA, accB, Bm, Bp, Bm, bias, h);
-    row_block2<E, (1 * KS) % 16, KS, ACT, true, false, false, 0, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 32, h);
-    row_block2<E, (2 * KS) % 16, KS, ACT, true, false, false, 2, PipeT, KH>(P, accA, accB, Bm, Bp, Bo, bias + 64, h);
-    row_block2<E, (3 * KS) % 16, KS, ACT, true, false, false, 4, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 96, h);
-    row_block2<E, (4 * KS) % 16, KS, ACT, true, false, false, 6, PipeT, KH>(P, accA, accB, Bm, Bp, Bo, bias + 128, h);
-    row_block2<E, (5 * KS) % 16, KS, ACT, true, false, false, 8, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 160, h);
-    row_block2<E, (6 * KS) % 16, KS, ACT, true, false, false, 10, PipeT, KH>(P, accA, accB, Bm, Bp, Bo, bias + 192, h);
-    if constexpr (NRB == 8)
-        row_block2<E, (7 * KS) % 16, KS, ACT, true, false, false, 12, PipeT, KH>(P, accB, accA, Bm, Bp, Bo, bias + 224, h);
-}
-
 // ---- compensated row blocks (K3C, ra_k3c.hpp): near-fp32 products from f16 MFMAs -----------------------------------------------
 // Both operands are carried as hi + lo pairs of IEEE halves (x = hi + lo exactly to 22 bits; the lo parts of small values are f16
 // subnormals, which the matrix pipe multiplies exactly) and a k-step is three MFMAs into ONE fp32 accumulator:
@@ -418,7 +345,7 @@ __device__ __forceinline__ void layer2(PipeT& P, f32x16 (&accA)[2], f32x16 (&acc
 // (The first K3C used the 32x32x16 tile, one wave per SIMD: 150 us per 128-point tile)
 // D fragment: lane (point n = lane & 15, row group g = lane >> 4) holds rows 16 rb + 4 g + i; the packed D fragments of row blocks 2 m and
 // 2 m + 1 side by side are the next layer's B fragment of k-step m (ra_pack.cpp hidden_feature16).
-// One accumulator chain: a second chain for the two small products (RA_K3C_CHAINS=2) measured slower on both tiles — 165 against 150 us on
+// One accumulator chain: a second chain for the two small products (round 4, removed) measured slower on both tiles — 165 against 150 us on
 // the 32x32 tile (extra AGPR traffic), 106 against 98 us for 2 400 points on this one — so the chain of dependent MFMAs is not what bounds a
 // lone wave here; the ~5 non-MFMA instructions it has to issue per 16-cycle MFMA are (5808 MFMAs in 98 us = 37 cycles each).
 #ifndef RA_K3C_E0
@@ -429,21 +356,9 @@ __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f3
 // One row block: 3 KS MFMAs (fragments FM0.. of the stage, [hi | lo] per k-step) into `acc`, interleaved with the pending epilogue of
 // `accPrev` (activation ACT_PREV), whose four values per lane go to registers 2 DH, 2 DH + 1 of fragment DI of dstH / dstL.
 // KH hidden k-steps (from BmH / BmL), then KS - KH encoding k-steps (BpH / BpL).  ELAST: with EARLY, the last slot that may still write.
-#ifndef RA_K3C_CHAINS
-#define RA_K3C_CHAINS 1      // accumulator chains per row block: 1 = all three products into one accumulator; 2 = the two small products apart
-#endif
-struct Acc16 {               // m = bias + sum Ah Bh (+ the small products with one chain); s = sum (Ah Bl + Al Bh)
+struct Acc16 {               // bias + sum of the three products of every k-step
     f32x4 m;
-#if RA_K3C_CHAINS >= 2
-    f32x4 s;
-#endif
-    __device__ __forceinline__ float val(int e) const {
-#if RA_K3C_CHAINS >= 2
-        return m[e] + s[e];
-#else
-        return m[e];
-#endif
-    }
+    __device__ __forceinline__ float val(int e) const { return m[e]; }
 };
 
 template <int FM0, int KS, int ACT_PREV, bool PENDING, bool EARLY, bool TAIL, int DI, int DH, typename PipeT, int KH = (KS == 2 ? 0 : 8), int ELAST = 20>
@@ -459,20 +374,10 @@ __device__ __forceinline__ void row_block_16(PipeT& P, Acc16& acc, const Acc16& 
         const u32x4 bh = ks < KH ? BmH[ks & 7] : BpH[(ks - KH) & 1];
         const u32x4 bl = ks < KH ? BmL[ks & 7] : BpL[(ks - KH) & 1];
         constexpr int fh = (FM0 + 2 * ks) % PF, fl = (FM0 + 2 * ks + 1) % PF;
-#if RA_K3C_CHAINS >= 2
-        // small, main, small: neighbouring MFMAs are independent except (ks, m = 2) -> (ks + 1, m = 0)
-        if constexpr (m == 0) {
-            if constexpr (ks == 0) { const f32x4 z = {}; acc.s = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), z); }
-            else acc.s = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc.s);
-        }
-        if constexpr (m == 1) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc.m);
-        if constexpr (m == 2) acc.s = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc.s);
-#else
         if constexpr (m == 0) P.template ready<fh, fl>();
         if constexpr (m == 0) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bl), acc.m);
         if constexpr (m == 1) acc.m = mfma16(P.af[fl], __builtin_bit_cast(f16x8, bh), acc.m);
         if constexpr (m == 2) acc.m = mfma16(P.af[fh], __builtin_bit_cast(f16x8, bh), acc.m);
-#endif
         if constexpr (m == 2) {
             if constexpr (!(TAIL && ks + PFK >= KS)) {
                 P.template fetch<(FM0 + 2 * (ks + PFK)) % PipeT::MOD>();            // hi first: position 0 of a stage turns the ring

@@ -36,6 +36,11 @@ class RaysPending:
         self._event.synchronize()
         P = int(self._host[:1].view(torch.int32).item())
         ro, rd, near, far, mask = self._bufs
+        # the buffers were allocated on the issuing stream; whoever consumes them on another stream must keep the caching allocator
+        # from recycling the blocks under it (advisor, round 4)
+        cur = torch.cuda.current_stream(ro.device)
+        for b in self._bufs:
+            b.record_stream(cur)
         out = dotdict(ray_o=ro[:P], ray_d=rd[:P], near=near[:P], far=far[:P], mask_at_box=mask.view(self.H, self.W).bool(),
                       wbounds_host=self._host[1:7].clone().reshape(1, 2, 3))
         if self._mask_host is not None:
@@ -61,7 +66,8 @@ class Engine:
                       tonemapping=int(cfg.tonemapping_rendering), bg_brightness=cfg.bg_brightness,
                       mlp_f16=int(cfg.mlp_dtype == 'f16'), query_skip=int(cfg.get('query_skip', True)),
                       k4_batch_slots=int(cfg.get('k4_batch_slots', 0)), trace_precision=int(cfg.get('trace_precision', 1)),
-                      clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)))
+                      clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)),
+                      shadow_requery_tol=float(cfg.get('shadow_requery_tol', 2e-3)))
         assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None

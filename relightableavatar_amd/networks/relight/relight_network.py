@@ -46,6 +46,15 @@ class Network(base_network.Network):
     def light_xyz(self):
         return self.light_xyz_
 
+    def invalidate_env_map(self):
+        """drop the eval-mode cache of `global_env_map` (needed after a write to `global_env_map_` that bypasses autograd's version
+        counter, e.g. through `.data`)"""
+        self._env_cache_key = None
+
+    def load_state_dict(self, *a, **kw):
+        self._env_cache_key = None
+        return super().load_state_dict(*a, **kw)
+
     @property
     def global_env_map(self):
         """softplus of the optimisable map (relight_network.py:86-89).  In eval mode the parameter does not change from frame to frame:
@@ -53,6 +62,7 @@ class Network(base_network.Network):
         p = self.global_env_map_
         if self.training or torch.is_grad_enabled() and p.requires_grad:
             return F.softplus(p.expand(*p.shape[:2], 3))
+        # `.data` writes do not bump the version counter: call invalidate_env_map() after one (load_state_dict does)
         key = (p._version, p.data_ptr(), p.device)
         if getattr(self, '_env_cache_key', None) != key:
             with torch.no_grad():

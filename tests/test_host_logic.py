@@ -362,7 +362,7 @@ def test_ctypes_structs_match_the_header():
     import tempfile
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
-    structs = {'ra_config': 'clip_far', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
+    structs = {'ra_config': 'shadow_requery_tol', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
                'ra_sphere_params': 'box_start', 'ra_ground_params': 'box_start', 'ra_ground_out': 'ldot', 'ra_pose_in': 'bounds_padding',
                'ra_pose_out': 'Th', 'ra_image_params': 'tbounds', 'ra_counters': 'n_fine_sdf_comp'}
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "relightableavatar.h"\nint main(){\n' + \
@@ -376,6 +376,22 @@ def test_ctypes_structs_match_the_header():
         cls = getattr(_lib, name)
         assert C.sizeof(cls) == int(size), (name, C.sizeof(cls), size)
         assert getattr(cls, structs[name]).offset == int(off), (name, structs[name])
+
+
+def test_default_config_matches_the_python_defaults():
+    """ra_default_config() (no ctx, no GPU) hands a C caller the documented defaults — a zero-initialised ra_config is NOT the default
+    (trace_precision 0, clip_far 0: rejected by ra_set_config) — and they are the values make_cfg('relight') sends through the binding."""
+    import ctypes as C
+    from relightableavatar_amd.config import make_cfg
+    c = _lib.ra_config()
+    assert _lib.lib().ra_default_config(C.byref(c)) == 0
+    cfg = make_cfg('relight')
+    for k in ('xyz_res', 'sdf_res', 'view_res', 'n_bones', 'resd_limit', 'blend_radius', 'albedo_slope', 'albedo_bias', 'roughness_slope',
+              'roughness_bias', 'fresnel_f0', 'shading_albedo', 'albedo_multiplier', 'bg_brightness', 'trace_precision', 'shadow_requery_tol',
+              'k4_batch_slots'):
+        assert abs(float(getattr(c, k)) - float(cfg[k])) < 1e-6, k
+    assert c.relight == 1 and c.mlp_f16 == 1 and c.query_skip == 1 and c.tonemapping == 1 and c.lambert_only == 0 and c.glossy_only == 0
+    assert abs(c.clip_near - 0.02) < 1e-7 and c.clip_far == 10.0
 
 
 def test_k3cc_fragment_registers_are_only_touched_by_name():
