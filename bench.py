@@ -111,8 +111,7 @@ def psnr_vs_oracle(renderer, ref, H, skin_noise, dev, n_target=512, cam_dist=2.0
            'sample': f'every {stride}th in-box ray of the benchmarked {H}x{H} frame, skin_noise {skin_noise}',
            'contract': 'SURVEY.md:409: rgb PSNR >= 50 dB and max |err| <= 1e-2, asserted over every ray the reference\'s own fp32 arithmetic pins '
                        '(`*_fp32_stable`; `rgb`, `max_abs`, `rays_over_1e-2` are the same over ALL sampled rays; a ray is fp32-unstable when 3e-7 noise on the traced distances moves its surface point by > 0.1 mm: '
-                       'tools/fp32_stability.py, DESIGN.md section 2).  The surface trace runs in compensated arithmetic (config.trace_precision 1), '
-                       'amplified penumbra candidates of the shadow rays are re-evaluated in it (config.shadow_requery_tol).'}
+                       'tools/fp32_stability.py, DESIGN.md section 2).  The surface trace runs in compensated arithmetic (config.trace_precision 1).'}
     res['contract_met'] = bool(res['rgb_fp32_stable'] >= 50.0 and res['max_abs_fp32_stable'] <= 1e-2)
     res['contract_met_all_rays'] = bool(res['rgb'] >= 50.0 and res['max_abs'] <= 1e-2)
     return res

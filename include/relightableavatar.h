@@ -70,16 +70,10 @@ typedef struct ra_config {
                                                  ra_hdq_sdf / ra_observed_sdf and the shadow rays (validation; 3x the MFMA work) */
     float clip_near, clip_far;                /* 0.02, 10.0: the volume renderer's near.clip(min=clip_near), far.clip(max=clip_far)
                                                  (base_renderer.py:120-121; config.py clip_near / clip_far), applied by ra_render_volume_chunk */
-    float shadow_requery_tol;                 /* 2e-3 (default): adaptive precision of the DFSS shadow rays under trace_precision 1.  A penumbra
-                                                 candidate is cls = d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): where the amplification
-                                                 sharp / (2 t) lifts the 6e-5 rms distance error of plain f16 operands over this tolerance AND the
-                                                 candidate can still lower the ray's visibility, the candidate is taken from a distance re-computed
-                                                 in compensated arithmetic (one extra K3C launch per light-visibility stage on the listed points,
-                                                 ra_counters.n_fine_sdf_comp) instead of the plain one.  0: off (round 4's behaviour) */
 } ra_config;
 /* A zero-initialised ra_config is NOT the default configuration (trace_precision 0 = plain operands, clip_far 0, ...): start from
- * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2,
- * clip_far <= clip_near (or NaN) and a negative / NaN shadow_requery_tol. */
+ * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2 and
+ * clip_far <= clip_near (or NaN). */
 int ra_default_config(ra_config* out);
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 

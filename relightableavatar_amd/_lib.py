@@ -23,8 +23,7 @@ class ra_config(C.Structure):
                 ('roughness_slope', C.c_float), ('roughness_bias', C.c_float), ('fresnel_f0', C.c_float),
                 ('shading_albedo', C.c_float), ('albedo_multiplier', C.c_float), ('lambert_only', C.c_int),
                 ('glossy_only', C.c_int), ('tonemapping', C.c_int), ('bg_brightness', C.c_float), ('mlp_f16', C.c_int), ('query_skip', C.c_int),
-                ('k4_batch_slots', C.c_int), ('trace_precision', C.c_int), ('clip_near', C.c_float), ('clip_far', C.c_float),
-                ('shadow_requery_tol', C.c_float)]
+                ('k4_batch_slots', C.c_int), ('trace_precision', C.c_int), ('clip_near', C.c_float), ('clip_far', C.c_float)]
 
 
 class ra_frame(C.Structure):

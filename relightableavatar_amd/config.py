@@ -124,9 +124,6 @@ def default_cfg() -> dotdict:
     # trace in compensated arithmetic (f16 hi + lo pairs, 3 MFMAs per k-step: as accurate as the reference's fp32), shadow rays plain;
     # 0 = plain 16-bit operands everywhere; 2 = compensated everywhere (validation)
     c.trace_precision = 1
-    # adaptive precision of the shadow rays under trace_precision 1 (ra_config.shadow_requery_tol): penumbra candidates whose plain-f16
-    # distance error is amplified over this visibility tolerance are re-evaluated from a compensated distance; 0 = off
-    c.shadow_requery_tol = 2e-3
     c.k4_batch_slots = 0         # full queries per forward+backward launch pair (bounds the 4.9 KB/slot activation tape); 0 = 1 Mi
     return c
 

@@ -102,7 +102,7 @@ int ra_default_config(ra_config* o) {
     o->albedo_slope = 1.f; o->albedo_bias = 0.f; o->roughness_slope = 0.9f; o->roughness_bias = 0.09f;
     o->fresnel_f0 = 0.02f; o->shading_albedo = 0.8f; o->albedo_multiplier = 1.f;
     o->tonemapping = 1; o->bg_brightness = 0.f; o->mlp_f16 = 1; o->query_skip = 1; o->k4_batch_slots = 0;
-    o->trace_precision = 1; o->clip_near = 0.02f; o->clip_far = 10.f; o->shadow_requery_tol = 2e-3f;
+    o->trace_precision = 1; o->clip_near = 0.02f; o->clip_far = 10.f;
     return 0;
 }
 
@@ -111,7 +111,6 @@ int ra_set_config(ra_ctx* c, const ra_config* cfg) {
     RA_CHECK(cfg->n_bones > 0 && cfg->n_bones <= 256, "ra_set_config: bad n_bones");
     RA_CHECK(cfg->trace_precision >= 0 && cfg->trace_precision <= 2, "ra_set_config: trace_precision must be 0, 1 or 2 (a zero-initialised ra_config is not the default: ra_default_config)");
     RA_CHECK(cfg->clip_far > cfg->clip_near, "ra_set_config: clip_far must exceed clip_near (a zero-initialised ra_config is not the default: ra_default_config)");
-    RA_CHECK(cfg->shadow_requery_tol >= 0.f, "ra_set_config: shadow_requery_tol must be >= 0");
     c->cfg = *cfg;
     c->have_cfg = true;
     return 0;
@@ -228,7 +227,7 @@ struct Timer {
 
 DevCounters* dcnt(ra_ctx* c) { return c->dcounters.as<DevCounters>(); }
 int* icnt(ra_ctx* c, int k) { return reinterpret_cast<int*>(c->dcounters.as<char>() + 128) + k; }   // small int counters
-enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_RQ = 4, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
+enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
 
 // Every hierarchical-distance pass compacts its fine points through a device counter that must start at zero.  Instead of one
 // 4-byte memset launch per pass (21 per relit chunk), the counters are a set that ONE memset zeroes per chunk; each pass takes
@@ -266,18 +265,8 @@ void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s) {
     }
 }
 
-// adaptive precision of a shadow iteration (ra_kernels.hpp RequeryList): the ray state the candidates are computed from, the list
-struct Requery {
-    const TraceState* ts;
-    const ra_trace_params* p;
-    int iter;
-    float tol;
-    float* keep;          // n: slot -> coarse distance
-    RequeryList list;
-};
-
 // one hierarchical distance query over the points of rs; writes sdf[n]
-int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s, int what = Q_OTHER, const Requery* rq = nullptr) {
+int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s, int what = Q_OTHER) {
     if (n <= 0) return 0;
     int err = 0;
     int* fine_idx = c->buf<int>("fine_idx", n, &err);
@@ -285,15 +274,12 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     if (err) return 1;
     HdqOut out{};
     out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
-    out.keep = rq ? rq->keep : nullptr;
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     MlpIO io{};
     io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     fine_level(c, io, n, precise(c, what), s);
-    // the fine slots whose visibility candidate is both amplified and live join the re-query list (answered once, after the loop)
-    if (rq) launch_requery_select(*rq->ts, sdf, fine_idx, bpts, rq->keep, out.fine_count, n, rq->iter, *rq->p, rq->tol, rq->list, s);
     return 0;
 }
 
@@ -532,28 +518,9 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         sh = alloc_trace(c, "sh_", (int)NR, true, &err);
         ssdf = c->buf<float>("sh_sdf", NR, &err);
     }
-    // adaptive precision (ra_config.shadow_requery_tol): with the surface trace compensated and the shadow rays plain (trace_precision 1),
-    // the shadow candidates whose distance error is amplified over the tolerance are re-evaluated from a compensated distance
-    Requery rq{};
-    const bool requery = traced && c->cfg.trace_precision == 1 && c->cfg.shadow_requery_tol > 0.f && shadow.soft_shadow;
-    if (requery) {
-        const size_t cap = NR < ((size_t)1 << 30) ? NR : ((size_t)1 << 30);
-        sh.defer = c->buf<unsigned char>("sh_defer", NR, &err);
-        rq.keep = c->buf<float>("rq_keep", NR, &err);
-        rq.list.cap = (int)cap;
-        rq.list.count = icnt(c, CNT_RQ);
-        rq.list.idx = c->buf<int>("rq_idx", cap, &err);
-        rq.list.bpts = c->buf<float>("rq_bpts", cap * 3, &err);
-        rq.list.sdf = c->buf<float>("rq_sdf", cap, &err);
-        rq.list.ray = c->buf<int>("rq_ray", cap, &err);
-        rq.list.t = c->buf<float>("rq_t", cap, &err);
-        rq.list.d0 = c->buf<float>("rq_d0", cap, &err);
-        rq.ts = &sh; rq.p = &shadow; rq.tol = c->cfg.shadow_requery_tol;
-    }
     if (err) return 1;
     // frames in flight: this stage (the frame's large launches) starts when the stage submitted before it through the same gate has ended
     if (c->gate && c->gate->armed) RA_HIP(hipStreamWaitEvent(s, c->gate->done, 0));
-    if (requery && !c->cnt_zero) RA_HIP(hipMemsetAsync(rq.list.count, 0, sizeof(int), s));
     launch_shadow_gen(g, P, s, c->cnt_zero);     // the chunk's bulk memset covers the first shadow stage; a second one zeroes its counter itself
     c->cnt_zero = false;
     if (traced) {
@@ -570,16 +537,8 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
             // first pass: a shadow ray starts next to its pixel's surface point, whose neighbours the surface trace's last query found
             r2.hint_src = it == 0 ? pix_nn : nullptr;
             r2.hint_src_index = it == 0 ? g.ray_pix : nullptr;
-            rq.iter = it;
-            if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s, Q_OTHER, requery ? &rq : nullptr)) return 1;
+            if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
             launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
-        }
-        if (requery) {          // the listed candidates: one compensated distance launch, then occ = min(occ, cls)
-            MlpIO io{};
-            io.bpts = rq.list.bpts; io.idx = rq.list.idx; io.count = rq.list.count; io.sdf = rq.list.sdf; io.dist_th = shadow.dist_th; io.smooth = 1;
-            io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
-            fine_level(c, io, rq.list.cap, true, s);
-            launch_requery_apply(sh, rq.list, shadow, s);
         }
         launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
         launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);

@@ -149,17 +149,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     P.sstage = STAGES - 1;
     P.rd = P.ring;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef RA_BAR2
-#pragma unroll
-    for (int st = 0; st < ST_AHEAD - 1; ++st) P.issue(st, st);
-#else
 #pragma unroll
     for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
-#endif
-#ifdef RA_K3_PRIO
-    // EXPERIMENT (round 5): static priority for the younger half of an 8-wave workgroup (MI355X_MICROARCH.md, "Static priority")
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(RA_K3_PRIO);
-#endif
 
     long long* ts = nullptr;
 #ifdef RA_TIMESTAMPS
@@ -173,11 +164,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     // Measured on one box (tools/bench_mlp.py): 470 400 points 0.894 -> 0.852 ms; with three active waves (tried) it is a wash.
     const int G = gridDim.x;
     const int full = ntiles / G, remt = ntiles - full * G;
-#ifdef RA_K3_NOSPREAD
-    const bool spread = false;
-#else
     const bool spread = NW == 8 && full >= 1 && remt > 0 && 4 * remt <= G;
-#endif
     int wact = NW, tail_start = 0;
     if (spread) {
         const int base = full * G * ST_TM;

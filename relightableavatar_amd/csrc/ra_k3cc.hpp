@@ -2,7 +2,7 @@
 // small launches of a surface-trace loop (one rank of eight, small images: a few hundred to a few thousand points per iteration).
 //
 // Why: a K3C tile is one wave walking 5808 dependent-issue MFMAs: 77 us of MFMA issue + 25 us of exposed weight-stream latency = 102 us
-// whatever the launch size (tools/bench_k3c.py, `-DRA_ABL=5`), and a 2 400-point launch occupies 150 of the chip's 1024 SIMDs.  Sixteen
+// whatever the launch size (tools/bench_k3c.py; round 4's stream ablation), and a 2 400-point launch occupies 150 of the chip's 1024 SIMDs.  Sixteen
 // iterations of that are the longest dependent chain of a rank's frame.  Here the 16 row blocks of a layer are dealt to the four SIMDs of
 // a CU (wave w owns row blocks 4 i + w), so a layer is four row blocks deep instead of sixteen:
 //   * weights: every wave walks a PRIVATE stream (ra_pack.cpp: its own row blocks in order, both heads in every stream), and because no
@@ -94,10 +94,9 @@ struct PipeReg {
 
     template <int FM>
     __device__ __forceinline__ void fetch() {
-        if (RA_ABL != 5) CcSlot<FM>::load(voff, cur);
+        CcSlot<FM>::load(voff, cur);
         cur += 1024;
-        if (RA_ABL == 7) { if (cur == beg + 4096) cur = beg; }
-        else if (cur == end) cur = beg;
+        if (cur == end) cur = beg;
     }
     template <int FH, int FL>
     __device__ __forceinline__ void ready() {
@@ -132,7 +131,6 @@ __device__ __forceinline__ void finish_16(const Acc16& a, u32x4 (&oH)[8], u32x4 
 }
 
 __device__ __forceinline__ void act_barrier() {
-    if (RA_ABL == 4) return;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 

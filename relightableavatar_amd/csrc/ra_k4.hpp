@@ -191,9 +191,6 @@ __device__ __forceinline__ void flush(const f32x16& accPrev, u32x4& o0, u32x4& o
 }
 
 __device__ __forceinline__ void tape_store2(EpiAux& aux, const u32x4& a, const u32x4& b) {
-#ifdef RA_EXP_NOTAPE
-    return;         // timing experiment: results are garbage
-#endif
     if (aux.st) {
         __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(aux.st));          // written once, read once by another kernel:
         __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(aux.st + 1024));   // streaming stores, -13 % forward time
@@ -429,12 +426,8 @@ struct TapeQ {
     template <int S>
     __device__ __forceinline__ void issue() {
         const char* p = base + off(next < 56 ? next : 55);
-#ifdef RA_EXP_NOLOAD
-        q[S][0] = u32x4{(unsigned)next, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; q[S][1] = q[S][0];      // timing experiment: results are garbage
-#else
         q[S][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
         q[S][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 1024));
-#endif
         ++next;
     }
     template <int K01>

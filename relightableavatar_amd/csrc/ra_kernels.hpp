@@ -35,8 +35,6 @@ struct HdqOut {
     float* mats;          // slot x 24 or nullptr
     float* raw_zero;      // nullable: n x raw_C rows that non-fine points zero (Network.forward's zeros outside dist_th)
     int raw_C;
-    float* keep;          // nullable: slot -> the point's coarse distance (sdf[idx] is overwritten by the fine level's blend; a later
-                          // re-query of the slot in compensated arithmetic blends against this value again)
     // debug (nullable): per point
     float* dbg_sdf_batch; // n x 3
     int* dbg_nn_batch;    // n x 3
@@ -65,34 +63,9 @@ struct TraceState {       // SoA per ray
     const float* tan_i;   // per ray (mode 1) or per light (mode 2) or nullptr -> scalar
     const int* light;     // mode 2
     unsigned char* stuck; // ray did not move in the last update (t clamped at far / near): the next query would repeat the last one
-    // nullable (shadow rays, ra_config.shadow_requery_tol > 0): bit 0 / bit 1 = this iteration's plain / claybook visibility candidate of
-    // the ray is DEFERRED — it sits in the re-query list (requery_select_kernel) and enters occ after the loop, from a distance computed
-    // in compensated arithmetic (requery_apply_kernel); the update must not take it from the plain-f16 distance
-    unsigned char* defer;
 };
 void launch_trace_init(const TraceState& ts, int n, const int* n_dev, const ra_trace_params& p, hipStream_t s);
 
-// Adaptive precision of the DFSS shadow rays (ra_config.shadow_requery_tol; light_visibility, sphere_tracing_renderer.py:157-179).
-// A penumbra candidate is cls = d * sharp / (2 t): near the surface (t ~ 3 cm, sharp <= 29) the 6e-5 distance error of plain f16
-// operands is amplified several hundred times.  After the fine level of a shadow iteration, requery_select looks at every fine slot:
-// where the amplification A = sharp / (2 max(t, near)) makes the error matter (A * err_rms > tol) AND the candidate can still lower
-// the ray's visibility (cls - A * err_max < occ), the slot is appended to a list (its big-pose point, its coarse distance, the ray
-// state the candidate is computed from) and the ray's `defer` bits keep trace_update from taking the candidate from the plain
-// distance.  After the loop ONE compensated distance launch (K3C) answers the list and requery_apply takes the minimum.
-// occ = min over candidates is order-independent, so the result is what an update with the accurate distance would have produced.
-struct RequeryList {
-    int cap;              // capacity (entries)
-    int* count;           // device counter, zero before the loop
-    int* idx;             // entry -> entry (the K3C launch scatters to sdf[idx[k]] = sdf[k])
-    float* bpts;          // entry x 3
-    float* sdf;           // entry: in = coarse distance, out = blended compensated distance
-    int* ray;             // entry -> shadow ray
-    float* t;             // entry: ray parameter of the query
-    float* d0;            // entry: the previous distance (claybook)
-};
-void launch_requery_select(const TraceState& ts, const float* sdf, const int* fine_idx, const float* bpts, const float* keep,
-                           const int* fine_count, int n, int iter, const ra_trace_params& p, float tol, const RequeryList& rl, hipStream_t s);
-void launch_requery_apply(const TraceState& ts, const RequeryList& rl, const ra_trace_params& p, hipStream_t s);
 void launch_trace_update(const TraceState& ts, const float* sdf, int n, const int* n_dev, int iter,
                          const ra_trace_params& p, hipStream_t s);
 

@@ -43,24 +43,53 @@ extern "C" int ra_shard_plan(const unsigned char* mask, int H, int W, int world,
     //    of the whole ray list (chunk_pos[r * n_edges + e] = how many of rank r's rays lie before ray edges[e])
     std::vector<long long> cnt(world, 0);
     std::vector<unsigned char> own_local;
+    if ((long long)H * W > 0x7fffffffLL) { ra_set_error("ra_shard_plan: frame too large"); return 1; }
     unsigned char* own = owner;
     if (!own) { own_local.resize((size_t)(P > 0 ? P : 1)); own = own_local.data(); }
+    // pass A: the frame pixel of every ray, eight pixels per test (most of a frame is outside the box)
+    std::vector<int> pix((size_t)(P > 0 ? P : 1));
     long long r = 0;
-    int e = 0;
-    for (int y = 0; y < H; ++y) {
-        const unsigned char* row = mask + (size_t)y * W;
-        const unsigned char* trk = tile_rank.data() + (size_t)(y / TILE) * tx;
-        for (int x = 0; x < W; ++x) {
-            if (!row[x]) continue;
-            if (r >= P) { ra_set_error("ra_shard_plan: the mask holds more pixels than P"); return 1; }
-            while (e < n_edges && edges[e] <= r) { for (int k = 0; k < world; ++k) chunk_pos[(size_t)k * n_edges + e] = cnt[k]; ++e; }
-            const unsigned char o = trk[x / TILE];
-            own[r++] = o;
-            ++cnt[o];
+    {
+        int* pp = pix.data();
+        for (int y = 0; y < H; ++y) {
+            const unsigned char* row = mask + (size_t)y * W;
+            const int f0 = y * W;
+            int x = 0;
+            for (; x + 8 <= W; x += 8) {
+                unsigned long long w;
+                memcpy(&w, row + x, 8);
+                if (w == 0ull) continue;
+                for (int k = 0; k < 8; ++k)
+                    if (row[x + k]) {
+                        if (r >= P) { ra_set_error("ra_shard_plan: the mask holds more pixels than P"); return 1; }
+                        pp[r++] = f0 + x + k;
+                    }
+            }
+            for (; x < W; ++x)
+                if (row[x]) {
+                    if (r >= P) { ra_set_error("ra_shard_plan: the mask holds more pixels than P"); return 1; }
+                    pp[r++] = f0 + x;
+                }
         }
     }
     if (r != P) { ra_set_error("ra_shard_plan: the mask holds fewer pixels than P"); return 1; }
-    for (; e < n_edges; ++e) for (int k = 0; k < world; ++k) chunk_pos[(size_t)k * n_edges + e] = cnt[k];
+    // pass B: owners and counts, chunk by chunk of the unsharded ray list
+    {
+        long long c8[256] = {0};
+        long long i = 0;
+        const unsigned char* tr = tile_rank.data();
+        for (int e = 0; e <= n_edges; ++e) {
+            const long long stop = e < n_edges ? (edges[e] < P ? edges[e] : P) : P;
+            for (; i < stop; ++i) {
+                const int f = pix[i], y = f / W, x = f - y * W;
+                const unsigned char o = tr[(size_t)(y / TILE) * tx + x / TILE];
+                own[i] = o;
+                ++c8[o];
+            }
+            if (e < n_edges) for (int k = 0; k < world; ++k) chunk_pos[(size_t)k * n_edges + e] = c8[k];
+        }
+        for (int k = 0; k < world; ++k) cnt[k] = c8[k];
+    }
     // 3. the exchange's index vectors: order = rays grouped by owner (original order inside), src[j] = where item j of `order` sits
     //    in the all_gather's output (rank * n_max + position in the rank's shard)
     long long n_max = 0;
@@ -68,17 +97,12 @@ extern "C" int ra_shard_plan(const unsigned char* mask, int H, int W, int world,
     for (int k = 0; k < world; ++k) { counts[k] = cnt[k]; offs[k + 1] = offs[k] + cnt[k]; if (cnt[k] > n_max) n_max = cnt[k]; }
     *n_max_out = n_max;
     std::vector<long long> fill(offs.begin(), offs.end() - 1);
-    for (long long i = 0; i < P; ++i) order[fill[own[i]]++] = i;
+    if (inds && !ground_pos) { ra_set_error("ra_shard_plan: inds needs ground_pos"); return 1; }
+    if (inds) for (long long i = 0; i < P; ++i) { const long long j = fill[own[i]]++; order[j] = i; inds[j] = ground_pos[pix[i]]; }
+    else for (long long i = 0; i < P; ++i) order[fill[own[i]]++] = i;
     for (int k = 0; k < world; ++k)
         for (long long j = offs[k]; j < offs[k + 1]; ++j) src[j] = (long long)k * n_max + (j - offs[k]);
-    // 4. with the ground pass: where every rank's human rays sit in its list of ground pixels (ground_pos: per frame pixel, its position
-    //    in its owner's full-frame pixel list — a function of the frame size only, cached by the caller)
-    if (inds) {
-        if (!ground_pos) { ra_set_error("ra_shard_plan: inds needs ground_pos"); return 1; }
-        std::vector<long long> pix((size_t)(P > 0 ? P : 1));
-        long long q = 0;
-        for (long long f = 0; f < (long long)H * W; ++f) if (mask[f]) pix[q++] = f;
-        for (long long j = 0; j < P; ++j) inds[j] = ground_pos[pix[order[j]]];
-    }
+    // (with the ground pass, inds = where every rank's human rays sit in its list of ground pixels, was filled beside `order`: ground_pos
+    // is per frame pixel its position in its owner's full-frame pixel list — a function of the frame size only, cached by the caller)
     return 0;
 }

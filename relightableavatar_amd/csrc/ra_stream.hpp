@@ -5,12 +5,6 @@
 #include "ra_common.hpp"
 #include <type_traits>
 
-#ifndef RA_SCHED
-#define RA_SCHED 0     // 1: pin the per-MFMA-slot instruction order with sched_barrier(0) (A/B: 1 % slower)
-#endif
-#ifndef RA_ABL
-#define RA_ABL 0      // compile-time ablations for timing experiments (tools/): results are garbage when != 0
-#endif
 
 namespace {
 
@@ -78,7 +72,7 @@ __device__ __forceinline__ float sp_finish(float c, float z) { return __builtin_
 
 template <int ACT>
 __device__ __forceinline__ float act(float z) {
-    if (ACT == ACT_RELU || RA_ABL == 1) return max0(z);
+    if (ACT == ACT_RELU) return max0(z);
     return sp_finish(__builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(z)), z);
 }
 
@@ -118,41 +112,15 @@ struct Pipe {
         const char* sb = g;
         asm volatile("" : "+s"(sb));            // keeps the 244 per-stage addresses from being precomputed (and spilled)
         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + ring_slot * ST_STAGE_BYTES);
-        const char* src = sb + (size_t)(RA_ABL == 7 ? (stream_stage & 1) : stream_stage) * ST_STAGE_BYTES;
-        if (RA_ABL != 5 && RA_ABL != 6) {
+        const char* src = sb + (size_t)stream_stage * ST_STAGE_BYTES;
 #pragma unroll
-            for (int j = 0; j < FPW / 2; ++j) glds16x2(src, voff + j * 2048, voff + j * 2048 + 1024, dst + j * 2048);
-        }
+        for (int j = 0; j < FPW / 2; ++j) glds16x2(src, voff + j * 2048, voff + j * 2048 + 1024, dst + j * 2048);
     }
     // the next stage of the stream becomes readable; the ring slot two stages back is refilled ST_AHEAD stages ahead.
     // The stage position is run-time state (SGPRs), so the code below only depends on a fragment's position in its stage.
-#ifdef RA_BAR2
-    // EXPERIMENT (round 5, tools/ab_k3_variants.sh): one barrier per TWO stages.  At an even stage s the wave waits for its pieces of
-    // stages s and s + 1, the barrier makes both readable, and stages s + 5, s + 6 refill the slots of s - 3, s - 2 (s - 1 may still be
-    // read: its last ST_PF fragments are requested but not consumed).  Five stages in flight instead of six, half the barriers.
     __device__ __forceinline__ void sync_stage() {
-        slot = (slot + 1) & (ST_RING - 1);
-        sstage = sstage + 1 == STAGES ? 0 : sstage + 1;
-        if ((sstage & 1) == 0) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * 3) : "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            int a5 = sstage + 5, a6 = sstage + 6;
-            a5 = a5 >= STAGES ? a5 - STAGES : a5;
-            a6 = a6 >= STAGES ? a6 - STAGES : a6;
-            issue(a5, (slot + 5) & (ST_RING - 1));
-            issue(a6, (slot + 6) & (ST_RING - 1));
-        }
-        rd = ring + slot * ST_STAGE_BYTES;
-    }
-#else
-    __device__ __forceinline__ void sync_stage() {
-#ifdef RA_SYNC_DRAIN
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // experiment: no counted wait
-#else
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1)) : "memory");
-#endif
-        if (RA_ABL != 4 && RA_ABL != 6) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         slot = (slot + 1) & (ST_RING - 1);
         sstage = sstage + 1 == STAGES ? 0 : sstage + 1;
@@ -161,7 +129,6 @@ struct Pipe {
         issue(ahead, (slot + ST_AHEAD) & (ST_RING - 1));
         rd = ring + slot * ST_STAGE_BYTES;
     }
-#endif
     // FM: position of the fragment in its 16-fragment stage
     template <int FM>
     __device__ __forceinline__ void fetch() {
@@ -204,7 +171,7 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
             // transcendental chain would hold back the next MFMA).  LAST: last slot whose results may still be written.
             static_for<0, 16>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
-                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS && RA_ABL != 1 && RA_ABL != 3 && RA_ABL != 6;
+                constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
                 constexpr int DEPTH = SP ? 3 : 0;
                 constexpr int LAST = (KS == 4) ? 3 : (EARLY ? ELAST : KS - 1);
                 constexpr int s0 = (KS == 4) ? 0 : (e * (LAST - DEPTH + 1)) / 16;
@@ -222,12 +189,12 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
                     // f16: ReLU AFTER the pack (v_cvt_pk + v_pk_max_f16: 1.0 instead of 1.5 VALU per element).  Rounding is monotone
                     // and keeps the sign, so max(round(z), 0) == round(max(z, 0)): bitwise identical distances on 200 k points,
                     // -6.6 % VALU instructions, -0.5 .. -0.8 % kernel time (same-box A/B) — VALU count is not what bounds K3.
-                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e] = (Tr<E>::is_f16 || RA_ABL == 3 || RA_ABL == 6) ? accPrev[e] : max0(accPrev[e]);
+                    if constexpr ((KS == 4 ? e / 4 : s0) == ks) ta[e] = Tr<E>::is_f16 ? accPrev[e] : max0(accPrev[e]);
                 }
                 constexpr int sdone = (KS == 4) ? (SP ? 3 : e / 4) : s0 + DEPTH;
                 if constexpr ((e & 1) && sdone == ks) {
-                    unsigned w = (RA_ABL == 3 || RA_ABL == 6) ? __builtin_bit_cast(unsigned, ta[e]) : pack2<E>(ta[e - 1], ta[e]);
-                    if constexpr (!SP && Tr<E>::is_f16 && RA_ABL != 3 && RA_ABL != 6) {
+                    unsigned w = pack2<E>(ta[e - 1], ta[e]);
+                    if constexpr (!SP && Tr<E>::is_f16) {
                         typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
                         h2_t v = __builtin_bit_cast(h2_t, w);
                         v = __builtin_elementwise_max(v, h2_t{(_Float16)0, (_Float16)0});
@@ -237,7 +204,6 @@ __device__ __forceinline__ void row_block(PipeT& P, f32x16& acc, const f32x16& a
                 }
             });
         }
-        if (RA_SCHED) __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -348,9 +314,7 @@ __device__ __forceinline__ void layer_pairs(PipeT& P, f32x16& a0, f32x16& a1, f3
 // One accumulator chain: a second chain for the two small products (round 4, removed) measured slower on both tiles — 165 against 150 us on
 // the 32x32 tile (extra AGPR traffic), 106 against 98 us for 2 400 points on this one — so the chain of dependent MFMAs is not what bounds a
 // lone wave here; the ~5 non-MFMA instructions it has to issue per 16-cycle MFMA are (5808 MFMAs in 98 us = 37 cycles each).
-#ifndef RA_K3C_E0
-#define RA_K3C_E0 2          // MFMA slots before the pending epilogue first touches the previous accumulator (its last MFMA is still in the pipe)
-#endif
+constexpr int K3C_E0 = 2;    // MFMA slots before the pending epilogue first touches the previous accumulator (its last MFMA is still in the pipe)
 __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // One row block: 3 KS MFMAs (fragments FM0.. of the stage, [hi | lo] per k-step) into `acc`, interleaved with the pending epilogue of
@@ -390,7 +354,7 @@ __device__ __forceinline__ void row_block_16(PipeT& P, Acc16& acc, const Acc16& 
                 constexpr bool SP = ACT_PREV == ACT_SOFTPLUS;
                 constexpr int DA = SP ? 3 : 0;                       // slots until the activation's value exists
                 constexpr int LAST = EARLY ? ELAST : NS - 1;         // last slot that may still write the outputs
-                constexpr int E0 = NS >= 24 ? RA_K3C_E0 : 0;
+                constexpr int E0 = NS >= 24 ? K3C_E0 : 0;
                 constexpr int s0 = E0 + (e * (LAST - E0 - (DA + 2) + 1)) / 4;
                 if constexpr (SP) {
                     if constexpr (s0 == i) ta[e] = __builtin_amdgcn_exp2f(accPrev.val(e));

@@ -34,7 +34,6 @@ __global__ void trace_init_kernel(TraceState ts, int n_launch, const int* n_dev,
     ts.d0[i] = 1e9f;
     ts.occ[i] = 1.f;
     if (ts.stuck) ts.stuck[i] = 0;
-    if (ts.defer) ts.defer[i] = 0;
     if (ts.dt) ts.dt[i] = 1e9f;
     if (ts.st) ts.st[i] = fr;
     if (ts.ot) ts.ot[i] = fr;
@@ -63,9 +62,7 @@ __global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf
     float off = ts.off ? ts.off[i] : p.offset;
     float rlx = ts.rlx ? ts.rlx[i] : p.relax;
     float ot = ts.ot ? ts.ot[i] : 0.f;
-    // candidates that wait in the re-query list for their compensated distance (requery_select_kernel) are not taken from this one
-    const unsigned df = (SOFT && ts.defer) ? ts.defer[i] : 0u;
-    if (SOFT && p.clay_book && iter >= p.shadow_skip_iter && !(df & 2u)) {    // :157-172
+    if (SOFT && p.clay_book && iter >= p.shadow_skip_iter) {    // :157-172
         const float dx0 = d0 + rlx * d0 + off;
         const float dx1 = d1 + rlx * d1 + off;
         const float dy = (dx1 * dx1) / (2.f * dx0);
@@ -75,7 +72,7 @@ __global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf
         const bool msk = (cls < occ) && (dy < t) && (dx1 > 0.f) && (dx0 > 0.f) && (dx > 0.f) && (dy > 0.f) && (dy < dx0);
         if (msk) { ot = t - dy; occ = cls; }
     }
-    if (iter >= p.shadow_skip_iter && !(df & 1u)) {             // :175-179
+    if (iter >= p.shadow_skip_iter) {                           // :175-179
         const float cls = fmaxf(d1, 0.f) / fmaxf(fmaxf(t, nr), p.eps) / tan2;
         if (cls < occ) { ot = t; occ = cls; }
     }
@@ -105,110 +102,10 @@ __global__ void trace_update_kernel(TraceState ts, const float* __restrict__ sdf
     // a ray clamped at far (or near) queries the same point again: the distance is already known, the state machine
     // still runs on it (exact), only the query is skipped
     // A shadow ray whose visibility reached 0 is decided (occ = min(occ, cls >= 0) and only occ is read back): no more queries.
-    const bool stuck = t == t_prev || (SOFT && occ == 0.f);
-    if (ts.stuck) ts.stuck[i] = stuck ? 1 : 0;
-    // a ray that moves is looked at again by the next iteration's selection; one that does not is not queried again and evaluates the
-    // SAME plain candidate from the same distance next time (already in the list once), a claybook candidate from (d1, d1) — not listed
-    if (SOFT && df) ts.defer[i] = stuck ? (unsigned char)(df & 1u) : (unsigned char)0;
+    if (ts.stuck) ts.stuck[i] = (t == t_prev || (SOFT && occ == 0.f)) ? 1 : 0;
     ts.d0[i] = d1;
     ts.occ[i] = occ;
     if (ts.ot) ts.ot[i] = ot;
-}
-
-// ------------------------------------------------------------------------------------------ adaptive precision of the shadow rays
-// the two visibility candidates of one DFSS iteration (sphere_tracing_renderer.py:157-179) from the distances d0 (previous) and d1 at
-// ray parameter t: cls_clay (valid: the claybook conditions except cls < occ), cls_plain; den_*: the denominators (for the error bound)
-struct ShadowCand { float clay, plain, a_clay, a_plain; bool clay_ok; };
-__device__ __forceinline__ ShadowCand shadow_candidates(float d0, float d1, float t, float nr, float tan2, float off, float rlx, float eps, bool clay_book) {
-    ShadowCand c;
-    c.a_plain = 1.f / fmaxf(fmaxf(t, nr), eps) / tan2;
-    c.plain = fmaxf(d1, 0.f) / fmaxf(fmaxf(t, nr), eps) / tan2;
-    c.clay = 0.f; c.a_clay = 0.f; c.clay_ok = false;
-    if (clay_book) {
-        const float dx0 = d0 + rlx * d0 + off;
-        const float dx1 = d1 + rlx * d1 + off;
-        const float dy = (dx1 * dx1) / (2.f * dx0);
-        const float dx = (sqrtf(dx1 * dx1 - dy * dy) - off) / (1.f + rlx);
-        const float den = fmaxf(fmaxf(t - dy, nr), eps);
-        c.clay = fmaxf(dx, 0.f) / den / tan2;
-        c.a_clay = 1.f / den / tan2;
-        c.clay_ok = (dy < t) && (dx1 > 0.f) && (dx0 > 0.f) && (dx > 0.f) && (dy > 0.f) && (dy < dx0);
-    }
-    return c;
-}
-
-// distance error of the plain-f16 fine level against fp32 (5.9e-5 rms, 2.4e-4 max on 20 000 near-surface points)
-constexpr float RQ_ERR_RMS = 6.0e-5f, RQ_ERR_MAX = 2.5e-4f;
-
-__global__ void requery_select_kernel(TraceState ts, const float* __restrict__ sdf, const int* __restrict__ fine_idx, const float* __restrict__ bpts,
-                                      const float* __restrict__ keep, const int* __restrict__ fine_count, int n_launch, ra_trace_params p, float tol,
-                                      RequeryList rl) {
-    const int j = blockIdx.x * TPB + threadIdx.x;
-    const int n = min(*fine_count, n_launch);
-    bool flag = false;
-    int i = 0;
-    float t = 0.f, d0 = 0.f;
-    if (j < n) {
-        i = fine_idx[j];
-        const float occ = ts.occ[i];
-        if (occ > 0.f) {
-            const float d1 = sdf[i];
-            d0 = ts.d0[i];
-            t = ts.t[i];
-            const float nr = ts.near_[i];
-            const float ti = ts.tan_i ? (ts.light ? ts.tan_i[ts.light[i]] : ts.tan_i[i]) : p.tan_i;
-            const float tan2 = (1.f / (p.tan_i_multiplier * ti)) * 2.f;
-            const ShadowCand c = shadow_candidates(d0, d1, t, nr, tan2, p.offset, p.relax, p.eps, p.clay_book != 0);
-            // the error matters (amplified rms over the tolerance) and the candidate can still lower the visibility
-            flag = (c.a_plain * RQ_ERR_RMS > tol) && (c.plain - c.a_plain * RQ_ERR_MAX < occ);
-            // claybook: d1 enters dx and dy; twice the plain bound covers its sensitivity away from the degenerate dy -> dx1
-            if (p.clay_book && c.clay_ok) flag = flag || ((c.a_clay * RQ_ERR_RMS > tol) && (c.clay - 2.f * c.a_clay * RQ_ERR_MAX < occ));
-        }
-        // the slot is looked at: whatever an earlier iteration left in the ray's bits is replaced
-        if (!flag) ts.defer[i] = 0;
-    }
-    const unsigned long long m = __ballot(flag);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63, cnt = __popcll(m);
-    int base = -1;
-    if (lane == 0) {                 // reserve cnt entries, or none: a full list leaves the wave's candidates to the plain distance
-        int old = *rl.count;
-        while (old + cnt <= rl.cap) {
-            const int seen = atomicCAS(rl.count, old, old + cnt);
-            if (seen == old) { base = old; break; }
-            old = seen;
-        }
-    }
-    base = __shfl(base, 0);
-    if (!flag) return;
-    if (base < 0) { ts.defer[i] = 0; return; }
-    const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-    rl.idx[k] = k;
-    rl.bpts[3 * k] = bpts[3 * j]; rl.bpts[3 * k + 1] = bpts[3 * j + 1]; rl.bpts[3 * k + 2] = bpts[3 * j + 2];
-    rl.sdf[k] = keep[j];
-    rl.ray[k] = i;
-    rl.t[k] = t;
-    rl.d0[k] = d0;
-    ts.defer[i] = 3;                 // both candidates of this iteration come from the compensated distance
-}
-
-// after the loop: the listed candidates from their compensated distances; occ = min(occ, cls) is order-independent (cls >= 0: the float
-// minimum is the minimum of the bit patterns)
-__device__ __forceinline__ void requery_apply_one(const TraceState& ts, const RequeryList& rl, const ra_trace_params& p, int k) {
-    const int i = rl.ray[k];
-    const float d1 = rl.sdf[k], d0 = rl.d0[k], t = rl.t[k];
-    const float nr = ts.near_[i];
-    const float ti = ts.tan_i ? (ts.light ? ts.tan_i[ts.light[i]] : ts.tan_i[i]) : p.tan_i;
-    const float tan2 = (1.f / (p.tan_i_multiplier * ti)) * 2.f;
-    const ShadowCand c = shadow_candidates(d0, d1, t, nr, tan2, p.offset, p.relax, p.eps, p.clay_book != 0);
-    float cls = c.plain;
-    if (c.clay_ok && c.clay < cls) cls = c.clay;
-    if (!(cls > 0.f)) cls = 0.f;
-    atomicMin(reinterpret_cast<int*>(ts.occ + i), __float_as_int(cls));
-}
-__global__ void requery_apply_kernel(TraceState ts, RequeryList rl, ra_trace_params p) {
-    const int n = min(*rl.count, rl.cap);
-    for (int k = blockIdx.x * TPB + threadIdx.x; k < n; k += gridDim.x * TPB) requery_apply_one(ts, rl, p, k);
 }
 
 // ------------------------------------------------------------------------------------------ surface
@@ -890,18 +787,6 @@ void launch_trace_update(const TraceState& ts, const float* sdf, int n, const in
     if (n <= 0) return;
     if (p.soft_shadow) hipLaunchKernelGGL(trace_update_kernel<true>, grid_for(n), dim3(TPB), 0, s, ts, sdf, n, n_dev, iter, p);
     else hipLaunchKernelGGL(trace_update_kernel<false>, grid_for(n), dim3(TPB), 0, s, ts, sdf, n, n_dev, iter, p);
-}
-
-void launch_requery_select(const TraceState& ts, const float* sdf, const int* fine_idx, const float* bpts, const float* keep,
-                           const int* fine_count, int n, int iter, const ra_trace_params& p, float tol, const RequeryList& rl, hipStream_t s) {
-    if (n <= 0 || iter < p.shadow_skip_iter) return;            // no visibility candidate before shadow_skip_iter (:175)
-    hipLaunchKernelGGL(requery_select_kernel, grid_for(n), dim3(TPB), 0, s, ts, sdf, fine_idx, bpts, keep, fine_count, n, p, tol, rl);
-}
-
-void launch_requery_apply(const TraceState& ts, const RequeryList& rl, const ra_trace_params& p, hipStream_t s) {
-    if (rl.cap <= 0) return;
-    const long long blocks = ((long long)rl.cap + TPB - 1) / TPB;      // cap is an upper bound: a bounded grid strides over the real count
-    hipLaunchKernelGGL(requery_apply_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(TPB), 0, s, ts, rl, p);
 }
 
 void launch_surface_finish(const float* ray_o, const float* ray_d, const float* st, const float* occ, int P, float* surf,

@@ -66,8 +66,7 @@ class Engine:
                       tonemapping=int(cfg.tonemapping_rendering), bg_brightness=cfg.bg_brightness,
                       mlp_f16=int(cfg.mlp_dtype == 'f16'), query_skip=int(cfg.get('query_skip', True)),
                       k4_batch_slots=int(cfg.get('k4_batch_slots', 0)), trace_precision=int(cfg.get('trace_precision', 1)),
-                      clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)),
-                      shadow_requery_tol=float(cfg.get('shadow_requery_tol', 2e-3)))
+                      clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)))
         assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None

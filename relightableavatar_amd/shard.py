@@ -141,6 +141,66 @@ def _frame_of(batch):
     return mask, H, W
 
 
+_NUMPY_PLAN = False      # tests: True forces the numpy restatement below (the two must agree element for element)
+
+
+def _chunk_edges(total: int, chunk_size: int):
+    """chunk boundaries of a list of `total` items (chunkify's size rule, net_utils.py:323)"""
+    actual = math.ceil(total / math.ceil(total / chunk_size))
+    return np.minimum(np.arange(0, total + actual, actual), total).astype(np.int64)
+
+
+def _make_plan_native(m: np.ndarray, P: int, world: int, H: int, W: int, device, ground: bool, render_chunk_size):
+    """the per-frame part of the plan in ONE pass over the mask (C ABI: ra_shard_plan, csrc/ra_shard.cpp), its index vectors written
+    straight into the pinned staging block that is uploaded with one non-blocking copy.  Returns None when the mask does not hold P
+    pixels (the caller then deals runs of rays)."""
+    import ctypes as C
+    from . import _lib
+    mb = np.ascontiguousarray(m.view(np.uint8) if m.dtype == np.bool_ else (m != 0).astype(np.uint8))
+    if int(np.count_nonzero(mb)) != P:
+        return None
+    cuda = torch.device(device).type == 'cuda'
+    fg = _frame_ground(_frame_deal(H, W, world, device), H, W, world, device) if ground else None
+    n_vec = 3 if ground else 2
+    stage = torch.empty(max(n_vec * P, 1), dtype=torch.int64, pin_memory=cuda)
+    sv = stage.numpy()
+    owner = np.empty(max(P, 1), np.uint8)
+    counts = np.zeros(world, np.int64)
+    edges = _chunk_edges(P, render_chunk_size) if (render_chunk_size is not None and P > 0) else np.zeros(0, np.int64)
+    cpos = np.zeros(max(world * edges.size, 1), np.int64)
+    n_max = C.c_longlong(0)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    base = stage.data_ptr()
+    _lib.check(_lib.lib().ra_shard_plan(ptr(mb), H, W, world, int(bool(ground)), P, ptr(fg.pos) if ground else None,
+                                        ptr(edges) if edges.size else None, int(edges.size), ptr(owner), C.c_void_p(base), C.c_void_p(base + 8 * P),
+                                        C.c_void_p(base + 16 * P) if ground else None, ptr(counts), ptr(cpos) if edges.size else None, C.byref(n_max)),
+               'ra_shard_plan')
+    counts_l = counts.tolist()
+    offs = np.concatenate([[0], np.cumsum(counts)]).tolist()
+    dev = stage.to(device, non_blocking=True) if cuda else stage
+    per_rank = lambda t, o: [t[o[r]:o[r + 1]] for r in range(world)]
+    order_d, src_d = dev[:P], dev[P:2 * P]
+    pl = dotdict(P=P, world=world, H=H, W=W, counts=counts_l, n_max=int(n_max.value), idx=per_rank(order_d, offs), order=order_d, src=src_d,
+                 idx_host=per_rank(sv[:P], offs), owner_host=owner[:P], _stage=stage)
+    pl.owner = torch.from_numpy(owner[:P].astype(np.int64))
+    if edges.size:
+        cp = cpos[:world * edges.size].reshape(world, edges.size).tolist()
+        pl.render_chunks = [[(cp[r][i], cp[r][i + 1]) for i in range(edges.size - 1)] for r in range(world)]
+    elif render_chunk_size is not None:
+        pl.render_chunks = [[] for _ in range(world)]
+    if ground:
+        F = H * W
+        inds_d = dev[2 * P:3 * P]
+        g = dotdict(F=F, counts=fg.counts, n_max=fg.n_max, idx=per_rank(fg.order, fg.offs), order=fg.order, src=fg.src, idx_host=fg.idx,
+                    inds=per_rank(inds_d, offs))
+        if render_chunk_size is not None:
+            if render_chunk_size not in fg.chunks:
+                fg.chunks[render_chunk_size] = [_chunk_ranges(i, F, render_chunk_size) for i in fg.idx]
+            g.chunks = fg.chunks[render_chunk_size]
+        pl.ground = g
+    return _mark_ready(pl, device)
+
+
 def make_plan(P: int, world: int, batch=None, device=None, mask=None, ground: bool = False, render_chunk_size=None, use_cache: bool = True) -> dotdict:
     """The frame's ownership + exchange index vectors.  `mask`: the frame's mask_at_box on the HOST (torch / numpy) — what a
     loader hands over; when omitted it is taken from `batch` (a device-resident mask costs one D2H copy = one sync; pass the
@@ -162,6 +222,14 @@ def make_plan(P: int, world: int, batch=None, device=None, mask=None, ground: bo
         hit = _PLANS.get(key)
         if hit is not None:
             return hit
+    if m is not None and world <= 256 and not _NUMPY_PLAN:
+        pl = _make_plan_native(m, P, world, H, W, device, ground, render_chunk_size)
+        if pl is not None:
+            if key is not None:
+                if len(_PLANS) > 16:
+                    _PLANS.clear()
+                _PLANS[key] = pl
+            return pl
     pix = None
     if m is not None:
         pix = np.flatnonzero(m)

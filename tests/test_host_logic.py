@@ -362,7 +362,7 @@ def test_ctypes_structs_match_the_header():
     import tempfile
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
-    structs = {'ra_config': 'shadow_requery_tol', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
+    structs = {'ra_config': 'clip_far', 'ra_frame': 'n_verts', 'ra_trace_params': 'dist_th', 'ra_render_out': 'volume_roughness',
                'ra_sphere_params': 'box_start', 'ra_ground_params': 'box_start', 'ra_ground_out': 'ldot', 'ra_pose_in': 'bounds_padding',
                'ra_pose_out': 'Th', 'ra_image_params': 'tbounds', 'ra_counters': 'n_fine_sdf_comp'}
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "relightableavatar.h"\nint main(){\n' + \
@@ -378,6 +378,55 @@ def test_ctypes_structs_match_the_header():
         assert getattr(cls, structs[name]).offset == int(off), (name, structs[name])
 
 
+def test_native_plan_equals_the_numpy_plan():
+    """shard.make_plan's per-frame part runs in ONE C call (ra_shard_plan, csrc/ra_shard.cpp: host code, no GPU); the numpy restatement
+    it replaced stays as its checker: ownership, exchange index vectors, per-rank chunk ranges and ground-pass positions must agree
+    element for element — odd frame sizes, masks with holes, 1 .. 8 ranks, with and without the ground pass and render chunks."""
+    import numpy as np
+    from relightableavatar_amd.base_utils import dotdict
+    rng = np.random.default_rng(0)
+
+    def same(a, b, path=''):
+        if isinstance(a, dict):
+            for k in a:
+                if k.startswith('_') or k in ('ready', 'owner_host'):
+                    continue
+                assert k in b, (path, k)
+                same(a[k], b[k], path + '/' + k)
+        elif isinstance(a, (list, tuple)):
+            assert len(a) == len(b), (path, len(a), len(b))
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, f'{path}[{i}]')
+        elif torch.is_tensor(a):
+            assert torch.equal(a.cpu(), torch.as_tensor(b).cpu()), path
+        elif isinstance(a, np.ndarray):
+            assert np.array_equal(a, np.asarray(b)), path
+        else:
+            assert a == b, (path, a, b)
+
+    try:
+        for H, W in ((64, 64), (60, 52), (130, 67), (256, 256)):
+            yy, xx = np.mgrid[0:H, 0:W]
+            for world in (1, 2, 3, 8):
+                for ground in (False, True):
+                    for chunk in (None, 700, 65536):
+                        m = ((yy - H / 2) ** 2 + (xx - W / 2.3) ** 2 < (0.3 * H) ** 2) & (rng.random((H, W)) > 0.1)
+                        P = int(m.sum())
+                        batch = dotdict(mask_at_box=torch.from_numpy(m.reshape(1, -1)), meta=dotdict(H=torch.tensor([H]), W=torch.tensor([W])))
+                        shard._NUMPY_PLAN = False
+                        a = shard.make_plan(P, world, batch, ground=ground, render_chunk_size=chunk, use_cache=False)
+                        assert '_stage' in a                      # the native path ran
+                        shard._NUMPY_PLAN = True
+                        b = shard.make_plan(P, world, batch, ground=ground, render_chunk_size=chunk, use_cache=False)
+                        same(dict(b), dict(a))
+        # a mask that does not hold P pixels: no tile deal, runs of rays (both paths)
+        shard._NUMPY_PLAN = False
+        c = shard.make_plan(P - 1, 2, batch, use_cache=False)
+        assert '_stage' not in c and sum(c.counts) == P - 1
+    finally:
+        shard._NUMPY_PLAN = False
+
+
 def test_default_config_matches_the_python_defaults():
     """ra_default_config() (no ctx, no GPU) hands a C caller the documented defaults — a zero-initialised ra_config is NOT the default
     (trace_precision 0, clip_far 0: rejected by ra_set_config) — and they are the values make_cfg('relight') sends through the binding."""
@@ -387,7 +436,7 @@ def test_default_config_matches_the_python_defaults():
     assert _lib.lib().ra_default_config(C.byref(c)) == 0
     cfg = make_cfg('relight')
     for k in ('xyz_res', 'sdf_res', 'view_res', 'n_bones', 'resd_limit', 'blend_radius', 'albedo_slope', 'albedo_bias', 'roughness_slope',
-              'roughness_bias', 'fresnel_f0', 'shading_albedo', 'albedo_multiplier', 'bg_brightness', 'trace_precision', 'shadow_requery_tol',
+              'roughness_bias', 'fresnel_f0', 'shading_albedo', 'albedo_multiplier', 'bg_brightness', 'trace_precision',
               'k4_batch_slots'):
         assert abs(float(getattr(c, k)) - float(cfg[k])) < 1e-6, k
     assert c.relight == 1 and c.mlp_f16 == 1 and c.query_skip == 1 and c.tonemapping == 1 and c.lambert_only == 0 and c.glossy_only == 0
