@@ -46,14 +46,15 @@ extern "C" int ra_shard_plan(const unsigned char* mask, int H, int W, int world,
     if ((long long)H * W > 0x7fffffffLL) { ra_set_error("ra_shard_plan: frame too large"); return 1; }
     unsigned char* own = owner;
     if (!own) { own_local.resize((size_t)(P > 0 ? P : 1)); own = own_local.data(); }
-    // pass A: the frame pixel of every ray, eight pixels per test (most of a frame is outside the box)
-    std::vector<int> pix((size_t)(P > 0 ? P : 1));
+    // pass A: the frame pixel and the tile of every ray, eight pixels per test (most of a frame is outside the box)
+    std::vector<int> pix((size_t)(P > 0 ? P : 1)), tile_of((size_t)(P > 0 ? P : 1));
     long long r = 0;
     {
         int* pp = pix.data();
+        int* tt = tile_of.data();
         for (int y = 0; y < H; ++y) {
             const unsigned char* row = mask + (size_t)y * W;
-            const int f0 = y * W;
+            const int f0 = y * W, t0 = (y / TILE) * tx;
             int x = 0;
             for (; x + 8 <= W; x += 8) {
                 unsigned long long w;
@@ -62,12 +63,14 @@ extern "C" int ra_shard_plan(const unsigned char* mask, int H, int W, int world,
                 for (int k = 0; k < 8; ++k)
                     if (row[x + k]) {
                         if (r >= P) { ra_set_error("ra_shard_plan: the mask holds more pixels than P"); return 1; }
+                        tt[r] = t0 + x / TILE;
                         pp[r++] = f0 + x + k;
                     }
             }
             for (; x < W; ++x)
                 if (row[x]) {
                     if (r >= P) { ra_set_error("ra_shard_plan: the mask holds more pixels than P"); return 1; }
+                    tt[r] = t0 + x / TILE;
                     pp[r++] = f0 + x;
                 }
         }
@@ -81,8 +84,7 @@ extern "C" int ra_shard_plan(const unsigned char* mask, int H, int W, int world,
         for (int e = 0; e <= n_edges; ++e) {
             const long long stop = e < n_edges ? (edges[e] < P ? edges[e] : P) : P;
             for (; i < stop; ++i) {
-                const int f = pix[i], y = f / W, x = f - y * W;
-                const unsigned char o = tr[(size_t)(y / TILE) * tx + x / TILE];
+                const unsigned char o = tr[tile_of[i]];
                 own[i] = o;
                 ++c8[o];
             }
