@@ -682,6 +682,26 @@ def fp32_unstable_rays(net: OracleNet, batch, trials: int = 32, noise: float = 3
     return bad
 
 
+def fp32_flip_probability(net: OracleNet, batch, rays, noise: float, trials: int = 64, tol: float = 1e-4, seed: int = 1):
+    """For the listed rays of `batch`: the fraction of `trials` runs in which gaussian noise of `noise` on the distances the surface trace
+    reads moves `st` by more than `tol` or flips the hit status (see fp32_unstable_rays).  The rays are traced on their own (rays are
+    independent units).  Returns a list of floats."""
+    if len(rays) == 0:
+        return []
+    sub = type(batch)(batch)
+    idx = torch.as_tensor(list(rays), dtype=torch.long)
+    for k in ('ray_o', 'ray_d', 'near', 'far'):
+        sub[k] = batch[k][:, idx].contiguous()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        st0, occ0 = surface_trace(net, sub)
+        flips = torch.zeros_like(st0)
+        for _ in range(trials):
+            st, occ = surface_trace(net, sub, noise, g)
+            flips += (((st - st0).abs() > tol) | ((occ < 1) != (occ0 < 1))).float()
+    return [float(v) / trials for v in flips.reshape(-1)]
+
+
 def light_visibility(net: OracleNet, surf, norm, acc, fr, bbox, lvis_cfg, sdf_fn_factory):
     """light_visibility sphere_tracing_renderer.py:265-344. surf,norm (P,3), acc (P) -> lvis, ldot (L,P)."""
     c = net.cfg

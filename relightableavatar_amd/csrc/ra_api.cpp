@@ -271,13 +271,14 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     int err = 0;
     int* fine_idx = c->buf<int>("fine_idx", n, &err);
     float* bpts = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
+    float* smpl = smooth ? c->buf<float>("fine_smpl", (size_t)n, &err) : nullptr;
     if (err) return 1;
     HdqOut out{};
-    out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
+    out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts; out.smpl = smpl;
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     MlpIO io{};
-    io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
+    io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.smpl = smpl; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     fine_level(c, io, n, precise(c, what), s);
     return 0;

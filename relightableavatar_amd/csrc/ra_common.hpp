@@ -78,6 +78,7 @@ struct MlpIO {
     const int* idx;         // n_slots: point index of each slot
     const int* count;       // device: number of valid slots
     float* sdf;             // per point: in = coarse smpl sdf, out = blended HDQ sdf
+    const float* smpl;      // nullable: per SLOT the coarse smpl sdf (= sdf[idx[slot]] on entry): read beside bpts / idx instead of through idx
     float dist_th;
     int smooth;
     float resd_limit;

@@ -11,18 +11,27 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
                                        amplify sdf noise (occ = 500 d / t), so frame maps are judged by the
                                        fraction of pixels within tolerance + PSNR, not by max error
   frames ............................. SURVEY.md:409 contract for the 16-bit path: rgb PSNR >= 50 dB and max |err| <= 1e-2.
-      * asserted as such on the well-conditioned frames (smooth skinning field, where the reference's own sphere trace
-        converges): frame_relight_smooth, frame_novel_ground, volume frames;
-      * on the SURVEY 8d body (white noise in the skinning logits -> the world -> big-pose warp jumps by ~1 cm between
-        neighbouring query points, the REFERENCE's trace ends in a limit cycle on ~9 % of the hit rays, and a 1e-4 distance perturbation flips the
-        cycle's phase on ~1 % of the pixels) no 16-bit-operand arithmetic reaches it: tests/golden/precision_floor.json holds
-        the result of the operand-rounding emulation of the oracle (tools/precision_floor.py, SURVEY.md:305's experiment) on
-        the same frames — 50.6 dB / max 4.7e-2 with f16, 40.2 dB with bf16.  Round 4: fp32 itself IS stable on all but ~0.5 % of those rays
-        (tools/precision_tiers.py: a float64-accumulated oracle agrees with the fp32 one to 89-110 dB), and compensating ONLY the surface
-        trace's distance queries (K3C, csrc/ra_k3c.hpp: f16 hi + lo operand pairs, 2 % of a frame's fine queries) reaches the contract:
-        every frame test asserts PSNR >= 50 dB over all rays and max |err| <= 1e-2 over every ray fp32 pins (assert_contract; the rays it
-        does not pin — coin tosses of the reference's own closest-approach rule — are listed in tests/golden/fp32_unstable_rays.json,
-        tools/fp32_stability.py).  Measured: frame_relight 63.8 dB / 3.3e-3 (plain f16: 50.7 / 4.7e-2), frame_novel 66.8-70.3 dB (46-52).
+      What assert_contract() asserts, exactly: PSNR >= 50 dB AND max |err| <= 1e-2 over the rays whose reference value fp32 itself pins,
+      and PSNR >= 40 dB over ALL rays (a sanity bound; where the all-ray figure reaches 50 dB it is asserted too: `all_rays=True`).
+      The rays fp32 does not pin are coin tosses of the reference's own closest-approach rule (tests/golden/fp32_unstable_rays.json,
+      tools/fp32_stability.py: listed when 3e-7 noise on the traced distances moves the surface point by > 0.1 mm in any of 32 runs;
+      the file also holds every listed ray's flip probability at fp32's own noise level, 1.2e-7 — 30-50 % for the rays listed on
+      frame_relight / frame_relight_smooth / frame_novel / frame_ground / smoke).  One such ray at 0.05 rgb takes a 256-ray frame
+      from 64 to 51 dB, which is why the all-ray PSNR is only a sanity bound there.
+      * through assert_contract: frame_relight, frame_relight_smooth, frame_novel (three probes), frame_ground, the multi-chunk and
+        other-pose cases, the full-size sample, the volume frames (> 80 dB);
+      * NOT through it: frame_novel_ground (max <= 2e-2 and at most 3 elements over 1e-2: one interior pixel of `main` sits at 1.1e-2, the
+        plain-f16 shadow rays' error amplified by sharp / (2 t), see below) and the full 512 x 512 frame against its all-compensated twin
+        (test_full_frame_shadow_tier_is_harmless: 2 of 19 929 hit pixels over 1e-2, max 1.3e-2).  Round 5 built the adaptive re-query
+        of amplified penumbra candidates the round-4 verdict asked for and measured it (profiles/r05_shadow_requery.txt): 11-29 % of the
+        fine queries qualify, the evaluation error is only ~40 % of the pixel error (the rest is the rays' step positions, which a
+        re-evaluated candidate does not change), 2 -> 1 pixels over 1e-2 — not shipped; the two tests keep their documented bounds.
+      History: on the SURVEY 8d body (white noise in the skinning logits -> the world -> big-pose warp jumps by ~1 cm between neighbouring
+      query points, the REFERENCE's trace ends in a limit cycle on ~9 % of the hit rays) plain 16-bit operands reach 50.6 dB / max 4.7e-2
+      (tests/golden/precision_floor.json, tools/precision_floor.py); fp32 itself IS stable on all but ~0.5 % of those rays
+      (tools/precision_tiers.py: a float64-accumulated oracle agrees with the fp32 one to 89-110 dB), and compensating ONLY the surface
+      trace's distance queries (K3C, csrc/ra_k3c.hpp: f16 hi + lo operand pairs, 2 % of a frame's fine queries) reaches the contract.
+      Measured: frame_relight 68.5 dB / 2.9e-3 on the fp32-stable rays (plain f16: 50.7 / 4.7e-2), frame_novel 66.7-73.5 dB (46-52).
   stage bisect ....................... test_mlp_stage_matches_the_operand_rounding_emulation: HIP sdf vs the kernel-like
         emulation is several times closer than the emulation is to fp32, i.e. the in-kernel loss IS the operand rounding
         (v_sin/v_cos encodings, scaled-domain softplus through v_exp/v_log and the f16 re-pack add nothing measurable).
@@ -415,7 +424,12 @@ def unstable_rays(case, n_rays):
     return m
 
 
-def assert_contract(rgb, rgb_ref, case, label=None, bad=None):
+def unstable_info(case):
+    here = os.path.dirname(os.path.abspath(__file__))
+    return json.load(open(os.path.join(here, 'golden', 'fp32_unstable_rays.json'))).get(case)
+
+
+def assert_contract(rgb, rgb_ref, case, label=None, bad=None, all_rays=False):
     """SURVEY.md:409 for the 16-bit path, asserted outright on every ray whose reference value fp32 itself pins: rgb PSNR >= 50 dB and
     max |err| <= 1e-2.  About 0.5 % of the rays are coin tosses of the reference's own arithmetic (unstable_rays): a change of the last
     bit of a distance moves their surface point by millimetres, so which side of the toss an implementation lands on changes with any
@@ -432,6 +446,12 @@ def assert_contract(rgb, rgb_ref, case, label=None, bad=None):
     assert p >= 50.0, (label or case, p)
     assert mx <= 1e-2, (label or case, mx)
     assert p_all >= 40.0, (label or case, p_all)          # a sanity bound only: the unstable rays are a handful
+    if all_rays:                                          # where every ray is pinned well enough, the contract's PSNR half holds over all of them
+        assert p_all >= 50.0, (label or case, p_all)
+    listed = unstable_info(case)
+    if listed and int(bad.sum()):
+        print(f'   fp32-unstable rays of {case}: {listed["unstable"]}, flip probability at noise 1.2e-7 (fp32\'s own level): '
+              f'{listed.get("flip_probability", {}).get("noise_1.2e-7")}, at 3e-7: {listed.get("flip_probability", {}).get("noise_3e-7")}')
     return p, mx
 
 
@@ -874,6 +894,45 @@ def test_merged_sphere_chunks_are_exact():
         assert torch.equal(outs[1][k], outs[2][k]), k
     assert torch.equal(parts[0], parts[2]) and torch.equal(parts[1], parts[2])
     assert float(outs[0]['shade_map'].abs().sum()) > 0
+
+
+def test_full_size_properties_frame_filling_subject():
+    """The frame-filling case of BASELINE's frame (bench.py --coverage 0.35: camera at 0.96 m, every one of the 262 144 pixels inside the
+    box, ~40 % hit pixels): four of the reference's 65 536-ray render chunks in ONE launch sequence (cfg.sphere_chunk_rays).  Size-independent
+    properties: finite maps in range, misses black, the expected coverage, the 2-shard merge bit-identical to the whole frame (a shard walks
+    the frame's four chunks and their grown boxes), and a strided sample of the rays rendered on its own equals the same rays of the
+    whole frame bit for bit (rays are independent units)."""
+    import math
+    from relightableavatar_amd import shard
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight')
+    rend = make_renderer(cfg, net)
+    cam = 0.8 * 0.4 / math.sqrt(0.35 / math.pi)
+    mk = lambda: synthetic.make_batch(512, 512, seed=0, posed=True, cam_dist=cam)
+    base = synthetic.to_device(mk(), dev)
+    P = base.ray_o.shape[1]
+    assert P == 512 * 512 and P == 4 * cfg.render_chunk_size
+    wb0 = base.wbounds.clone()
+    out = rend.render(base)
+    rgb, acc = out.rgb_map.clone(), out.acc_map.clone()
+    hit = acc[0] > 0
+    assert torch.isfinite(rgb).all() and float(rgb.min()) >= 0 and float(rgb.max()) <= 1.0 + 1e-6
+    assert 0.30 < float(hit.float().mean()) < 0.50
+    assert float(rgb[0][~hit].abs().max()) == 0.0
+    c = net.engine().counters()
+    assert c.n_hit_pixels == int(hit.sum()) and c.n_shadow_rays > 100 * c.n_hit_pixels
+    merged = torch.zeros_like(rgb[0])
+    for r in range(2):
+        base.wbounds.copy_(wb0)
+        o = rend.render(shard.shard_batch(base, r, 2, cfg.render_chunk_size))
+        merged[shard.shard_indices(P, r, 2, base, merged.device)] = o.rgb_map[0]
+    assert float((merged - rgb[0]).abs().max()) == 0.0
+    # every 509th ray on its own: one chunk, its shadow rays clipped against the FIRST chunk's box, so only rays of the first chunk compare
+    sub, _, stride = synthetic.sample_rays(mk(), 512)
+    o = rend.render(synthetic.to_device(sub, dev))
+    idx = torch.arange(0, P, stride, device=rgb.device)[:o.rgb_map.shape[1]]
+    first = idx < cfg.render_chunk_size
+    assert int(first.sum()) > 100 and float((o.rgb_map[0][first] - rgb[0][idx[first]]).abs().max()) == 0.0
 
 
 def test_frames_in_flight_are_bit_identical():
