@@ -6,6 +6,7 @@
 #include <vector>
 
 #include <cstring>
+#include <cstdio>
 #include <cstdlib>
 
 static thread_local std::string g_err;
@@ -129,6 +130,46 @@ static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
     return 0;
 }
 
+// K3CC (csrc/ra_k3cc.hpp) keeps 62 weight fragments in flight in AGPRs it addresses by name; that is safe only while the compiler writes no
+// AGPR of its own in that kernel — checked on the shipped object's assembly at build time (csrc/Makefile, tools/check_k3cc_isa.py) and
+// HERE, on the device: a few hundred points through K3CC and through K3C's 4-wave tiles (the same arithmetic, weights through LDS) must
+// agree bit for bit.  On a mismatch the context never launches K3CC (launch_mlp_sdf_comp allow_coop = false) and says so once on stderr.
+static int k3cc_self_test(ra_ctx* c, hipStream_t s) {
+    constexpr int N = 400;                    // 25 tiles of 16 points, the last tile of K3C's 64-point tiles partly filled
+    std::vector<float> x(3 * N);
+    unsigned u = 12345u;
+    for (float& v : x) { u = u * 1664525u + 1013904223u; v = ((u >> 8) * (1.f / 16777216.f) - 0.5f) * 0.9f; }
+    std::vector<int> idx(N);
+    for (int i = 0; i < N; ++i) idx[i] = i;
+    DevBuf bx, bi, bc, ba, bb, bz;
+    if (bx.ensure(x.size() * 4) || bi.ensure(N * 4) || bc.ensure(4) || ba.ensure(N * 4) || bb.ensure(N * 4) || bz.ensure(2048)) return 1;
+    struct Free { DevBuf* b[6]; ~Free() { for (DevBuf* p : b) p->release(); } } fr_{{&bx, &bi, &bc, &ba, &bb, &bz}};
+    RA_HIP(hipMemcpyAsync(bx.p, x.data(), x.size() * 4, hipMemcpyHostToDevice, s));
+    RA_HIP(hipMemcpyAsync(bi.p, idx.data(), N * 4, hipMemcpyHostToDevice, s));
+    const int n = N;
+    RA_HIP(hipMemcpyAsync(bc.p, &n, 4, hipMemcpyHostToDevice, s));
+    RA_HIP(hipMemsetAsync(ba.p, 0xff, N * 4, s));
+    RA_HIP(hipMemsetAsync(bb.p, 0, N * 4, s));
+    RA_HIP(hipMemsetAsync(bz.p, 0, 2048, s));
+    FrameState f{};
+    f.bias_r0 = bz.as<float>(); f.bias_r4 = bz.as<float>() + 256;          // no frame yet: zero pose biases
+    MlpIO io{};
+    io.bpts = bx.as<float>(); io.idx = bi.as<int>(); io.count = bc.as<int>(); io.dist_th = 1.f; io.smooth = 0; io.resd_limit = c->cfg.resd_limit;
+    io.sdf = ba.as<float>();
+    launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), f, io, N, s, true);
+    io.sdf = bb.as<float>();
+    launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), f, io, N, s, false);
+    std::vector<unsigned> a(N), b(N);
+    RA_HIP(hipMemcpyAsync(a.data(), ba.p, N * 4, hipMemcpyDeviceToHost, s));
+    RA_HIP(hipMemcpyAsync(b.data(), bb.p, N * 4, hipMemcpyDeviceToHost, s));
+    RA_HIP(hipStreamSynchronize(s));
+    RA_HIP(hipGetLastError());
+    c->k3cc_ok = a == b;
+    if (!c->k3cc_ok)
+        fprintf(stderr, "relightableavatar: K3CC self-test failed (its distances differ from K3C's): the cooperative small-launch kernel is disabled for this context\n");
+    return 0;
+}
+
 int ra_finalize_weights(ra_ctx* c, void* stream) {
     RA_CHECK(c && c->have_cfg, "ra_finalize_weights: call ra_set_config first");
     hipStream_t s = (hipStream_t)stream;
@@ -160,6 +201,7 @@ int ra_finalize_weights(ra_ctx* c, void* stream) {
         launch_light_dirs(c->light_xyz.as<float>(), c->n_lights, c->light_dir.as<float>(), s);
     }
     RA_HIP(hipStreamSynchronize(s));     // host staging vectors may be reused
+    if (k3cc_self_test(c, s)) return 1;
     c->have_weights = true;
     return 0;
 }
@@ -258,7 +300,7 @@ bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || 
 void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s) {
     if (comp) {
         Timer t(c, s, 3);
-        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, n, s);
+        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, n, s, c->k3cc_ok);
     } else {
         Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
         k3_launch(c, io, n, s);
@@ -271,14 +313,13 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     int err = 0;
     int* fine_idx = c->buf<int>("fine_idx", n, &err);
     float* bpts = c->buf<float>("fine_bpts", (size_t)n * 3, &err);
-    float* smpl = smooth ? c->buf<float>("fine_smpl", (size_t)n, &err) : nullptr;
     if (err) return 1;
     HdqOut out{};
-    out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts; out.smpl = smpl;
+    out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     MlpIO io{};
-    io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.smpl = smpl; io.dist_th = th; io.smooth = smooth;
+    io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     fine_level(c, io, n, precise(c, what), s);
     return 0;

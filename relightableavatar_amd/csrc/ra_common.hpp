@@ -78,7 +78,6 @@ struct MlpIO {
     const int* idx;         // n_slots: point index of each slot
     const int* count;       // device: number of valid slots
     float* sdf;             // per point: in = coarse smpl sdf, out = blended HDQ sdf
-    const float* smpl;      // nullable: per SLOT the coarse smpl sdf (= sdf[idx[slot]] on entry): read beside bpts / idx instead of through idx
     float dist_th;
     int smooth;
     float resd_limit;
@@ -129,7 +128,10 @@ void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const voi
 inline int k3c_waves(int max_slots) { return max_slots <= 256 * 64 ? 4 : 8; }
 constexpr int k3c_coop_max = 256 * 32;
 void launch_mlp_sdf_coop(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
-void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
+// allow_coop = false: launches of at most k3c_coop_max points take K3C's 4-wave tiles instead of K3CC (the context's self-test of K3CC
+// failed at ra_finalize_weights: ra_ctx::k3cc_ok)
+void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream,
+                         bool allow_coop = true);
 
 // K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list
 size_t mlp_full_rev_tape_bytes(int slots);

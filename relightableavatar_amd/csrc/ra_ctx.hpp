@@ -53,6 +53,7 @@ struct ra_ctx {
     ra_gate* gate = nullptr;
     ra_config cfg{};
     bool have_cfg = false, have_weights = false, have_frame = false;
+    bool k3cc_ok = true;        // K3CC's self-test against K3C at ra_finalize_weights (bit for bit); false -> launches of <= 8 Ki points use K3C's 4-wave tiles
     std::map<std::string, std::vector<float>> state_dict;
     HostNets host;
     // device copies

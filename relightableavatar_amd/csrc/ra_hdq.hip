@@ -589,7 +589,6 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
 #pragma unroll
     for (int r = 0; r < 3; ++r) bp[r] = M[12 + 4 * r] * tp[0] + M[12 + 4 * r + 1] * tp[1] + M[12 + 4 * r + 2] * tp[2] + M[12 + 4 * r + 3];
     out.fine_idx[slot] = i;
-    if (out.smpl) out.smpl[slot] = smpl;
     out.bpts[3 * slot] = bp[0]; out.bpts[3 * slot + 1] = bp[1]; out.bpts[3 * slot + 2] = bp[2];
     if (out.mats) {
         float4* dst = reinterpret_cast<float4*>(out.mats + (size_t)slot * 24);

@@ -39,20 +39,8 @@ extern "C" int ra_k3_read_timestamps(long long* out) { return (int)hipMemcpyFrom
 namespace {
 
 // one network: L0 (encoding) .. L7, then the <= 32-row head; returns the head accumulator (bias included)
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-
-// the lane index, recomputed where it is needed (volatile: not merged with an earlier copy).  The 8-wave kernel runs at the 256-register
-// cap: a per-lane value held across the tile is spilled, and a scratch reload in the middle of a tile comes with the compiler's
-// vmcnt(0), which drains the weight stream (12 LDS-DMA pieces in flight).
-__device__ __forceinline__ int lane_now() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
-
-// hook: called once, before the last hidden layer (9 stage turns before the net's end: the 8-wave kernel issues the next tile's input prefetch there)
-template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO, typename PipeT, typename Hook = NoHook>
-__device__ __forceinline__ f32x16 run_net(PipeT& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h, long long* ts, Hook&& hook = Hook()) {
+template <typename E, int NW, bool LAST, int ACT, int PEL, bool LO, typename PipeT>
+__device__ __forceinline__ f32x16 run_net(PipeT& P, const float (&x)[3], const float* bias /* 8 layer rows + head row */, int h, long long* ts) {
     u32x4 B0[16], B1[16], Bp[4];
     f32x16 accA, accB;
     pe_frags<E, PEL, LO>(Bp, x, h);
@@ -74,7 +62,6 @@ __device__ __forceinline__ f32x16 run_net(PipeT& P, const float (&x)[3], const f
         RA_STAMP(ts, 5);
         layer<E, NW, 16, ACT, ACT, true>(P, accB, accA, B1, Bp, B0, bias + 1536, h);
         RA_STAMP(ts, 6);
-        hook();
         layer<E, NW, 16, ACT, ACT, true>(P, accB, accA, B0, Bp, B1, bias + 1792, h);
         RA_STAMP(ts, 7);
         row_block<E, NW, 0, 16, ACT, true, true, LAST>(P, accB, accA, B1, Bp, B1[14], B1[15], bias + 2048, h);
@@ -143,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     }
     if (tid == 0) sm.count = *io.count;
     __syncthreads();
-    const int count = __builtin_amdgcn_readfirstlane(sm.count);      // scalar: everything derived from it (tile deal, prefetch slots) stays in SGPRs
+    const int count = sm.count;
     if (blockIdx.x == 0 && tid == 0 && io.counters) {
         atomicAdd(&io.counters->n_fine_sdf, (unsigned long long)count);
         if (NW == 8) atomicAdd(&io.counters->n_fine_sdf_wide, (unsigned long long)count);
@@ -153,16 +140,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
 
     constexpr bool PAIRS = NW < 8;          // one wave per SIMD: two row blocks in flight (pair-ordered stream), A fragments read 8 ahead
     constexpr int STAGES = PAIRS ? ST_STAGES : ST_STAGES_TRIM;          // the 8-wave kernel walks the trimmed stream
-    // The 8-wave kernel keeps its tile boundary free of compiler-visible VMEM (round 5).  Before: the next tile's point, index and coarse
-    // distance were plain loads at the top of the tile — two dependent round trips (sdf[idx[s]]) behind a vmcnt(0) that first drained the
-    // stream's 12 pieces in flight: resd L0 took 7.5 k cycles per tile instead of ~2 k (profiles/r05_k3_variants.txt), 3 us of every 107.
-    // Now every wave fetches the inputs of its NEXT tile with five LDS-DMA loads (no register, no compiler wait) nine stage turns before the
-    // tile ends and reads them from LDS when it gets there; the store of the distance is the only other VMEM operation, and both are
-    // accounted for in the stream's counted waits (Pipe::note_extra).  The narrow variants (one tile per workgroup) load directly.
-    constexpr bool LDSIN = NW == 8;
-    __shared__ float pin[LDSIN ? 2 * 5 * 32 * NW : 4];          // [buffer][x, y, z, idx, smpl][point of the workgroup's tile]
-    Pipe<E, NW, STAGES, PAIRS ? 8 : ST_PF, LDSIN> P;
-    P.xcnt = 0; P.xsyncs = 0;
+    Pipe<E, NW, STAGES, PAIRS ? 8 : ST_PF> P;
     P.g = reinterpret_cast<const char*>(stream);
     P.voff = wave * (16 / NW) * 1024 + lane * 16;
     P.ring = reinterpret_cast<const char*>(sm.ring) + lane * 16;
@@ -170,6 +148,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
     P.slot = ST_RING - 1;            // the first sync_stage() advances to slot 0 / stream stage 0
     P.sstage = STAGES - 1;
     P.rd = P.ring;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
+
     long long* ts = nullptr;
 #ifdef RA_TIMESTAMPS
     int tiles_done = 0;
@@ -190,31 +172,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
         tail_start = base + (int)blockIdx.x * 32 * wact;
     }
     const int n_it = full + ((spread ? tail_start < count : (int)blockIdx.x < remt) ? 1 : 0);
-    // slot of lane column c in tile `it` of this workgroup (the spread tile deals 32 * wact consecutive points to the first wact waves)
-    auto slot_base = [&](int it) { return (spread && it == full) ? tail_start + wave * 32 : (it * G + (int)blockIdx.x) * ST_TM + wave * 32; };     // scalar
-    auto slot_of = [&](int it) { return slot_base(it) + c; };
-    // LDS-DMA of the inputs of tile `it` into buffer it & 1 (lanes 0..31: one point each; slots past the end read the last valid one).
-    // The lane index is recomputed here (v_mbcnt): held across the tile it was spilled, and a scratch reload in the middle of the tile
-    // comes with the compiler's vmcnt(0), which drains the weight stream.
-    auto prefetch = [&](int it) {
-        if constexpr (LDSIN) {
-            const int ln = lane_now();
-            if (ln < 32) {
-                const unsigned sc = (unsigned)min(slot_base(it) + ln, count - 1);
-                const unsigned dst = (unsigned)(size_t)pin + (unsigned)(((it & 1) * 5 * ST_TM + wave * 32) * 4);
-                glds4(io.bpts, 12u * sc, dst);
-                glds4(io.bpts, 12u * sc + 4u, dst + ST_TM * 4);
-                glds4(io.bpts, 12u * sc + 8u, dst + 2 * ST_TM * 4);
-                glds4(io.idx, 4u * sc, dst + 3 * ST_TM * 4);
-                glds4(io.smpl ? (const void*)io.smpl : (const void*)io.idx, 4u * sc, dst + 4 * ST_TM * 4);
-            }
-        }
-    };
-    // the first tile's inputs, before the stream starts (nothing else in flight: a plain wait)
-    if (n_it > 0) prefetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int st = 0; st < ST_AHEAD; ++st) P.issue(st, st);
     for (int it = 0; it < n_it; ++it) {
         const bool spread_tile = spread && it == full;
 #ifdef RA_TIMESTAMPS
@@ -227,18 +184,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
-        const int s = slot_of(it);
+        const int s = spread_tile ? tail_start + wave * 32 + c : (it * G + (int)blockIdx.x) * ST_TM + wave * 32 + c;
         float x[3] = {0.f, 0.f, 0.f};
         int pidx = 0;
         float smpl = 0.f;
-        const int pin0 = LDSIN ? (it & 1) * 5 * ST_TM + wave * 32 : 0;          // scalar: this wave's rows of the input buffer
-        if constexpr (LDSIN) {
-            const float* pi = pin + pin0 + (lane_now() & 31);
-            x[0] = pi[0]; x[1] = pi[ST_TM]; x[2] = pi[2 * ST_TM];
-        } else if (s < count) {
+        if (s < count) {
             x[0] = io.bpts[3 * s]; x[1] = io.bpts[3 * s + 1]; x[2] = io.bpts[3 * s + 2];
             pidx = io.idx[s];
-            if (io.smooth) smpl = io.smpl ? io.smpl[s] : io.sdf[pidx];
+            if (io.smooth) smpl = io.sdf[pidx];
         }
         // the first ST_PF fragments of the tile (stage 0 of the stream)
         static_for<0, decltype(P)::PF>([&](auto f_) { P.template fetch<decltype(f_)::value>(); });
@@ -247,58 +200,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
         if constexpr (PAIRS) hr = run_net_pairs<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h, ts);
         else hr = run_net<E, NW, false, ACT_RELU, 10, false>(P, x, sm.bias, h, ts);
         float cp[3];
-        {
-            const int cc = LDSIN ? (lane_now() & 31) : c;
-            if constexpr (LDSIN) {          // the point again (LDS): three registers less through the residual net
-                const float* pi = pin + pin0 + cc;
-                x[0] = pi[0]; x[1] = pi[ST_TM]; x[2] = pi[2 * ST_TM];
-            }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float r = tanhf(hr[k]) * io.resd_limit;           // valid in lanes h = 0 (rows 0..2)
-                // lane cc's value (ds_bpermute; __shfl would re-derive this lane's own index from threadIdx, a spilled register)
-                cp[k] = x[k] + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(cc << 2, __builtin_bit_cast(int, r)));
-            }
+        for (int k = 0; k < 3; ++k) {
+            const float r = tanhf(hr[k]) * io.resd_limit;           // valid in lanes h = 0 (rows 0..2)
+            cp[k] = x[k] + __shfl(r, c);
         }
         // ---- signed distance net (softplus, scaled domain); head row 0 = sdf
         f32x16 hs;
         if constexpr (PAIRS) hs = run_net_pairs<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr);
-        else {
-            // before the last hidden layer: the next tile's inputs (if this wave computes in it)
-            auto hook = [&]() {
-                if constexpr (LDSIN) {
-                    const bool next = it + 1 < n_it && !(spread && it + 1 == full && wave >= wact);
-                    if (next) { prefetch(it + 1); P.note_extra(5); }
-                }
-            };
-            hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr, hook);
-        }
-        bool mine = h == 0 && s < count;
-        if constexpr (LDSIN) {
-            const int ln = lane_now();
-            mine = ln < 32 && slot_base(it) + ln < count;
-            if (mine) {
-                const float* pi = pin + pin0 + ln;
-                pidx = __builtin_bit_cast(int, pi[3 * ST_TM]);
-                smpl = pi[4 * ST_TM];
-            }
-        }
-        if (mine) {
+        else hs = run_net<E, NW, true, ACT_SOFTPLUS, 8, true>(P, cp, sm.bias + 9 * 256, h, ts ? ts + 9 : nullptr);
+        if (h == 0 && s < count) {
             float d = hs[0] * SP_INV;                                 // head accumulates beta*log2(e) * sdf
             if (io.smooth) {                                          // HDQ blend (base_network.py:374-382)
                 const float r = fminf(fmaxf(fabsf(d) / io.dist_th, 0.f), 1.f);
                 d = smpl * r + d * (1.f - r);
             }
-            if constexpr (LDSIN) {
-                // a store the compiler never waits for; one more VMEM operation in the stream's counted window
-                float* dst = io.sdf + pidx;
-                asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(d) : "memory");
-            } else {
-                io.sdf[pidx] = d;
-            }
+            io.sdf[pidx] = d;
         }
-        if constexpr (LDSIN) P.note_extra(1);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RA_TIMESTAMPS
         RA_STAMP(ts, 18);
         ++tiles_done;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_comp_kernel(
         if (s < count) {
             x[0] = io.bpts[3 * s]; x[1] = io.bpts[3 * s + 1]; x[2] = io.bpts[3 * s + 2];
             pidx = io.idx[s];
-            if (io.smooth) smpl = io.smpl ? io.smpl[s] : io.sdf[pidx];
+            if (io.smooth) smpl = io.sdf[pidx];
         }
         static_for<0, 8>([&](auto f_) { P.template fetch<decltype(f_)::value>(); });      // the tile's first PF fragments
         // ---- residual deformation net (ReLU); head: resd = tanh(z) * resd_limit, cpts = bpts + resd

@@ -4,9 +4,10 @@
 #ifdef RA_TESTING
 #include <cstdlib>
 #endif
-void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
+void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream,
+                         bool allow_coop) {
     if (max_slots <= 0) return;
-    int coop_max = k3c_coop_max;
+    int coop_max = allow_coop ? k3c_coop_max : 0;
 #ifdef RA_TESTING            // test / experiment builds only (tools/build_variant.sh, tools/ab_coop.sh): RA_K3C_COOP_MAX=0 restores the 2-wave tiles
     static const int force = getenv("RA_K3C_COOP_MAX") ? atoi(getenv("RA_K3C_COOP_MAX")) : -1;
     if (force >= 0) coop_max = force;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * CC_W, 1) void mlp_sdf_coop_kernel(GeoNet net, 
         if (s < count) {
             x[0] = io.bpts[3 * s]; x[1] = io.bpts[3 * s + 1]; x[2] = io.bpts[3 * s + 2];
             pidx = io.idx[s];
-            if (io.smooth) smpl = io.smpl ? io.smpl[s] : io.sdf[pidx];
+            if (io.smooth) smpl = io.sdf[pidx];
         }
         const f32x4 hr = coop_net<ACT_RELU, 10, false>(P, x, sm.bias, sm.act, wave, g, lane);
         float cp[3];

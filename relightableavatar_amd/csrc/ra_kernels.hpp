@@ -35,8 +35,6 @@ struct HdqOut {
     float* mats;          // slot x 24 or nullptr
     float* raw_zero;      // nullable: n x raw_C rows that non-fine points zero (Network.forward's zeros outside dist_th)
     int raw_C;
-    float* smpl;          // nullable: slot -> the point's coarse distance (= sdf[fine_idx[slot]]): the fine level blends against it and
-                          // reads it beside bpts / fine_idx in ONE round trip instead of a dependent gather through fine_idx
     // debug (nullable): per point
     float* dbg_sdf_batch; // n x 3
     int* dbg_nn_batch;    // n x 3

@@ -91,17 +91,9 @@ __device__ __forceinline__ void glds16x2(const char* sbase, unsigned voff, unsig
                  : "=&s"(keep) : "v"(voff), "v"(voff2), "s"(sbase), "s"(lds_dst) : "memory", "scc");
 }
 
-// one dword per ACTIVE lane: global (uniform base + per-lane byte offset) -> LDS (uniform base + lane * 4); no register in between
-__device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
 // the weight stream as seen by one wave of an NW-wave workgroup (each wave moves 16 / NW fragments of every stage)
 // PF: A fragments read ahead of their MFMA (4 with two waves per SIMD; a lone wave per SIMD needs 8 to cover the LDS latency)
-// XTRA: the wave also issues VMEM operations of its OWN between the stream's pieces (K3's input prefetch and result store, note_extra)
-template <typename E, int NW, int STAGES = ST_STAGES, int PF_ = ST_PF, bool XTRA = false>
+template <typename E, int NW, int STAGES = ST_STAGES, int PF_ = ST_PF>
 struct Pipe {
     static constexpr int FPW = 16 / NW;
     static constexpr int PF = PF_;
@@ -115,15 +107,6 @@ struct Pipe {
     int sstage;             // its position in the tile's stream, 0 .. ST_STAGES-1 (wave-uniform)
     const char* rd;         // ring + slot * 16 KB + lane * 16
     typename Tr<E>::x8 af[PF];
-    int xcnt, xsyncs;       // XTRA: VMEM operations of the wave's own inside the counted window, stage turns they stay there (wave-uniform)
-
-    // The wave has just issued n (1 or 5) VMEM operations of its own: 5 LDS-DMA loads of the next tile's inputs, or the store of the tile's
-    // distance.  vmcnt counts them like the stream's pieces and they complete in order with them, so while they can still be among the
-    // youngest FPW * (ST_AHEAD - 1) + n operations — the next ST_AHEAD stage turns — the counted wait must allow n more operations in
-    // flight; after that they are older than every piece the wait may leave outstanding.  (A compiler-visible load instead would come with
-    // the compiler's own vmcnt(0..n), which knows nothing of the stream and drains its 12 pieces in flight: what the tile boundary cost
-    // before round 5.)
-    __device__ __forceinline__ void note_extra(int n) { xcnt = n; xsyncs = ST_AHEAD; }
 
     __device__ __forceinline__ void issue(int stream_stage, unsigned ring_slot) {
         const char* sb = g;
@@ -136,17 +119,7 @@ struct Pipe {
     // the next stage of the stream becomes readable; the ring slot two stages back is refilled ST_AHEAD stages ahead.
     // The stage position is run-time state (SGPRs), so the code below only depends on a fragment's position in its stage.
     __device__ __forceinline__ void sync_stage() {
-        if constexpr (XTRA) {
-            if (xsyncs > 0) {
-                --xsyncs;
-                if (xcnt == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1) + 5) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1) + 1) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1)) : "memory");
-            }
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1)) : "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FPW * (ST_AHEAD - 1)) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         slot = (slot + 1) & (ST_RING - 1);

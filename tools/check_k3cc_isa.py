@@ -2,17 +2,33 @@
 that a load is pending in them between a `global_load_dwordx4 a[..]` and the counted wait of its k-step.  This check compiles the kernel to
 assembly with the product flags and verifies the assumption that makes that safe: outside the inline-asm statements NO instruction writes
 an AGPR (the MFMA accumulators are VGPR-form, nothing spills into the AGPR file), and reads of AGPRs happen only after a counted wait.
-usage: python tools/check_k3cc_isa.py [path/to/hipcc]   (exit status 0 = ok; run by tests/test_host_logic.py)"""
+usage: python tools/check_k3cc_isa.py [path/to/hipcc] | --listing file.s   (exit status 0 = ok; run by csrc/Makefile on the assembly of the
+compilation that makes the shipped object — the object is not installed otherwise — and by tests/test_host_logic.py)"""
 import os, re, subprocess, sys, tempfile
 
-def check(hipcc='/opt/rocm/bin/hipcc'):
+def compile_listing(hipcc='/opt/rocm/bin/hipcc'):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, 'relightableavatar_amd', 'csrc', 'ra_k3cc_f16.hip')
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, 'k3cc.s')
         subprocess.run([hipcc, '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wno-unused-value', '-fno-slp-vectorize', '-mllvm',
                         '-amdgpu-mfma-vgpr-form=1', '-S', '--cuda-device-only', src, '-o', out], check=True, stderr=subprocess.DEVNULL)
-        lines = open(out).read().split('\n')
+        return open(out).read().split('\n')
+
+
+def shipped_listing():
+    """the assembly the build kept beside the shipped object (csrc/Makefile: -save-temps of the very compilation that made ra_k3cc_f16.o)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, 'relightableavatar_amd', 'csrc', 'ra_k3cc_f16.s')
+    o = os.path.join(root, 'relightableavatar_amd', 'csrc', 'ra_k3cc_f16.o')
+    if os.path.exists(p) and os.path.exists(o) and os.path.getmtime(p) <= os.path.getmtime(o) + 60:
+        return open(p).read().split('\n')
+    return None
+
+
+def check(hipcc='/opt/rocm/bin/hipcc', lines=None):
+    if lines is None:
+        lines = shipped_listing() or compile_listing(hipcc)
     in_asm, problems, loads, waits, reads = False, [], 0, 0, 0
     agpr = re.compile(r'\ba(\d+|\[\d+:\d+\])')
     for n, l in enumerate(lines, 1):
@@ -44,7 +60,10 @@ def check(hipcc='/opt/rocm/bin/hipcc'):
     return problems, dict(loads=loads, waits=waits, agpr_reads=reads)
 
 if __name__ == '__main__':
-    problems, stats = check(*sys.argv[1:2])
+    if len(sys.argv) > 2 and sys.argv[1] == '--listing':        # the build: check the assembly of the compilation that made the object
+        problems, stats = check(lines=open(sys.argv[2]).read().split('\n'))
+    else:
+        problems, stats = check(*sys.argv[1:2])
     print(stats)
     for p in problems[:20]:
         print('PROBLEM', p)
