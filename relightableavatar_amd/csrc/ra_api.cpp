@@ -90,6 +90,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     for (auto& kv : c->scratch) kv.second.release();
     for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int k = 0; k < PinRing::n; ++k) if (c->pin.ev[k]) hipEventDestroy(c->pin.ev[k]);
+    for (HintSlot& h : c->hints) { if (h.ev) hipEventDestroy(h.ev); if (h.host) hipHostFree(h.host); }
     if (c->pin.base) hipHostFree(c->pin.base);
     delete c;
     return 0;
@@ -240,6 +241,7 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     fr.bvh_soa = c->fbvh_pts.as<float>();
     fr.bvh_sbox = c->fbvh_pairs.as<float4>(); fr.bvh_lpair = reinterpret_cast<const float*>(fr.bvh_sbox + (size_t)2 * nsuper); fr.bvh_leaves = nleaf; fr.bvh_supers = nsuper;
     c->have_frame = true;
+    c->call_no = 0;             // render calls are numbered from here (launch-variant hints, ra_ctx.hpp HintSlot)
     RA_HIP(hipGetLastError());
     return 0;
 }
@@ -277,14 +279,61 @@ enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_FC0 = 8, CNT_FC_SLOTS = 96, 
 void zero_chunk_counters(ra_ctx* c, hipStream_t s) {
     hipMemsetAsync(icnt(c, 0), 0, CNT_ALL * sizeof(int), s);
     c->fc_next = 0;
+    c->fc_wrapped = false;
     c->cnt_zero = true;
 }
 int* next_fine_counter(ra_ctx* c, hipStream_t s) {
     if (c->fc_next >= CNT_FC_SLOTS) {
         hipMemsetAsync(icnt(c, CNT_FC0), 0, CNT_FC_SLOTS * sizeof(int), s);
         c->fc_next = 0;
+        c->fc_wrapped = true;           // slots are being reused: no hints from or for this call
     }
     return icnt(c, CNT_FC0 + c->fc_next++);
+}
+
+// one render call's window on the hints (ra_ctx.hpp HintSlot): construction picks the slot of this call and harvests the counts an earlier
+// frame left there; destruction queues the copy of this call's fine-count slots behind an event
+struct HintScope {
+    ra_ctx* c; hipStream_t s;
+    HintScope(ra_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+        const int k = c->call_no++;
+        if (k >= 64) { c->cur_hint = nullptr; return; }
+        if ((int)c->hints.size() <= k) c->hints.resize(k + 1);
+        HintSlot& h = c->hints[k];
+        if (!h.ev) {
+            if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess || hipHostMalloc((void**)&h.host, CNT_FC_SLOTS * sizeof(int)) != hipSuccess) {
+                h.ev = nullptr; h.host = nullptr; c->cur_hint = nullptr; (void)hipGetLastError(); return;
+            }
+        }
+        if (h.pending && hipEventQuery(h.ev) == hipSuccess) {
+            h.vals.assign(h.host, h.host + h.n_pending);
+            h.n_valid = h.n_pending;
+            h.pending = false;
+        }
+        (void)hipGetLastError();            // hipEventQuery's hipErrorNotReady is not an error of the call
+        c->cur_hint = &h;
+    }
+    ~HintScope() {
+        HintSlot* h = c->cur_hint;
+        c->cur_hint = nullptr;
+        if (!h || h->pending || c->fc_next <= 0 || c->fc_wrapped) return;      // an unread copy is still in flight: keep it
+        if (hipMemcpyAsync(h->host, icnt(c, CNT_FC0), (size_t)c->fc_next * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return;
+        if (hipEventRecord(h->ev, s) != hipSuccess) return;
+        h->n_pending = c->fc_next;
+        h->pending = true;
+    }
+};
+
+// the fine count the pass that takes fine-count slot k found in an earlier frame (-1: unknown)
+int fine_hint(const ra_ctx* c, int k) {
+    const HintSlot* h = c->cur_hint;
+    return (h && !c->fc_wrapped && k < h->n_valid) ? h->vals[k] : -1;
+}
+// the size the variant choice of a fused MLP launch sees: the bound, or — with a hint — a quarter more than the earlier count
+int variant_size(int n, int hint) {
+    if (hint < 0) return n;
+    const long long v = (long long)hint + hint / 4 + 1024;
+    return v < n ? (int)v : n;
 }
 
 void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s) {
@@ -297,13 +346,16 @@ enum { Q_OTHER = 0, Q_SURFACE = 1 };
 bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what == Q_SURFACE); }
 
 // the fine level of one query: K3, or K3C where the pass is in the precise tier
-void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s) {
+// n: upper bound of the device-side count; hint: the count this pass found in an earlier frame (-1: none).  Every variant is correct for
+// every count (persistent over tiles); the size only picks the workgroup width and the grid.
+void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s, int hint = -1) {
+    const int nv = variant_size(n, hint);
     if (comp) {
         Timer t(c, s, 3);
-        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, n, s, c->k3cc_ok);
+        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, nv, s, c->k3cc_ok);
     } else {
-        Timer t(c, s, k3_waves(n) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
-        k3_launch(c, io, n, s);
+        Timer t(c, s, k3_waves(nv) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
+        k3_launch(c, io, nv, s);
     }
 }
 
@@ -316,12 +368,13 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     if (err) return 1;
     HdqOut out{};
     out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
+    const int hint = fine_hint(c, c->fc_next - 1);
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
     MlpIO io{};
     io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
-    fine_level(c, io, n, precise(c, what), s);
+    fine_level(c, io, n, precise(c, what), s, hint);
     return 0;
 }
 
@@ -611,6 +664,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     int err = 0;
     const int S = p->n_samples, C = c->cfg.relight ? 17 : 16, L = c->n_lights;
     zero_chunk_counters(c, s);                // ONE memset for every device counter this chunk uses
+    HintScope hints(c, s);
     // ---- spatially coherent ray order (per-ray results are order-free; outputs go back through perm)
     const int* perm = nullptr;
     if (bbox) {
@@ -753,6 +807,7 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     zero_chunk_counters(c, s);
+    HintScope hints(c, s);
     c->cnt_zero = false;                      // launch_ground_hit zeroes its hit counter itself
     GroundIn g{};
     g.ray_o = ray_o; g.ray_d = ray_d; g.acc = acc; g.P = P;
@@ -816,6 +871,7 @@ int ra_render_volume_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     hipStream_t s = (hipStream_t)stream;
     int err = 0;
     zero_chunk_counters(c, s);
+    HintScope hints(c, s);
     const int S = n_samples, C = 16;
     const size_t N = (size_t)((P + 63) & ~63) * S;          // samples are laid out per group of 64 rays (padded)
     RA_CHECK(N < (1u << 30), "ra_render_volume_chunk: chunk too large");

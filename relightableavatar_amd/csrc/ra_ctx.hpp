@@ -47,8 +47,25 @@ struct PinRing {
     bool used[n] = {};
 };
 
+// Launch-variant hints.  The fused MLP kernels are persistent over tiles and correct for ANY device-side count; which variant (workgroup
+// width) a launch gets only decides its speed, and it is chosen from a host-side UPPER BOUND of the count.  Where the bound is far above
+// the real count (the ground pass: pixels x 512 lights against a handful of fine points), the 8-wave kernel ran almost empty.  Each render
+// call therefore copies its fine-count slots to pinned memory behind an event when it ends, and the SAME call of a later frame (calls are
+// numbered from ra_set_frame) reads them — if the event has passed; the host never waits — as a hint for the variant choice only.
+struct HintSlot {
+    hipEvent_t ev = nullptr;
+    int* host = nullptr;        // pinned, HINT_SLOTS ints
+    bool pending = false;
+    int n_pending = 0;          // fine-count slots the pending copy holds
+    int n_valid = 0;
+    std::vector<int> vals;
+};
+
 struct ra_ctx {
     int device = 0;
+    std::vector<HintSlot> hints;    // per render call since ra_set_frame
+    int call_no = 0;
+    HintSlot* cur_hint = nullptr;
     PinRing pin;
     ra_gate* gate = nullptr;
     ra_config cfg{};
@@ -71,6 +88,7 @@ struct ra_ctx {
     std::map<std::string, DevBuf> scratch;
     DevBuf dcounters;       // DevCounters (64 B) + at byte 128: the int counters of a chunk (ra_api.cpp: CNT_*, fine-count slots)
     int fc_next = 0;        // next unused fine-count slot (each hdq pass takes a fresh, still-zero one)
+    bool fc_wrapped = false;
     bool cnt_zero = false;  // the named counters (hit / ray / sample counts) were zeroed by the chunk's bulk memset
     // host-side counters
     uint64_t n_coarse = 0, n_shaded = 0;
