@@ -403,16 +403,18 @@ def main():
     # same number of frames (the frame all_gather is a collective)
     n_soak = 0
     if args.soak > 0:
-        step(); sync()
+        step(); step(); sync()                  # cold frames (allocations, first launches): not a measure of anything
         t_probe = time.perf_counter()
-        step(); sync()
-        ns = torch.tensor([max(0, int(args.soak / max(time.perf_counter() - t_probe, 1e-4)))], device=dev)
+        for _ in range(3):
+            step()
+        sync()
+        ns = torch.tensor([max(0, int(args.soak / max((time.perf_counter() - t_probe) / 3, 1e-4)))], device=dev)
         if use_dist:
             dist.broadcast(ns, 0)
         n_soak = int(ns.item())
         for _ in range(n_soak):
             step()
-        n_soak += 2
+        n_soak += 5
     for _ in range(args.warmup):
         step()
     sync()
@@ -538,7 +540,7 @@ def main():
         line['hit_pixels_per_sec'] = cnts[3].item() / dt          # the 84 % of rays that miss the box cost nothing: rays/s flatters
         line['fine_queries_per_sec'] = cnts[0].item() / dt
         line['config']['frame_setup'] = 'static frame (set-up excluded)' if args.static_frame else 'per-frame body state (vertex blend, BVH build, bias folds) re-run every step inside the timed region'
-        line['config']['soak'] = f'{n_soak} untimed frames in {args.soak:.1f} s before the {args.warmup} warm-up steps'
+        line['config']['soak'] = f'{n_soak} untimed frames (about {args.soak:.1f} s, sized from three probe frames after two cold ones) before the {args.warmup} warm-up steps'
         line['config']['soak_frames'] = n_soak
         line['config']['frames_in_flight'] = D
         line['config']['camera_distance_m'] = round(cam_dist, 4)

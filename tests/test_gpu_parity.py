@@ -935,6 +935,34 @@ def test_full_size_properties_frame_filling_subject():
     assert int(first.sum()) > 100 and float((o.rgb_map[0][first] - rgb[0][idx[first]]).abs().max()) == 0.0
 
 
+def test_launch_variant_hints_change_speed_only():
+    """Launch-variant hints (csrc/ra_ctx.hpp HintSlot): a render call's fine counts, copied to pinned memory behind an event, size the
+    fused MLP kernel's workgroup width for the same call of a later frame.  The first frame of a context runs without hints (the ground
+    pass's distance launches take the 8-wave kernel: their bound is pixels x 512 lights), later ones with (the narrow kernel): the frames
+    must be bit-identical, and the variant must really have changed."""
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight', vis_ground_shading=True)
+    rend = make_renderer(cfg, net)
+    eng = net.engine()
+    eng.enable_timing(True)
+    frames, wide, narrow = [], [], []
+    for k in range(4):
+        batch = synthetic.to_device(synthetic.make_batch(256, 256, seed=0, posed=True), dev)
+        eng.reset_counters()
+        out = rend.render(batch)
+        torch.cuda.synchronize()
+        frames.append({kk: out[kk].clone() for kk in ('rgb_map', 'acc_map', 'shade_map')})
+        wide.append(eng.kernel_time(2)[1])
+        narrow.append(eng.kernel_time(3)[1])
+    eng.enable_timing(False)
+    print(f'8-wave / narrow distance launches per frame: {list(zip(wide, narrow))}')
+    for f in frames[1:]:
+        for kk in f:
+            assert torch.equal(f[kk], frames[0][kk]), kk
+    assert wide[0] > wide[-1] and narrow[-1] > narrow[0]            # the ground pass's launches moved to the narrow kernel
+    assert wide[0] + narrow[0] == wide[-1] + narrow[-1]            # ... and nothing else changed
+
+
 def test_frames_in_flight_are_bit_identical():
     """relightableavatar_amd/pipeline.py: frames rendered two at a time on two HIP streams (contexts sharing a gate that serialises
     their light-visibility stages) equal the frames rendered one after the other, bit for bit — alternating poses, so that a frame
