@@ -180,7 +180,9 @@ def dry_rank(args, rank, world):
     else:
         ref = payload(base.ray_d[0], base.near[0], base.far[0], None)
 
-    def step():
+    def submit(f):
+        """frame f: plan, this rank's stand-in render (the payload times a per-frame factor, so that frames cannot be mistaken for one
+        another), the frame gather issued without waiting: returns finish() -> gathered frame"""
         pl = shard.make_plan(P, world, base, mask=base.mask_at_box, ground=args.ground, render_chunk_size=65536, use_cache=False)      # per frame, as the timed loop does
         sb = shard.shard_batch(base, rank, world, 65536, pl, args.ground)
         local = payload(sb.ray_d[0], sb.near[0], sb.far[0], None)
@@ -192,18 +194,41 @@ def dry_rank(args, rank, world):
             inds = sb.ground_inds if 'ground_inds' in sb else base.mask_at_box.reshape(-1).nonzero()[:, 0]
             g[inds] += local[0]
             local = g[None]
-        return shard.gather_maps(local, P, rank, world, plan=pl, ground=args.ground), pl
-    for _ in range(args.warmup):
-        step()
+        local = local * float(1 + f % 5)
+        if world == 1:
+            return (lambda: local), pl
+        return shard.gather_maps_async(local, P, rank, world, pl, ground=args.ground), pl
+
+    # D frames in flight: the gathers of frames f .. f + D - 1 are outstanding in ONE process group when frame f is collected (what the
+    # replica streams of relightableavatar_amd/pipeline.py do on the GPU); every gathered frame must be ITS frame
+    D = max(1, args.frames_in_flight)
+    good = True
+
+    def run(n, first):
+        nonlocal good
+        pending, last = [], None
+
+        def collect():
+            nonlocal good, last
+            g, fin, last = pending.pop(0)
+            good = good and torch.equal(fin(), ref * float(1 + g % 5))
+        for f in range(first, first + n):
+            fin, pl_ = submit(f)
+            pending.append((f, fin, pl_))
+            if len(pending) == D:
+                collect()
+        while pending:
+            collect()
+        return last
+    run(args.warmup, 0)
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, pl = step()
+    pl = run(args.steps, args.warmup)
     my_ms = (time.perf_counter() - t0) / args.steps * 1e3
     dist.barrier()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    ok = torch.tensor([1.0 if torch.equal(out, ref) else 0.0])
+    ok = torch.tensor([1.0 if good else 0.0])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     seen = torch.ones(1, dtype=torch.float64)
     dist.all_reduce(seen)
@@ -218,7 +243,7 @@ def dry_rank(args, rank, world):
                           'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'ms_per_step_sequential': dt / args.steps * 1e3,
                           'higher_is_better': True, 'scaling': 'strong',
                           'vs_baseline': None, 'dtype': 'none', 'data': 'dry run: no kernels, plumbing only',
-                          'config': {'workload': f'DRY {H}x{H}', 'backend': args.backend, 'gather_ok': bool(ok.item() == 1.0)},
+                          'config': {'workload': f'DRY {H}x{H}', 'backend': args.backend, 'gather_ok': bool(ok.item() == 1.0), 'frames_in_flight': D},
                           'ranks_seen': int(seen.item()),
                           'per_rank': {'ms_per_step': [round(float(t[0]), 4) for t in per_rank], 'rays_per_frame': [int(t[1]) for t in per_rank]},
                           'gather': {'collective': f'all_gather_into_tensor ({args.backend}), one per frame, shards padded to the largest',

@@ -338,6 +338,30 @@ def _exchange(x: torch.Tensor, n_max: int, order, src, total: int, world: int, g
     return full
 
 
+def gather_maps_async(local: torch.Tensor, P: int, rank: int, world: int, plan, group=None, ground: bool = False):
+    """the frame all_gather issued WITHOUT waiting for it: returns finish() -> (1, P, C) (or (1, H*W, C) with `ground`).  Several frames'
+    collectives may be in flight in one process group — what frames in flight do on the GPU, where every frame's gather is queued on its
+    replica's stream; the process group runs them in submission order, which must be the same on every rank.  (On the GPU the plain
+    `gather_maps` is already asynchronous for the host: the collective is stream-ordered.)"""
+    squeeze = local.ndim == 2
+    x = local[0] if not squeeze else local[0, :, None]
+    _use(plan)
+    pl = plan.ground if ground else plan
+    total = pl.F if ground else P
+    buf = x.new_zeros(pl.n_max, x.shape[-1])
+    buf[:x.shape[0]] = x
+    out = x.new_empty(world * pl.n_max, x.shape[-1])
+    work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        full = x.new_empty(total, x.shape[-1])
+        full[pl.order] = out[pl.src]
+        full = full[None]
+        return full[..., 0] if squeeze else full
+    return finish
+
+
 def gather_maps(local: torch.Tensor, P: int, rank: int, world: int, group=None, force_collective=False, batch=None, plan=None,
                 ground: bool = False) -> torch.Tensor:
     """local: (1, P_local, C) or (1, P_local) maps of this rank's rays -> (1, P, C) on every rank (`ground`: full-frame maps of

@@ -217,6 +217,22 @@ def test_bench_launcher_starts_n_ranks():
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stdout + r.stderr)
 
 
+@pytest.mark.parametrize('extra', [[], ['--ground', '--mode', 'novel_light', '--probes', '2']])
+def test_frames_in_flight_keep_their_collectives_apart_gloo_world4(extra):
+    """Four ranks, THREE frames in flight in one process group (bench.py --dry --frames-in-flight 3: the gathers of frames f, f + 1, f + 2
+    are outstanding when frame f is collected, as the replica streams of pipeline.py leave them on the GPU).  Every frame carries its own
+    payload factor, every rank checks every gathered frame against ITS frame: the collectives run in submission order on all ranks and
+    no frame picks up a neighbour's shards (gloo here; what RCCL's internal stream does with them is the hardware run's to show)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--backend', 'gloo', '--dry', '--size', '96', '--steps', '7',
+                        '--warmup', '2', '--frames-in-flight', '3'] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert line['n_gpus'] == 4 and line['ranks_seen'] == 4 and line['config']['gather_ok'] is True and line['config']['frames_in_flight'] == 3
+    assert len(line['per_rank']['rays_per_frame']) == 4 and sum(line['per_rank']['rays_per_frame']) > 0
+
+
 def test_shards_carry_the_frames_chunk_boundaries():
     """quirk 1 (per-chunk growth of batch.wbounds): a shard renders its rays chunk by chunk of the WHOLE frame"""
     b = synthetic.make_batch(96, 96, seed=0)
