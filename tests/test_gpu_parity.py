@@ -1170,6 +1170,68 @@ def test_animation_inputs_are_asynchronous(relight):
     assert float(outs[0].max()) > 0.05
 
 
+def test_animated_frames_in_flight_are_bit_identical():
+    """An ANIMATED sequence through the device-side loader with frames in flight: every frame poses a new body (ra_pose_frame) and culls
+    its rays (ra_gen_rays) a pipeline turn ahead, on its replica's stream, while the other replicas render — and must equal the same
+    frame posed, culled and rendered strictly one after the other, bit for bit, INCLUDING the loader's own outputs.
+    Round 5: this failed in 10-15 % of the frames (tools/soak_pipeline.py's animated leg; it had not been part of the GPU suite):
+    lbs_verts_kernel returned wrong z coordinates for groups of 16 consecutive vertices — the low half of compiler-formed packed-fp32
+    chains (SLP: v_pk_fma_f32 / v_pk_add_f32 with op_sel swizzles) — whenever its waves shared SIMDs with another frame's MFMA kernels,
+    never alone; the library is built with -fno-slp-vectorize throughout since (csrc/Makefile)."""
+    from relightableavatar_amd.data_utils import DeviceFrameLoader
+    from relightableavatar_amd.pipeline import FramePipeline
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight')
+    sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+    sk = synthetic.make_skeleton(0)
+    H = 192
+    K, R, Tc = synthetic.make_camera(H, H)
+    tv, w = T(sk.tverts).to(dev), T(sk.weights).to(dev)
+    eng0 = net.engine()
+    eye = np.tile(np.eye(4, dtype=np.float32), (52, 1, 1))
+    big_A = eng0.pose_frame(sk.big_poses, sk.tjoints, sk.parents, tv, w, eye, sk.faces, np.zeros(3, np.float32), np.zeros(3, np.float32)).A.cpu().numpy()
+    loader = DeviceFrameLoader(H, H, K, R, Tc, sk.tjoints, sk.parents, tv, w, big_A, sk.faces)
+    ph = np.arange(sk.poses.size, dtype=np.float32).reshape(sk.poses.shape)
+    NA, N = 8, 32
+    seq = [((sk.poses + 0.06 * np.sin(0.37 * f + ph)).astype(np.float32), sk.Rh, (sk.Th + np.float32(0.01 * np.sin(0.3 * f))).astype(np.float32)) for f in range(NA)]
+    keys_in = ('pverts', 'pnorm', 'wbounds', 'ray_o')
+
+    def one(rend, pend):
+        b = loader.batch(pend)
+        snap = {'in_' + k: b[k].clone() for k in keys_in}          # before the renderer grows wbounds in place
+        out = rend.render(b)
+        snap.update({k: out[k].clone() for k in ('rgb_map', 'acc_map', 'surf_map')})
+        return snap
+    serial = make_renderer(cfg, net)
+    want = []
+    for q in seq:
+        want.append(one(serial, loader.issue(eng0, *q)))
+        torch.cuda.synchronize()
+    for depth in (2, 3):
+        pipe = FramePipeline(cfg, sd, dev, depth=depth)
+        ahead, fno = [None] * depth, [0]
+
+        def frame(net_r, rend_r):
+            f = fno[0]
+            r = f % depth
+            eng = net_r.engine()
+            pend = ahead[r] or loader.issue(eng, *seq[f % NA])
+            out = one(rend_r, pend)
+            ahead[r] = loader.issue(eng, *seq[(f + depth) % NA])
+            fno[0] += 1
+            return out
+        pend = [pipe.submit(fn=frame) for _ in range(N)]
+        bad = {}
+        for k, p in enumerate(pend):
+            out = p.result()
+            for key, x in out.items():
+                y = want[k % NA][key]
+                if x.shape != y.shape or not torch.equal(x, y):
+                    bad.setdefault(key, []).append(k)
+        torch.cuda.synchronize()
+        assert not bad, (depth, {k: v[:6] for k, v in bad.items()})
+
+
 def test_frame_novel_ground(golden):
     """the README's relight command (readme.md:64: vis_novel_light + vis_ground_shading): main + every probe, the human AND the
     ground layer re-shaded per probe and blended per light (novel_light_sphere_tracing.py:70-99,138-213) vs the reference's

@@ -8,7 +8,7 @@ name=$1; src=$2; flags=$3
 mkdir -p $R/gpurun_tmp/variants
 make -s -j8 -C $C
 base=$(basename $(basename $src .hip) .cpp)
-nos=""; case $base in ra_hdq|ra_k3_*|ra_k3c_*|ra_k4_*) nos=-fno-slp-vectorize;; ra_k3cc_*) nos="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1";; esac
+nos=-fno-slp-vectorize; case $base in ra_k3cc_*) nos="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1";; esac      # no SLP-packed fp32 anywhere (csrc/Makefile)
 ext=hip; xf=""; [ -f $C/$base.cpp ] && { ext=cpp; xf="-x hip"; }
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value $nos $flags $xf -c $C/$base.$ext -o $R/gpurun_tmp/variants/$name.o
 objs=""
