@@ -28,12 +28,19 @@ for mode, kw in (('relight', {}), ('relight', GROUND), ('novel_light', dict(GROU
     bad = 0
     for depth in (2, 3):
         pipe = FramePipeline(cfg, sd, dev, depth=depth)
-        pend = [pipe.submit(mk(k % 3)) for k in range(N)]
-        for k, p in enumerate(pend):
-            out = pick(p.result())
-            for key in ('rgb_map', 'acc_map'):
-                if not torch.equal(out[key], want[k % 3][key]):
-                    bad += 1
+        pend = []                       # a sliding window: a long soak must not keep every frame's maps alive (500 ground frames are 270 GB)
+        for k in range(N + 2 * depth):
+            if k < N:
+                pend.append((k, pipe.submit(mk(k % 3))))
+            if len(pend) > 2 * depth or k >= N:
+                if not pend:
+                    break
+                j, p = pend.pop(0)
+                out = pick(p.result())
+                for key in ('rgb_map', 'acc_map'):
+                    if not torch.equal(out[key], want[j % 3][key]):
+                        bad += 1
+                del out, p
         torch.cuda.synchronize()
     print(mode, sorted(kw.keys()), f'{2 * N} frames, differing from sequential rendering:', bad, flush=True)
     assert bad == 0
@@ -77,12 +84,19 @@ for depth in (2, 3):
         ahead[r] = loader.issue(eng, *seq[(f + depth) % NA])
         fno[0] += 1
         return out
-    pend = [pipe.submit(fn=frame) for _ in range(N)]
-    for k, p in enumerate(pend):
-        out = p.result()
-        for key in ('rgb_map', 'acc_map'):
-            if out[key].shape != want[k % NA][key].shape or not torch.equal(out[key], want[k % NA][key]):
-                bad += 1
+    pend = []
+    for k in range(N + 2 * depth):
+        if k < N:
+            pend.append((k, pipe.submit(fn=frame)))
+        if len(pend) > 2 * depth or k >= N:
+            if not pend:
+                break
+            j, p = pend.pop(0)
+            out = p.result()
+            for key in ('rgb_map', 'acc_map'):
+                if out[key].shape != want[j % NA][key].shape or not torch.equal(out[key], want[j % NA][key]):
+                    bad += 1
+            del out, p
     torch.cuda.synchronize()
 print('animated relight (DeviceFrameLoader, poses / rays issued a turn ahead)', f'{2 * N} frames, differing from sequential rendering:', bad, flush=True)
 assert bad == 0
