@@ -11,10 +11,13 @@ from relightableavatar_amd.pipeline import FramePipeline
 dev = torch.device('cuda:0')
 GROUND = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0])
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-for mode, kw in (('relight', {}), ('relight', GROUND), ('novel_light', dict(GROUND, novel_light_timing=False)), ('anisdf', {})):
-    cfg = make_cfg(mode, **kw)
+# round 5: + sphere tracing, + a multi-chunk frame with 8 probes (config-5-like: merged render chunks, several boxes per launch sequence)
+for mode, kw in (('relight', {}), ('relight', GROUND), ('novel_light', dict(GROUND, novel_light_timing=False)), ('anisdf', {}),
+                 ('sphere_tracing', {}), ('novel_light', dict(novel_light_timing=False, render_chunk_size=4096, n_probes=8))):
+    kw = dict(kw)
     relight = mode in ('relight', 'novel_light')
-    nl = 2 if mode == 'novel_light' else 0
+    nl = kw.pop('n_probes', 2) if mode == 'novel_light' else 0
+    cfg = make_cfg(mode, **kw)
     sd = synthetic.make_state_dict(0, relight=relight, cfg=cfg)
     net = make_network(cfg); net.load_state_dict(sd); net = net.to(dev).eval()
     serial = make_renderer(cfg, net)
@@ -44,6 +47,49 @@ for mode, kw in (('relight', {}), ('relight', GROUND), ('novel_light', dict(GROU
         torch.cuda.synchronize()
     print(mode, sorted(kw.keys()), f'{2 * N} frames, differing from sequential rendering:', bad, flush=True)
     assert bad == 0
+
+# ---- SHARDED frames in flight (round 5): every frame is one rank's shard of a 4-rank job — plan rebuilt per frame (shard.make_plan, the C
+# call), shard_batch on the replica's stream — against the same shard rendered sequentially
+from relightableavatar_amd import shard
+cfg = make_cfg('relight')
+sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+net = make_network(cfg); net.load_state_dict(sd); net = net.to(dev).eval()
+serial = make_renderer(cfg, net)
+H = 256
+def shard_of(seed, rank):
+    b = mk2(seed)
+    P = b.ray_o.shape[1]
+    pl = shard.make_plan(P, 4, b, dev, mask=b.mask_at_box.cpu(), render_chunk_size=cfg.render_chunk_size, use_cache=False)
+    return shard.shard_batch(b, rank, 4, cfg.render_chunk_size, pl)
+mk2 = lambda seed: synthetic.to_device(synthetic.make_batch(H, H, seed=seed, posed=True), dev)
+want = []
+for k in range(12):                      # frame k renders shard (k % 3, k % 4): period 12
+    out = serial.render(shard_of(k % 3, k % 4))
+    want.append({kk: out[kk].clone() for kk in ('rgb_map', 'acc_map')})
+bad = 0
+for depth in (2, 3):
+    pipe = FramePipeline(cfg, sd, dev, depth=depth)
+    fno = [0]
+    def sframe(net_r, rend_r):
+        k = fno[0]; fno[0] += 1
+        return rend_r.render(shard_of(k % 3, k % 4))
+    pend = []
+    for k in range(N + 2 * depth):
+        if k < N:
+            pend.append((k, pipe.submit(fn=sframe)))
+        if len(pend) > 2 * depth or k >= N:
+            if not pend:
+                break
+            j, p = pend.pop(0)
+            out = p.result()
+            w = want[j % 12]
+            for key in ('rgb_map', 'acc_map'):
+                if out[key].shape != w[key].shape or not torch.equal(out[key], w[key]):
+                    bad += 1
+            del out, p
+    torch.cuda.synchronize()
+print('sharded relight (rank k % 4 of 4, plan rebuilt per frame)', f'{2 * N} frames, differing from sequential rendering:', bad, flush=True)
+assert bad == 0
 
 # ---- an ANIMATED sequence through the device-side loader (N3 + N2, relightableavatar_amd/data_utils.py): every frame a different pose, its
 # rays generated a pipeline turn ahead, against the same frames posed, culled and rendered strictly one after the other
