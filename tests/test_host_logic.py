@@ -443,6 +443,21 @@ def test_native_plan_equals_the_numpy_plan():
         shard._NUMPY_PLAN = False
 
 
+def test_no_unsafe_packed_fp32_in_the_shipped_objects():
+    """Round 5: on MI355X a packed fp32 instruction whose `op_sel` routes a HIGH source half into its LOW lane returns
+    wrong low halves when its wave shares a SIMD with another wave's MFMAs (tools/pk_f32_hazard.hip) — what corrupted the skinning kernel of
+    animated sequences with frames in flight.  The compiler's SLP vectoriser formed them; the library is built with -fno-slp-vectorize, and
+    no object may contain the form (plain packed ops and op_sel_hi-only selects, the coarse level's hand-written scan, are clean)."""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import check_packed_fp32
+    objs = sorted(__import__('glob').glob(os.path.join(REPO, 'relightableavatar_amd', 'csrc', '*.o')))
+    if not objs:
+        pytest.skip('library objects not built in-tree')
+    unsafe, report = check_packed_fp32.check(objs)
+    assert unsafe == 0, report
+    assert 'ra_hdq.o' in report           # the scan sees device code at all (the coarse level's hand-written packed fp32)
+
+
 def test_default_config_matches_the_python_defaults():
     """ra_default_config() (no ctx, no GPU) hands a C caller the documented defaults — a zero-initialised ra_config is NOT the default
     (trace_precision 0, clip_far 0: rejected by ra_set_config) — and they are the values make_cfg('relight') sends through the binding."""
