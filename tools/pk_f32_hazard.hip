@@ -50,9 +50,25 @@ __global__ void victim(const float* __restrict__ in, int n, unsigned* bad_lo, un
         } else if (FORM == 4) {
             asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(d), "v"(e), "v"(c));
             rl = __builtin_fmaf(d.x, e.x, c.x); rh = __builtin_fmaf(d.y, e.y, c.y);
-        } else {
+        } else if (FORM == 5) {
             asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(e), "s"(sg));
             rl = e.x * sg.x; rh = e.y * sg.x;
+        } else if (FORM == 6) {
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(e));
+            rl = a.y + e.x; rh = a.x + e.y;
+        } else if (FORM == 7) {
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(d), "v"(e), "v"(c));
+            rl = __builtin_fmaf(d.x, e.x, c.y); rh = __builtin_fmaf(d.y, e.y, c.x);
+        } else if (FORM == 8) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(r) : "v"(a), "v"(e));
+            rl = a.y * e.y; rh = a.x * e.x;
+        } else {
+            // packed f16 with the same swizzle (one dword per operand): compared as raw bits with the scalar f16 products
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 ha = {(_Float16)a.x, (_Float16)a.y}, hb = {(_Float16)e.x, (_Float16)e.y}, hr;
+            asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(hr) : "v"(ha), "v"(hb));
+            const _Float16 l = ha.x * hb.y, hgh = ha.y * hb.x;
+            r.x = (float)hr.x; r.y = (float)hr.y; rl = (float)l; rh = (float)hgh;
         }
         if (__float_as_uint(r.x) != __float_as_uint(rl)) { atomicAdd(bad_lo, 1u); atomicMin(first_bad, (unsigned)i); }
         if (__float_as_uint(r.y) != __float_as_uint(rh)) { atomicAdd(bad_hi, 1u); atomicMin(first_bad, (unsigned)i); }
@@ -82,10 +98,12 @@ int main() {
     (void)hipMalloc(&din, h.size() * 4); (void)hipMalloc(&dout, 256 * 256 * 4); (void)hipMalloc(&cnt, 12); (void)hipMalloc(&stop, 4);
     (void)hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipStream_t sv, sa; (void)hipStreamCreateWithFlags(&sv, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
-    const char* names[6] = {"0: SLP's chain (mul op_sel:[0,1] op_sel_hi:[1,0] -> fma -> fma op_sel_hi:[1,0,1] -> add)", "1: the chain without op_sel",
+    const char* names[10] = {"0: SLP's chain (mul op_sel:[0,1] op_sel_hi:[1,0] -> fma -> fma op_sel_hi:[1,0,1] -> add)", "1: the chain without op_sel",
                             "2: v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] alone", "3: v_pk_fma_f32 op_sel_hi:[1,0,1] alone", "4: plain v_pk_fma_f32 alone",
-                            "5: v_pk_mul_f32 v, s op_sel_hi:[1,0] (coarse-level form)"};
-    for (int form = 0; form < 6; ++form)
+                            "5: v_pk_mul_f32 v, s op_sel_hi:[1,0] (coarse-level form)", "6: v_pk_add_f32 op_sel:[1,0] op_sel_hi:[0,1]",
+                            "7: v_pk_fma_f32 op_sel:[0,0,1] op_sel_hi:[1,1,0] (only the addend swizzled)", "8: v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0] (both halves swapped)",
+                            "9: v_pk_mul_f16 op_sel:[0,1] op_sel_hi:[1,0] (packed f16)"};
+    for (int form = 0; form < 10; ++form)
         for (int with = 0; with < 2; ++with) {
             unsigned init[3] = {0, 0, 0xffffffffu};
             (void)hipMemcpy(cnt, init, 12, hipMemcpyHostToDevice);
@@ -98,7 +116,11 @@ int main() {
                     case 2: hipLaunchKernelGGL(victim<2>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
                     case 3: hipLaunchKernelGGL(victim<3>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
                     case 4: hipLaunchKernelGGL(victim<4>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
-                    default: hipLaunchKernelGGL(victim<5>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
+                    case 5: hipLaunchKernelGGL(victim<5>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
+                    case 6: hipLaunchKernelGGL(victim<6>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
+                    case 7: hipLaunchKernelGGL(victim<7>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
+                    case 8: hipLaunchKernelGGL(victim<8>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
+                    default: hipLaunchKernelGGL(victim<9>, dim3(n / 256), dim3(256), 0, sv, din, n, cnt, cnt + 1, cnt + 2); break;
                 }
             }
             (void)hipStreamSynchronize(sv);
