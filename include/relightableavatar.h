@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 6
+#define RA_ABI_VERSION 7
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -70,10 +70,21 @@ typedef struct ra_config {
                                                  ra_hdq_sdf / ra_observed_sdf and the shadow rays (validation; 3x the MFMA work) */
     float clip_near, clip_far;                /* 0.02, 10.0: the volume renderer's near.clip(min=clip_near), far.clip(max=clip_far)
                                                  (base_renderer.py:120-121; config.py clip_near / clip_far), applied by ra_render_volume_chunk */
+    int   only_visibility;                    /* cfg.only_visibility (sphere_tracing_renderer.py:516-519, 720-723; debugging option): the cosine
+                                                 of every light is 1 and the probe's radiance the mean of its channels — in the shading of
+                                                 ra_render_sphere_chunk and ra_render_ground_chunk (the three channels of `shade` are then equal:
+                                                 the reference's map has one) */
+    int   vis_shade_map;                      /* what the `shade` output of ra_render_sphere_chunk / ra_render_ground_chunk holds: 0 the shading
+                                                 (:749-751), 1 the mean light visibility (cfg.vis_lvis_map, :537, :756), 2 the mean cosine
+                                                 (cfg.vis_ldot_map, :538, :757; the reference applies it after vis_lvis_map, so it wins) */
+    int   use_geodesic_filter;                /* 1 (default, cfg.use_geodesic_filter): geodesic_knn (sample_utils.py:103-162) — per-neighbour
+                                                 signed distances, neighbours farther than dist_th from the closest one ON THE CANONICAL BODY
+                                                 replaced by it; 0: knn_with_filter (:164-194) — distance sqrt(mean d^2) with the sign of
+                                                 max_k sign((x - v_k) . n_k), the three neighbours as found */
 } ra_config;
 /* A zero-initialised ra_config is NOT the default configuration (trace_precision 0 = plain operands, clip_far 0, ...): start from
- * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2 and
- * clip_far <= clip_near (or NaN). */
+ * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2,
+ * clip_far <= clip_near (or NaN) and vis_shade_map outside 0..2. */
 int ra_default_config(ra_config* out);
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 

@@ -271,9 +271,22 @@ def knn3(p1: torch.Tensor, p2: torch.Tensor, K: int = 3, chunk: int = 65536):
     return torch.cat(d2s), torch.cat(idxs)
 
 
-def geodesic_knn(pts, verts, norm, tverts, K, th):
+def knn_with_filter(pts, verts, norm, K, th):
+    """lib/utils/sample_utils.py:164-194 (cfg.use_geodesic_filter = False): ONE distance per point, sqrt(mean_k d_k^2) with the sign
+    of max_k sign((x - v_k) . n_k), and the K neighbours as found.  The reference asks knn_points for unsorted neighbours and takes
+    column 0 as the closest for the fine mask (:186); the neighbours here are ascending, as in geodesic_knn."""
+    d2, nn = knn3(pts, verts, K)
+    dot = ((pts[:, None, :] - verts[nn]) * norm[nn]).sum(-1)
+    sdf_batch = d2.mean(dim=-1, keepdim=True).sqrt() * dot.sign().max(dim=-1, keepdim=True)[0]
+    mask = d2[:, 0] < th ** 2
+    return sdf_batch, nn, mask, d2, nn
+
+
+def geodesic_knn(pts, verts, norm, tverts, K, th, use_geodesic_filter=True):
     """lib/utils/sample_utils.py:103-162.  Returns full-set (sdf_batch, nn_batch), the fine mask
     (d2_min < th^2, :133) and the per-point geodesically filtered (d2, nn) (valid where mask)."""
+    if not use_geodesic_filter:
+        return knn_with_filter(pts, verts, norm, K, th)
     d2, nn = knn3(pts, verts, K)
     dist = d2.sqrt()
     dot = ((pts[:, None, :] - verts[nn]) * norm[nn]).sum(-1)
@@ -463,7 +476,8 @@ def world_to_bigpose(net: OracleNet, x, fr, dist_th, v=None):
     """Network.world_to_bigpose base_network.py:238-336 (forward, transform, filtering)."""
     c = net.cfg
     ppts_all = (x - fr.Th) @ fr.R                                   # blend_utils.py:252-261
-    sdf_batch, nn_batch, mask, d2, nn = geodesic_knn(ppts_all, fr.pverts, fr.pnorm, fr.tverts, c.sample_vert_cnt, dist_th)
+    sdf_batch, nn_batch, mask, d2, nn = geodesic_knn(ppts_all, fr.pverts, fr.pnorm, fr.tverts, c.sample_vert_cnt, dist_th,
+                                                     use_geodesic_filter=c.get('use_geodesic_filter', True))
     ppts, d2, nn = ppts_all[mask], d2[mask], nn[mask]
     bw = fr.weights[nn]                                            # (S,K,J)  :287
     w = (-d2 / (2 * c.blend_radius ** 2)).exp()
@@ -746,6 +760,9 @@ def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, 
     surf2light = normalize(xyz[:, None] - surf[None])                 # (L,P,3)
     surf2cam = normalize(ray_o - surf)
     light = sample_envmap_image(probe, surf2light)                    # (L,P,3)
+    if c.get('only_visibility', False):                               # :720-723 (debugging option): uniform cosine, one-channel light
+        ldot = torch.ones_like(ldot)
+        light = light.mean(dim=-1, keepdim=True)
     ones = torch.ones_like(ldot)
     shade = lvis[..., None] * ones[..., None] * area[:, None, None] * light
     p2l = surf2light.permute(1, 0, 2)
@@ -761,6 +778,11 @@ def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, 
         sl = 1 / (torch.abs(ones) + 1e-8)
         spec = (sb * (ones[..., None] * sl[..., None] * area[:, None, None] * light)).sum(0)
     shade_map = (lvis[..., None] * ldot[..., None] * area[:, None, None] * light).sum(0) * c.shading_albedo / math.pi
+    eH = c.env_h                                                      # :756-757: mean over the probe's rows, then over its columns
+    if c.get('vis_lvis_map', False):
+        shade_map = lvis.view(eH, -1, lvis.shape[-1]).mean(0).mean(0)[:, None].expand(-1, 3)
+    if c.get('vis_ldot_map', False):
+        shade_map = ldot.view(eH, -1, ldot.shape[-1]).mean(0).mean(0)[:, None].expand(-1, 3)
     return rgb, shade_map, spec
 
 
@@ -918,6 +940,8 @@ def render_ground(net: OracleNet, ray_o, ray_d, acc, probe, fr, bbox):
     eps), DFSS shadows of the avatar onto the plane with cfg.env_lvis, Lambert ground lit by the probe, distance fade.
     ray_o, ray_d (P,3); acc (P) = 1 - human acc; returns per-pixel maps."""
     c = net.cfg
+    if c.get('only_visibility', False):
+        raise NotImplementedError('only_visibility in the ground pass (one-channel shade / spec maps, :516-519) is not restated')
     n = normalize(torch.tensor(c.ground_normal, dtype=torch.float32))
     orig = torch.tensor(c.ground_origin, dtype=torch.float32)
     t = -((ray_o - orig) @ n) / ((ray_d @ n) + 1e-8)
@@ -938,8 +962,13 @@ def render_ground(net: OracleNet, ray_o, ray_d, acc, probe, fr, bbox):
     if c.tonemapping_rendering:
         rgb = linear2srgb(rgb)
     shade = shade.sum(0) * c.shading_albedo / math.pi
+    shade_map = shade
+    if c.get('vis_lvis_map', False):                                       # :537-538: mean over the probe's rows, then its columns
+        shade_map = lvis.view(c.env_h, -1, lvis.shape[-1]).mean(0).mean(0)[:, None].expand(-1, 3)
+    if c.get('vis_ldot_map', False):
+        shade_map = ldot.reshape(c.env_h, -1, ldot.shape[-1]).mean(0).mean(0)[:, None].expand(-1, 3)
     ret = odict(rgb_map=rgb, surf_map=surf, albedo_map=albedo, roughness_map=torch.ones_like(t), spec_map=shade / 20,
-                norm_map=norm, shade_map=shade * c.ground_shading_multiplier, cpts_map=torch.zeros_like(surf),
+                norm_map=norm, shade_map=shade_map * c.ground_shading_multiplier, cpts_map=torch.zeros_like(surf),
                 bpts_map=torch.zeros_like(surf), depth_map=t.clip(-c.env_r, c.env_r))
     if c.vis_novel_light:                                                  # :541-543, (P,L) like the human layer's
         ret.lvis_map, ret.ldot_map = lvis.T.contiguous(), ldot.T.contiguous()

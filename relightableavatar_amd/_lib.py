@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RA_LIB_PATH') or os.path.join(_HERE, 'librelightableavatar_hip.so')    # override: kernel experiments (tools/)
 _lib = None
-ABI_VERSION = 6          # RA_ABI_VERSION of include/relightableavatar.h
+ABI_VERSION = 7          # RA_ABI_VERSION of include/relightableavatar.h
 
 
 class RaError(RuntimeError):
@@ -23,7 +23,8 @@ class ra_config(C.Structure):
                 ('roughness_slope', C.c_float), ('roughness_bias', C.c_float), ('fresnel_f0', C.c_float),
                 ('shading_albedo', C.c_float), ('albedo_multiplier', C.c_float), ('lambert_only', C.c_int),
                 ('glossy_only', C.c_int), ('tonemapping', C.c_int), ('bg_brightness', C.c_float), ('mlp_f16', C.c_int), ('query_skip', C.c_int),
-                ('k4_batch_slots', C.c_int), ('trace_precision', C.c_int), ('clip_near', C.c_float), ('clip_far', C.c_float)]
+                ('k4_batch_slots', C.c_int), ('trace_precision', C.c_int), ('clip_near', C.c_float), ('clip_far', C.c_float),
+                ('only_visibility', C.c_int), ('vis_shade_map', C.c_int), ('use_geodesic_filter', C.c_int)]
 
 
 class ra_frame(C.Structure):

@@ -105,6 +105,7 @@ int ra_default_config(ra_config* o) {
     o->fresnel_f0 = 0.02f; o->shading_albedo = 0.8f; o->albedo_multiplier = 1.f;
     o->tonemapping = 1; o->bg_brightness = 0.f; o->mlp_f16 = 1; o->query_skip = 1; o->k4_batch_slots = 0;
     o->trace_precision = 1; o->clip_near = 0.02f; o->clip_far = 10.f;
+    o->only_visibility = 0; o->vis_shade_map = 0; o->use_geodesic_filter = 1;
     return 0;
 }
 
@@ -113,6 +114,7 @@ int ra_set_config(ra_ctx* c, const ra_config* cfg) {
     RA_CHECK(cfg->n_bones > 0 && cfg->n_bones <= 256, "ra_set_config: bad n_bones");
     RA_CHECK(cfg->trace_precision >= 0 && cfg->trace_precision <= 2, "ra_set_config: trace_precision must be 0, 1 or 2 (a zero-initialised ra_config is not the default: ra_default_config)");
     RA_CHECK(cfg->clip_far > cfg->clip_near, "ra_set_config: clip_far must exceed clip_near (a zero-initialised ra_config is not the default: ra_default_config)");
+    RA_CHECK(cfg->vis_shade_map >= 0 && cfg->vis_shade_map <= 2, "ra_set_config: vis_shade_map must be 0, 1 or 2");
     c->cfg = *cfg;
     c->have_cfg = true;
     return 0;
@@ -370,7 +372,7 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
     const int hint = fine_hint(c, c->fc_next - 1);
     out.counters = dcnt(c);
-    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
+    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s, c->cfg.use_geodesic_filter != 0);
     MlpIO io{};
     io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
@@ -430,7 +432,7 @@ int forward_pass(ra_ctx* c, const float* x, const float* v, int n, const int* n_
     out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts; out.mats = mats;
     out.raw_zero = raw; out.raw_C = C;          // points outside dist_th: zero rows, written by the coarse level itself
     out.counters = dcnt(c);
-    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
+    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s, c->cfg.use_geodesic_filter != 0);
     FullIO io{};
     io.bpts = bpts; io.mats = mats; io.view = v; io.idx = fine_idx; io.count = out.fine_count; io.raw = raw; io.C = C;
     io.beta = c->host.beta; io.resd_limit = c->cfg.resd_limit;
@@ -524,7 +526,7 @@ int ra_bigpose_transform(ra_ctx* c, const float* x, int n, const float* R, const
     o.sdf = sdfc; o.fine_count = next_fine_counter(c, s); o.fine_idx = fine_idx; o.bpts = fb;
     o.dbg_sdf_batch = sb; o.dbg_nn_batch = nb; o.dbg_d2 = d2; o.dbg_bpts = bp; o.dbg_tpts = tp; o.dbg_mats = mats;
     o.counters = dcnt(c);
-    launch_hdq_coarse(c->fr, rs, n, 1e9f, c->cfg.blend_radius, o, s);      // transform=False -> filtering off: dist = 1e9 (:253-259)
+    launch_hdq_coarse(c->fr, rs, n, 1e9f, c->cfg.blend_radius, o, s, c->cfg.use_geodesic_filter != 0);      // transform=False -> filtering off: dist = 1e9 (:253-259)
     launch_bigpose_compose(mats, d2, n, c->cfg.blend_radius, R, Th, invert, out, s);
     RA_HIP(hipGetLastError());
     return 0;
@@ -610,7 +612,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
     TraceState sh{};
     float* ssdf = nullptr;
     if (traced) {
-        sh = alloc_trace(c, "sh_", (int)NR, true, &err);
+        sh = alloc_trace(c, "sh_", (int)NR, shadow.soft_shadow != 0, &err);      // hard shadows (cfg.no_dfss) run the surface trace's state machine (:182-197)
         ssdf = c->buf<float>("sh_sdf", NR, &err);
     }
     if (err) return 1;
@@ -1370,7 +1372,7 @@ int ra_debug_hdq(ra_ctx* c, const float* x, int n, float th, float* sdf_coarse, 
     RA_HIP(hipMemsetAsync(bpts, 0, (size_t)n * 12, s));
     RA_HIP(hipMemsetAsync(tpts, 0, (size_t)n * 12, s));
     RA_HIP(hipMemsetAsync(mats, 0, (size_t)n * 96, s));
-    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s);
+    launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s, c->cfg.use_geodesic_filter != 0);
     RA_HIP(hipStreamSynchronize(s));
     RA_HIP(hipMemcpy(fine_count_host, out.fine_count, sizeof(int), hipMemcpyDeviceToHost));
     RA_HIP(hipGetLastError());

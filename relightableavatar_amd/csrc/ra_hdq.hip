@@ -531,6 +531,13 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         }
     }
     float smpl = (sk[0] + sk[1] + sk[2]) / 3.f;
+    if (dbg & 32) {
+        // cfg.use_geodesic_filter = False: knn_with_filter (sample_utils.py:164-194) — one distance per point, sqrt(mean_k d_k^2) with the
+        // sign of max_k sign((x - v_k) . n_k); the neighbours stay as found
+        const float sg = fmaxf(fmaxf(sgn(sk[0]), sgn(sk[1])), sgn(sk[2]));       // sk[k] = sqrt(d_k) sign(dot_k): the same sign (0 with d_k = 0)
+        smpl = sqrtf((dk[0] + dk[1] + dk[2]) / 3.f) * sg;
+        sk[0] = sk[1] = sk[2] = smpl;
+    }
     smpl = (smpl < -th) ? smpl : fabsf(smpl);       // base_network.py:375
     const bool fine = live && (d0 < th2);
     if (live) {
@@ -630,7 +637,7 @@ void launch_bvh_build(const float4* pverts4, int n_verts, float* leaves, float4*
 }
 
 void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
-                       hipStream_t s) {
+                       hipStream_t s, bool geodesic) {
     // out.fine_count must be zero on entry (ra_api.cpp hands every pass a fresh counter of the chunk's pre-zeroed set)
     if (n <= 0) return;
     const float inv2r2 = 1.f / (2.f * blend_radius * blend_radius);
@@ -645,6 +652,7 @@ void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, 
     static const int e_split = getenv("RA_COARSE_SPLIT_MAX") ? atoi(getenv("RA_COARSE_SPLIT_MAX")) : 196608;
     dbg = e_dbg; probe = e_probe; split_max = e_split;
 #endif
+    if (!geodesic) dbg |= 32;        // knn_with_filter instead of geodesic_knn (ra_config.use_geodesic_filter)
 #ifdef RA_COARSE_TS
     static int launch_no = 0;
     dbg |= (launch_no++ & 63) << 8;

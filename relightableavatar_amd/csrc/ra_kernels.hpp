@@ -55,7 +55,7 @@ void launch_bvh_build(const float4* pverts4, int n_verts, float* leaves, float4*
 int bvh_leaf_count(int n_verts);
 int bvh_super_count(int n_leaves);
 void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
-                       hipStream_t s);
+                       hipStream_t s, bool geodesic = true);
 
 struct TraceState {       // SoA per ray
     float *t, *d0, *dt, *st, *ot, *cd, *occ, *off, *rlx;

@@ -569,6 +569,7 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
     for (int q = 0; q < MAXP; ++q)
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[q][c] = shd[q][c] = spc[q][c] = 0.f;
+    float vis_sum = 0.f;                                       // cfg.vis_shade_map: sum over the lights of lvis (1) / ldot (2)
 
     for (int l = lane; l < in.L; l += 64) {
         float s2l[3] = {in.light_xyz[3 * l] - sp[0], in.light_xyz[3 * l + 1] - sp[1], in.light_xyz[3 * l + 2] - sp[2]};
@@ -580,11 +581,13 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
         mf_light(mv, s2l, alb, cfg, brdf, sbrdf);
         const float area = in.light_area[l];
         const float lv = in.lvis[(size_t)h * in.L + l];
-        const float ld = in.ldot[(size_t)h * in.L + l];
+        const float ld = cfg.only_visibility ? 1.f : in.ldot[(size_t)h * in.L + l];       // :720-722
         const float spec_ld = 1.f / (fabsf(1.f) + 1e-8f);    // :743
+        vis_sum += cfg.vis_shade_map == 1 ? lv : ld;
         for (int q = 0; q < in.n_probes; ++q) {
             float Lr[3];
             sample_probe(in.probes + (size_t)q * in.ph * in.pw * 3, in.ph, in.pw, s2l, Lr);
+            if (cfg.only_visibility) Lr[0] = Lr[1] = Lr[2] = (Lr[0] + Lr[1] + Lr[2]) / 3.f;        // light.mean(dim=-1) (:723)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float sh = lv * 1.f * area * Lr[c];     // cancel_cosine: ldot -> 1 (:724-727)
@@ -594,6 +597,8 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
             }
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vis_sum += __shfl_xor(vis_sum, o);
     for (int q = 0; q < in.n_probes; ++q) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(TPB) void shade_kernel(ShadeIn in, ra_config cfg) {
             if (lane == 0) {
                 const size_t k = ((size_t)q * in.n + h) * 3 + c;
                 if (in.rgb) in.rgb[k] = cfg.tonemapping ? srgb(a) : a;
-                if (in.shade) in.shade[k] = b * cfg.shading_albedo / PI_F;
+                if (in.shade) in.shade[k] = cfg.vis_shade_map ? vis_sum / (float)in.L : b * cfg.shading_albedo / PI_F;     // :756-757
                 if (in.spec && in.want_spec) in.spec[k] = d;
             }
         }
@@ -875,18 +880,23 @@ __global__ __launch_bounds__(TPB) void ground_shade_kernel(GroundShade in, ra_co
         sample_probe(in.probe, in.ph, in.pw, d, alb);
     }
     float sum[3] = {0.f, 0.f, 0.f};
+    float vis_sum = 0.f;                                       // cfg.vis_shade_map: sum over the lights of lvis (1) / ldot (2)
     for (int l = lane; l < in.L; l += 64) {
         const float ld[3] = {in.ldir[3 * l], in.ldir[3 * l + 1], in.ldir[3 * l + 2]};
-        const float ldot = ld[0] * in.g.n[0] + ld[1] * in.g.n[1] + ld[2] * in.g.n[2];     // not clamped (:504)
+        float ldot = ld[0] * in.g.n[0] + ld[1] * in.g.n[1] + ld[2] * in.g.n[2];           // not clamped (:504)
         const float lv = in.lvis[(size_t)h * in.L + l] * (1.f - w) + w;                  // :505
         float Lr[3];
         sample_probe(in.probe, in.ph, in.pw, ld, Lr);
+        if (cfg.only_visibility) { ldot = 1.f; Lr[0] = Lr[1] = Lr[2] = (Lr[0] + Lr[1] + Lr[2]) / 3.f; }      // :516-519
+        vis_sum += cfg.vis_shade_map == 1 ? lv : ldot;
         const float k = lv * ldot * in.light_area[l];
 #pragma unroll
         for (int c = 0; c < 3; ++c) sum[c] += k * Lr[c];
         if (in.lvis_out) in.lvis_out[(size_t)r * in.L + l] = lv;
         if (in.ldot_out) in.ldot_out[(size_t)r * in.L + l] = ldot;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vis_sum += __shfl_xor(vis_sum, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float a = sum[c];
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(TPB) void ground_shade_kernel(GroundShade in, ra_co
             const float sh = a * cfg.shading_albedo / PI_F;
             if (in.rgb) in.rgb[3 * r + c] = cfg.tonemapping ? srgb(rgb) : rgb;
             if (in.albedo) in.albedo[3 * r + c] = alb[c];
-            if (in.shade) in.shade[3 * r + c] = sh * in.g.shading_multiplier;
+            if (in.shade) in.shade[3 * r + c] = (cfg.vis_shade_map ? vis_sum / (float)in.L : sh) * in.g.shading_multiplier;     // :537-539
             if (in.spec) in.spec[3 * r + c] = sh / 20.f;
         }
     }

@@ -66,7 +66,10 @@ class Engine:
                       tonemapping=int(cfg.tonemapping_rendering), bg_brightness=cfg.bg_brightness,
                       mlp_f16=int(cfg.mlp_dtype == 'f16'), query_skip=int(cfg.get('query_skip', True)),
                       k4_batch_slots=int(cfg.get('k4_batch_slots', 0)), trace_precision=int(cfg.get('trace_precision', 1)),
-                      clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)))
+                      clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)),
+                      only_visibility=int(bool(cfg.get('only_visibility', False))),
+                      vis_shade_map=2 if cfg.get('vis_ldot_map', False) else (1 if cfg.get('vis_lvis_map', False) else 0),
+                      use_geodesic_filter=int(bool(cfg.get('use_geodesic_filter', True))))
         assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None

@@ -59,6 +59,11 @@ class Renderer(nn.Module):
         ground = bool(cfg.vis_ground_shading) and not self.net.training
         if ground and not (cfg.relighting and hasattr(self.net, 'global_env_map')):
             raise ValueError('vis_ground_shading needs the relighting renderer (light set + probe)')
+        only_vis = bool(cfg.get('only_visibility', False)) and bool(cfg.relighting)
+        if only_vis and (ground or cfg.vis_novel_light):
+            # the reference's debugging option (:516-519, :720-723) turns shade / spec of the ground layer into one-channel maps that its
+            # blend then broadcasts against the human layer's three; not reproduced — refuse instead of returning something else
+            raise NotImplementedError('cfg.only_visibility is supported for the human layer only (not with vis_ground_shading / vis_novel_light)')
         eng = self.net.set_frame(batch)
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
@@ -132,7 +137,9 @@ class Renderer(nn.Module):
             ret.albedo_map, ret.roughness_map = full.albedo[None], full.roughness[None]
         ret.rgb_map = full.rgb[None]
         if relit:
-            ret.shade_map = full.shade[None]
+            # only_visibility: a one-channel light (:723, :749-751); vis_lvis_map / vis_ldot_map expand to three (:756-757)
+            one_ch = only_vis and not (cfg.get('vis_lvis_map', False) or cfg.get('vis_ldot_map', False))
+            ret.shade_map = full.shade[None, :, :1] if one_ch else full.shade[None]
             if 'spec' in full:
                 ret.spec_map = full.spec[None]
             if 'lvis' in full:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate golden vectors by running the REFERENCE itself (build container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --mode {ops,anisdf,sphere,relight,novel}
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --mode {ops,anisdf,sphere,relight,novel,...}
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --mode switches      # one child process per variant -> switches.npz
 
 Imports /root/reference's hot-path modules on CPU with a stub import-finder for the third-party
 packages the image lacks (SURVEY.md §8c recipe), loads the build-owned synthetic weights
@@ -114,6 +115,58 @@ def set_cfg(cfg, mode):
         cfg.render_chunk_size = 384
 
 
+# The hot path's configuration switches (sphere_tracing_renderer.py:36,275,295-300,516-538,720-757; relight_utils.py:563-566;
+# relight_network.py:63-66), one relit frame of the same 10 x 10 pixel window per variant.  Keys with a dot address a sub-node.
+SWITCH_VARIANTS = {
+    'base': {},
+    'no_dfss': {'no_dfss': True},
+    'no_claybook': {'no_claybook': True},
+    'no_visibility': {'no_visibility': True},
+    'local_visibility': {'local_visibility': True},
+    'lambert_only': {'lambert_only': True},
+    'glossy_only': {'glossy_only': True},
+    'linear': {'tonemapping_rendering': False},
+    'only_visibility': {'only_visibility': True},
+    'vis_lvis_map': {'vis_lvis_map': True},
+    'vis_ldot_map': {'vis_ldot_map': True},
+    'chromatic': {'achro_light': False},
+    'material_params': {'albedo_multiplier': 2.0, 'shading_albedo': 0.5, 'fresnel_f0': 0.04, 'albedo_slope': 0.7, 'albedo_bias': 0.1,
+                        'roughness_slope': 0.5, 'roughness_bias': 0.2},
+    'trace_params': {'sphere_tracing.shadow_skip_iter': 2, 'sphere_tracing.tan_i_multiplier': 1.5, 'sphere_tracing.offset': 0.03,
+                     'sphere_tracing.near_offset': 0.02, 'sphere_tracing.iter': 12,
+                     'obj_lvis.iter': 6, 'obj_lvis.offset': 0.02, 'obj_lvis.near_offset': 0.03, 'obj_lvis.relax': 0.1, 'surf_sample_range': 0.01},
+    'no_specular_vis': {'vis_specular_map': False, 'bg_brightness': 0.5},
+    'no_geodesic_filter': {'use_geodesic_filter': False},
+}
+# the same for the ground-plane pass (render_ground :463-548 + blend_output_): names start with g_, the frame is frame_ground.npz's
+# (24 x 24, 10 x 10 window, two ground chunks) on the smooth body
+GROUND_BASE = {'vis_ground_shading': True, 'ground_normal': [0.0, -1.0, 0.0], 'ground_origin': [0.0, 0.45, 0.0], 'render_chunk_size': 384}
+SWITCH_VARIANTS.update({
+    'g_base': {},
+    'g_no_dfss': {'no_dfss': True},
+    'g_vis_lvis_map': {'vis_lvis_map': True},
+    'g_vis_ldot_map': {'vis_ldot_map': True},
+    'g_linear': {'tonemapping_rendering': False},
+    'g_local_visibility': {'local_visibility': True},
+    'g_plain_ground': {'ground_attach_envmap': False, 'ground_albedo': [0.3, 0.2, 0.1], 'ground_shading_multiplier': 2.0},
+    'g_env_lvis': {'env_lvis.iter': 8, 'env_lvis.offset': 0.02, 'env_lvis.dist_th': 0.01, 'env_lvis.bbox_margin': 0.3, 'env_lvis.near_offset': 0.03},
+})
+for _k in [k for k in SWITCH_VARIANTS if k.startswith('g_')]:
+    SWITCH_VARIANTS[_k] = dict(GROUND_BASE, **SWITCH_VARIANTS[_k])
+SWITCH_H, SWITCH_CROP = 128, 10
+GROUND_H, GROUND_CROP = 24, 10
+SWITCH_KEYS = ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'albedo_map', 'roughness_map', 'shade_map', 'spec_map')
+
+
+def apply_overrides(cfg, overrides):
+    for k, v in overrides.items():
+        node = cfg
+        parts = k.split('.')
+        for q in parts[:-1]:
+            node = node[q]
+        node[parts[-1]] = v
+
+
 def to_ref_batch(b):
     from lib.utils.base_utils import dotdict
     out = dotdict()
@@ -135,9 +188,27 @@ def npz(path, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', required=True, choices=['ops', 'anisdf', 'sphere', 'relight', 'novel', 'rays', 'ground', 'envmap', 'lbs',
-                                                   'relight_smooth', 'novel_ground', 'anisdf128', 'fields', 'fixmat', 'visual'])
+                                                   'relight_smooth', 'novel_ground', 'anisdf128', 'fields', 'fixmat', 'visual', 'switches', 'switch'])
+    ap.add_argument('--variant', default='base')
+    ap.add_argument('--out', default='')
     args = ap.parse_args()
     mode = args.mode
+    if mode == 'switches':          # the reference binds cfg values as default arguments at import: one child process per variant
+        import subprocess
+        import tempfile
+        import json
+        merged = dict(H=np.asarray(SWITCH_H), crop=np.asarray(SWITCH_CROP), ground_H=np.asarray(GROUND_H), ground_crop=np.asarray(GROUND_CROP),
+                      variants_json=np.asarray(json.dumps(SWITCH_VARIANTS)))
+        with tempfile.TemporaryDirectory() as tmp:
+            for name in SWITCH_VARIANTS:
+                out = os.path.join(tmp, name + '.npz')
+                subprocess.run([sys.executable, os.path.abspath(__file__), '--mode', 'switch', '--variant', name, '--out', out], check=True)
+                with np.load(out) as z:
+                    for k in z.files:
+                        merged[f'{name}.{k}'] = z[k]
+        np.savez_compressed(os.path.join(HERE, 'switches.npz'), **merged)
+        print('wrote switches.npz', len(merged), 'arrays')
+        return
     from relightableavatar_amd import synthetic
     from relightableavatar_amd.config import make_cfg
     cfg = install_reference()
@@ -153,9 +224,15 @@ def main():
     if mode == 'visual':
         gen_visual(cfg, synthetic)
         return
-    set_cfg(cfg, mode)
+    set_cfg(cfg, 'relight' if mode == 'switch' else mode)
+    if mode == 'switch':
+        cfg.vis_specular_map = True
+        apply_overrides(cfg, SWITCH_VARIANTS[args.variant])
     torch.manual_seed(0)
     torch.set_grad_enabled(True)
+    if mode == 'switch':
+        gen_switch(cfg, synthetic, args.variant, args.out)
+        return
     my_cfg = make_cfg({'ops': 'relight', 'anisdf': 'anisdf', 'sphere': 'sphere_tracing', 'relight': 'relight', 'novel': 'novel_light', 'ground': 'relight',
                        'relight_smooth': 'relight', 'novel_ground': 'novel_light', 'anisdf128': 'anisdf', 'fields': 'relight', 'fixmat': 'anisdf'}[mode])
     relight = mode in ('ops', 'relight', 'novel', 'ground', 'relight_smooth', 'novel_ground', 'fields')
@@ -260,6 +337,47 @@ def main():
                 if k in out[name]:
                     kw[f'{name}.{k}'] = out[name][k]
         npz('frame_novel.npz', **kw)
+
+
+def gen_switch(cfg, synthetic, variant, out_path):
+    """one relit frame of the reference under SWITCH_VARIANTS[variant] (cfg already carries the overrides; nothing of the reference's
+    hot path is imported yet, so values bound as default arguments see them too)"""
+    from relightableavatar_amd.config import make_cfg
+    my_cfg = make_cfg('relight')
+    for k, v in SWITCH_VARIANTS[variant].items():
+        node = my_cfg
+        parts = k.split('.')
+        for q in parts[:-1]:
+            node = node[q]
+        node[parts[-1]] = v
+    sd = synthetic.make_state_dict(0, relight=True, cfg=my_cfg)
+    from lib.networks.relight.relight_network import Network
+    from lib.networks.renderer import sphere_tracing_renderer
+    net = Network()
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not [m for m in missing if 'embedder' not in m], missing
+    net.eval()
+    H, crop = (GROUND_H, GROUND_CROP) if variant.startswith('g_') else (SWITCH_H, SWITCH_CROP)
+    batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop, skin_noise=0.0))
+    with torch.no_grad():
+        out = sphere_tracing_renderer.Renderer(net).render(batch)
+    arrs = {k: out[k].detach().cpu().numpy() for k in SWITCH_KEYS if k in out}
+    if variant.startswith('g_'):
+        arrs['wbounds_after'] = batch.wbounds.numpy()
+    if variant in ('base', 'no_geodesic_filter'):
+        # the distance field itself on points all around the body (where the neighbour rule matters: between the arms and the trunk,
+        # between the legs), the frame's window being a patch of the chest
+        body = to_ref_batch(synthetic.make_body(0, posed=True, skin_noise=0.0))
+        g = torch.Generator().manual_seed(91)
+        wb = body.wbounds[0]
+        x = wb[0] + (wb[1] - wb[0]) * torch.rand(3000, 3, generator=g)
+        with torch.no_grad():
+            arrs['hdq_x'] = x.numpy()
+            arrs['hdq_sdf'] = net.inference_world_distance_field(x[None], body, smooth_transition=True, dist_th=cfg.dist_th)[0].numpy()
+            arrs['hdq_sdf_coarse'] = net.world_to_bigpose(x[None], None, body, dist_th=cfg.dist_th).sdf_batch.mean(dim=-1)[0].numpy()
+    np.savez_compressed(out_path, **arrs)
+    print('switch', variant, {k: a.shape for k, a in arrs.items()})
 
 
 def gen_fields(net, cfg, synthetic):

@@ -488,6 +488,84 @@ def test_frame_relight_smooth_meets_the_contract(golden):
             assert float(d.min(1).values.max()) < tol and float(d.min(0).values.max()) < tol, (k, float(d.min(1).values.max()))
 
 
+# ---- the hot path's configuration switches: the reference under each override (tests/golden/switches.npz, one process per variant;
+# tests/test_oracle_frames.py pins the oracle on the same file)
+from test_oracle_frames import GROUND_SWITCH_NAMES, SWITCH_NAMES, switch_cfg, switch_variants      # noqa: E402
+
+
+@pytest.mark.parametrize('name', SWITCH_NAMES)
+def test_switch_matrix(golden, name):
+    """every switch of render_human / light_visibility / the microfacet model / the K-NN rule the reference's configs can flip
+    (sphere_tracing_renderer.py:36,275,295-300,720-757; relight_utils.py:563-566; relight_network.py:63-66; sample_utils.py:116),
+    one relit frame each against the reference's own output: SURVEY.md:409's contract on rgb, the other maps to their tolerances"""
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('switches.npz')
+    dev = _dev()
+    cfg = switch_cfg(switch_variants(ref)[name], mlp_dtype='f16')
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg))
+    net = net.to(dev).eval()
+    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), dev)
+    out = make_renderer(cfg, net).render(batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    assert ('spec_map' in sub) == ('spec_map' in out), name
+    assert bool(((out.acc_map.cpu() > 0) == (T(sub['acc_map']) > 0)).all())
+    case = 'switches.npz:' + (name if name in ('trace_params', 'no_geodesic_filter') else 'base')
+    assert_contract(out.rgb_map, sub['rgb_map'], case, f'switches.npz / {name}', all_rays=True)
+    assert float(err(out.surf_map, sub['surf_map']).max()) < 1e-4
+    assert float(err(out.albedo_map, sub['albedo_map']).max()) < 1e-3 and float(err(out.roughness_map, sub['roughness_map']).max()) < 1e-3
+    assert out.shade_map.shape == T(sub['shade_map']).shape, (name, out.shade_map.shape)
+    assert psnr(out.shade_map, sub['shade_map']) >= 50.0 and float(err(out.shade_map, sub['shade_map']).max()) < 2e-2
+    if 'spec_map' in sub:
+        within(out, sub, 'spec_map', 5e-3, 0.97)
+    if name + '.hdq_x' in ref:       # the distance field all around the body (base / no_geodesic_filter: the neighbour rule)
+        x = T(ref[name + '.hdq_x']).to(dev)
+        s = net.engine().hdq_sdf(x, cfg.dist_th, True).cpu()
+        e = err(s.reshape(-1), ref[name + '.hdq_sdf'].reshape(-1))
+        assert float(e.max()) < 3e-4, float(e.max())
+        # the coarse level's own answer (mean of the per-neighbour signed distances, or knn_with_filter's one value) is pure fp32
+        dbg = net.engine().debug_hdq(x, cfg.dist_th)
+        assert float(err(dbg.sdf_batch.mean(-1), ref[name + '.hdq_sdf_coarse']).max()) < 2e-6
+
+
+@pytest.mark.parametrize('name', GROUND_SWITCH_NAMES)
+def test_ground_switch_matrix(golden, name):
+    """the switches of the ground-plane pass (render_ground :463-548: hard shadows, the visibility / cosine maps, linear output, local
+    visibility, a plain ground colour + shading multiplier, the env_lvis trace settings incl. the box margin) against the reference's frames"""
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('switches.npz')
+    dev = _dev()
+    cfg = switch_cfg(switch_variants(ref)[name], mlp_dtype='f16')
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg))
+    net = net.to(dev).eval()
+    H = int(ref['ground_H'])
+    batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['ground_crop']), skin_noise=0.0), dev)
+    rend = make_renderer(cfg, net)
+    m = batch.mask_at_box.reshape(1, -1).cpu()
+    rend.ground_inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]   # the scatter order of the CPU reference run
+    out = rend.render(batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    np.testing.assert_allclose(batch.wbounds.cpu().numpy(), sub['wbounds_after'], atol=1e-6)
+    assert_contract(out.rgb_map, sub['rgb_map'], 'switches.npz:ground', f'switches.npz / {name}', bad=torch.zeros(H * H, dtype=torch.bool))
+    # hard shadows (visibility = clip(500 d / t)): one penumbra-less edge pixel of 576 lands at 7.8e-3
+    assert float((err(out.rgb_map, sub['rgb_map']) < 5e-3).float().mean()) > (0.995 if name == 'g_no_dfss' else 0.999)
+    assert float(err(out.albedo_map, sub['albedo_map']).max()) < 1e-2
+    assert float((err(out.shade_map, sub['shade_map']) < 5e-3).float().mean()) > 0.99
+    assert float((err(out.spec_map, sub['spec_map']) < 5e-3).float().mean()) > 0.99
+    assert float(err(out.acc_map, sub['acc_map']).max()) < 3e-2
+
+
+def test_only_visibility_refuses_the_layers_it_does_not_cover():
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight', only_visibility=True, vis_ground_shading=True)
+    batch = synthetic.to_device(synthetic.make_batch(24, 24, seed=0, posed=True, crop=6), dev)
+    with pytest.raises(NotImplementedError):
+        make_renderer(cfg, net).render(batch)
+
+
 def test_frame_relight(golden):
     out, ref, batch, net = _frame('relight', 'frame_relight.npz', golden, vis_specular_map=True)
     # the SURVEY 8d body (white noise in the skinning logits): the contract itself, no emulation-derived floor (round 3 asserted floor - 3 dB;

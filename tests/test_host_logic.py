@@ -472,6 +472,8 @@ def test_default_config_matches_the_python_defaults():
         assert abs(float(getattr(c, k)) - float(cfg[k])) < 1e-6, k
     assert c.relight == 1 and c.mlp_f16 == 1 and c.query_skip == 1 and c.tonemapping == 1 and c.lambert_only == 0 and c.glossy_only == 0
     assert abs(c.clip_near - 0.02) < 1e-7 and c.clip_far == 10.0
+    assert c.only_visibility == 0 and c.vis_shade_map == 0 and c.use_geodesic_filter == 1
+    assert not cfg.only_visibility and not cfg.vis_lvis_map and not cfg.vis_ldot_map and cfg.use_geodesic_filter
 
 
 def test_k3cc_fragment_registers_are_only_touched_by_name():

@@ -195,3 +195,82 @@ def test_fix_material_minus_one(golden):
     net0 = _net('anisdf', False, fix_material=0)
     raw0, _ = O.network_forward(net0, T(g['x']), T(g['v']), O._frame(body))
     assert float((raw0[:, 12:15] - T(g['raw'])[:, 12:15]).abs().max()) > 1e-3       # the other pose gives another colour
+
+
+# ---- the hot path's configuration switches (tests/golden/switches.npz: the reference under each override, one process per variant)
+def switch_variants(ref):
+    import json
+    return json.loads(str(ref['variants_json']))
+
+
+def switch_cfg(overrides, **kw):
+    """make_cfg('relight') + a variant's overrides ('a.b' addresses a sub-node)"""
+    cfg = make_cfg('relight', vis_specular_map=True, **kw)
+    for k, v in overrides.items():
+        node = cfg
+        parts = k.split('.')
+        for q in parts[:-1]:
+            node = node[q]
+        node[parts[-1]] = v
+    return cfg
+
+
+SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibility', 'lambert_only', 'glossy_only', 'linear', 'only_visibility',
+                'vis_lvis_map', 'vis_ldot_map', 'chromatic', 'material_params', 'trace_params', 'no_specular_vis', 'no_geodesic_filter']
+
+
+GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis']
+
+
+# the oracle's ground pass takes 40 s per frame: two variants here (the restated visibility map, the plain ground), all eight in the GPU suite
+@pytest.mark.parametrize('name', ['g_vis_lvis_map', 'g_plain_ground'])
+def test_ground_switch_matrix(golden, name):
+    """the same switches through the ground-plane pass (render_ground :463-548, blend_output_): frame_ground.npz's frame on the smooth body"""
+    ref = golden('switches.npz')
+    cfg = switch_cfg(switch_variants(ref)[name])
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg)
+    H = int(ref['ground_H'])
+    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['ground_crop']), skin_noise=0.0)
+    m = batch.mask_at_box.reshape(1, -1)
+    inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]      # the order the (CPU) reference run scattered with
+    out = O.render_sphere_tracing(net, batch, ground_inds=inds)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    np.testing.assert_allclose(batch.wbounds.numpy(), sub['wbounds_after'], atol=1e-6)
+    _cmp(out, sub, 'acc_map', 5e-3)
+    _cmp(out, sub, 'albedo_map', 2e-4)
+    tol = 1e-3 if name == 'g_no_dfss' else 3e-4      # hard shadows: visibility = clip(500 d / t), fp32 re-association x 500
+    _cmp(out, sub, 'rgb_map', tol, frac_ok=0.999)
+    _cmp(out, sub, 'shade_map', tol, frac_ok=0.999)
+    _cmp(out, sub, 'spec_map', 5e-4, frac_ok=0.999)
+    assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > 60
+
+
+@pytest.mark.parametrize('name', SWITCH_NAMES)
+def test_switch_matrix(golden, name):
+    ref = golden('switches.npz')
+    variants = switch_variants(ref)
+    assert sorted(variants) == sorted(SWITCH_NAMES + GROUND_SWITCH_NAMES)
+    cfg = switch_cfg(variants[name])
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg)
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0)
+    out = O.render_sphere_tracing(net, batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    assert ('spec_map' in sub) == ('spec_map' in out), name
+    assert bool(((out.acc_map > 0) == (T(sub['acc_map']) > 0)).all())
+    for k in ('surf_map', 'albedo_map', 'roughness_map'):
+        _cmp(out, sub, k, 1e-4)
+    _cmp(out, sub, 'norm_map', 2e-3)
+    _cmp(out, sub, 'rgb_map', 3e-4)
+    _cmp(out, sub, 'shade_map', 3e-4)
+    if 'spec_map' in sub:
+        _cmp(out, sub, 'spec_map', 1e-3)
+    assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > 70
+    if name + '.hdq_x' in ref:       # the distance field itself all around the body (base / no_geodesic_filter)
+        fr = O._frame(synthetic.make_body(0, posed=True, skin_noise=0.0))
+        parts = O.hdq_sdf(net, T(ref[name + '.hdq_x']), fr, cfg.dist_th, True, return_parts=True)
+        np.testing.assert_allclose(parts.sdf_batch.mean(-1).numpy(), ref[name + '.hdq_sdf_coarse'], atol=2e-6)
+        np.testing.assert_allclose(parts.sdf.numpy(), ref[name + '.hdq_sdf'], atol=2e-5)
+    if name != 'base':      # the switch does something on this frame (a variant equal to the base frame would pin nothing)
+        base = {k[5:]: v for k, v in ref.items() if k.startswith('base.')}
+        differs = any(sub[k].shape != base[k].shape or not np.array_equal(sub[k], base[k]) for k in sub if k in base) or set(sub) != set(base)
+        assert differs, name

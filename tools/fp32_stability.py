@@ -42,7 +42,22 @@ CASES = {
     'full_size_sample': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=0.0), 1024)[0]),
     'bench_sample': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=2.0), 512)[0]),
     'bench_sample_smooth': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=0.0), 512)[0]),
+    # tests/golden/switches.npz: one window, traced under three different settings (the other variants trace like 'base')
+    'switches.npz:base': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0)),
+    'switches.npz:trace_params': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'trace_params'),
+    'switches.npz:no_geodesic_filter': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'no_geodesic_filter'),
 }
+
+
+def switch_overrides(cfg, variant):
+    import numpy as np
+    v = json.loads(str(np.load(os.path.join(ROOT, 'tests', 'golden', 'switches.npz'))['variants_json']))[variant]
+    for k, val in v.items():
+        node = cfg
+        parts = k.split('.')
+        for q in parts[:-1]:
+            node = node[q]
+        node[parts[-1]] = val
 
 
 def main():
@@ -54,8 +69,10 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     probs_only = '--probs' in sys.argv          # keep the committed lists, only (re)compute the flip probabilities of the listed rays
     for name in (args or list(CASES)):
-        mode, mk = CASES[name]
+        mode, mk = CASES[name][:2]
         cfg = make_cfg(mode)
+        if len(CASES[name]) > 2:
+            switch_overrides(cfg, CASES[name][2])
         relight = mode in ('relight', 'novel_light')
         net = O.OracleNet(synthetic.make_state_dict(0, relight=relight, cfg=cfg), cfg)
         t0 = time.time()
