@@ -835,7 +835,11 @@ def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
         if c.albedo_multiplier > 0:
             albedo = albedo * c.albedo_multiplier
         ret.albedo_map, ret.roughness_map = albedo, rough[:, 0]
-    if c.relighting:
+    # :702-705: with none of the rendering / shading / specular maps wanted, render_human returns before any shading (no rgb_map)
+    early = not (c.get('vis_rendering_map', True) or c.get('vis_shading_map', False) or c.get('vis_specular_map', False))
+    if early:
+        pass
+    elif c.relighting:
         snet = net.shadow_net or net                                   # tiered precision (tools/precision_tiers.py)
         lvis, ldot = light_visibility(net, surf, norm, acc, fr, bbox, c.obj_lvis,
                                       lambda th: (lambda x: hdq_sdf(snet, x, fr, th, True)))

@@ -24,6 +24,27 @@ def active_cfg():
     return _ACTIVE
 
 
+# Switches of the reference's hot path that this build does NOT reproduce — each either cannot run in the reference release itself or needs
+# a third-party CUDA extension.  A cfg carrying one of them away from its default is refused (make_renderer / make_network), never ignored.
+UNSUPPORTED = {
+    'bruteforce_st': (False, 'render_bruteforce_human (sphere_tracing_renderer.py:787-940) needs lib/networks/relight/nerfactor_network.py, '
+                             'which the reference release does not contain'),
+    'smpl_distance': (False, 'the SMPL mesh distance (base_network.py:417-427) needs the bvh_distance_queries CUDA extension'),
+    'ablate_hdq_mode': ('hdq', "the world / can / curve tracing modes (sphere_tracing_renderer.py:141-151) call world_to_bigpose_transform, "
+                               "which raises on the dataset's Th of shape (B, 1, 3); the operators exist: ra_observed_sdf, ra_bigpose_transform"),
+    'check_bound_sdf': (False, 'debug colour map of |sdf| at termination (sphere_tracing_renderer.py:577-587, needs easyvolcap)'),
+    'geometry_normal': (False, 'part of render_bruteforce_human'),
+    'geometry_visibility': (False, 'part of render_bruteforce_human'),
+    'zero_roughness': (False, 'part of render_bruteforce_human'),
+}
+
+
+def check_supported(cfg):
+    for k, (default, why) in UNSUPPORTED.items():
+        if k in cfg and cfg[k] != default:
+            raise NotImplementedError(f'cfg.{k} = {cfg[k]!r} is not supported: {why}')
+
+
 def default_cfg() -> dotdict:
     c = dotdict()
     # plugin selection (lib/networks/make_network.py:4-7, renderer/make_renderer.py:5-8)

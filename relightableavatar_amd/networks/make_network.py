@@ -7,5 +7,6 @@ from .. import config
 
 
 def make_network(cfg):
+    config.check_supported(cfg)
     config.set_active_cfg(cfg)
     return importlib.import_module(cfg.network_module).Network()

@@ -5,5 +5,6 @@ from .. import config
 
 
 def make_renderer(cfg, network):
+    config.check_supported(cfg)
     config.set_active_cfg(cfg)
     return importlib.import_module(cfg.renderer_module).Renderer(network)

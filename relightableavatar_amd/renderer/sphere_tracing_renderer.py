@@ -59,6 +59,13 @@ class Renderer(nn.Module):
         ground = bool(cfg.vis_ground_shading) and not self.net.training
         if ground and not (cfg.relighting and hasattr(self.net, 'global_env_map')):
             raise ValueError('vis_ground_shading needs the relighting renderer (light set + probe)')
+        # render_human's early return (:702-705): with none of the rendering / shading / specular maps wanted there is no shading at all —
+        # no light visibility, no rgb_map — only the geometry and material maps (the reference's albedo / normal visualisations)
+        early = not (cfg.get('vis_rendering_map', True) or cfg.get('vis_shading_map', False) or cfg.get('vis_specular_map', False)) \
+            and not self.net.training
+        if early and (ground or cfg.vis_novel_light):
+            raise NotImplementedError('vis_rendering_map / vis_shading_map / vis_specular_map all off leaves no rgb_map for the ground pass / '
+                                      'the novel-light re-shade (the reference fails there too)')
         only_vis = bool(cfg.get('only_visibility', False)) and bool(cfg.relighting)
         if only_vis and (ground or cfg.vis_novel_light):
             # the reference's debugging option (:516-519, :720-723) turns shade / spec of the ground layer into one-channel maps that its
@@ -74,11 +81,12 @@ class Renderer(nn.Module):
         if envmap is not None:
             probe = envmap.probe
             probe = (probe[0] if probe.ndim == 4 else probe).to(dev, torch.float32).contiguous()
-        relit = bool(cfg.relighting)
+        relit = bool(cfg.relighting) and not early
         params = eng.sphere_params()
+        params.relighting = int(relit)
         if ground:
             params.premultiply = 0          # blend_output_ replaces alpha_output_ (:1108-1113)
-        names = ['rgb', 'acc', 'depth', 'surf', 'norm', 'cpts', 'bpts', 'resd', 'ray_o']
+        names = ([] if early else ['rgb']) + ['acc', 'depth', 'surf', 'norm', 'cpts', 'bpts', 'resd', 'ray_o']
         if eng.relight:
             names += ['albedo', 'roughness']
         if relit:
@@ -135,7 +143,8 @@ class Renderer(nn.Module):
         ret.cpts_map, ret.bpts_map, ret.resd_map, ret.norm_map = full.cpts[None], full.bpts[None], full.resd[None], full.norm[None]
         if eng.relight:
             ret.albedo_map, ret.roughness_map = full.albedo[None], full.roughness[None]
-        ret.rgb_map = full.rgb[None]
+        if not early:
+            ret.rgb_map = full.rgb[None]
         if relit:
             # only_visibility: a one-channel light (:723, :749-751); vis_lvis_map / vis_ldot_map expand to three (:756-757)
             one_ch = only_vis and not (cfg.get('vis_lvis_map', False) or cfg.get('vis_ldot_map', False))

@@ -137,6 +137,7 @@ SWITCH_VARIANTS = {
                      'obj_lvis.iter': 6, 'obj_lvis.offset': 0.02, 'obj_lvis.near_offset': 0.03, 'obj_lvis.relax': 0.1, 'surf_sample_range': 0.01},
     'no_specular_vis': {'vis_specular_map': False, 'bg_brightness': 0.5},
     'no_geodesic_filter': {'use_geodesic_filter': False},
+    'maps_only': {'vis_rendering_map': False, 'vis_specular_map': False},      # render_human's early return (:702-705): no shading at all
 }
 # the same for the ground-plane pass (render_ground :463-548 + blend_output_): names start with g_, the frame is frame_ground.npz's
 # (24 x 24, 10 x 10 window, two ground chunks) on the smooth body

@@ -509,14 +509,19 @@ def test_switch_matrix(golden, name):
     batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), dev)
     out = make_renderer(cfg, net).render(batch)
     sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
-    assert ('spec_map' in sub) == ('spec_map' in out), name
+    for k in ('rgb_map', 'shade_map', 'spec_map'):      # maps_only: render_human's early return (:702-705) leaves none of them
+        assert (k in sub) == (k in out), (name, k)
     assert bool(((out.acc_map.cpu() > 0) == (T(sub['acc_map']) > 0)).all())
     case = 'switches.npz:' + (name if name in ('trace_params', 'no_geodesic_filter') else 'base')
-    assert_contract(out.rgb_map, sub['rgb_map'], case, f'switches.npz / {name}', all_rays=True)
     assert float(err(out.surf_map, sub['surf_map']).max()) < 1e-4
     assert float(err(out.albedo_map, sub['albedo_map']).max()) < 1e-3 and float(err(out.roughness_map, sub['roughness_map']).max()) < 1e-3
-    assert out.shade_map.shape == T(sub['shade_map']).shape, (name, out.shade_map.shape)
-    assert psnr(out.shade_map, sub['shade_map']) >= 50.0 and float(err(out.shade_map, sub['shade_map']).max()) < 2e-2
+    assert float((err(out.norm_map, sub['norm_map']) < 2e-2).float().mean()) > 0.97
+    if 'rgb_map' in sub:
+        assert_contract(out.rgb_map, sub['rgb_map'], case, f'switches.npz / {name}', all_rays=True)
+        assert out.shade_map.shape == T(sub['shade_map']).shape, (name, out.shade_map.shape)
+        assert psnr(out.shade_map, sub['shade_map']) >= 50.0 and float(err(out.shade_map, sub['shade_map']).max()) < 2e-2
+    else:
+        assert net.engine().counters().n_shadow_rays == 0          # and no light visibility was traced for it
     if 'spec_map' in sub:
         within(out, sub, 'spec_map', 5e-3, 0.97)
     if name + '.hdq_x' in ref:       # the distance field all around the body (base / no_geodesic_filter: the neighbour rule)

@@ -485,3 +485,18 @@ def test_k3cc_fragment_registers_are_only_touched_by_name():
     problems, stats = check_k3cc_isa.check()
     assert not problems, problems[:5]
     assert stats['agpr_reads'] == 8 * stats['waits']
+
+
+def test_unsupported_reference_switches_are_refused_not_ignored():
+    """switches of the reference's hot path this build does not reproduce (each cannot run in the reference release either, or needs a
+    third-party CUDA extension) raise at make_network / make_renderer; at their defaults they pass"""
+    from relightableavatar_amd import config
+    from relightableavatar_amd.config import make_cfg
+    config.check_supported(make_cfg('relight'))
+    config.check_supported(make_cfg('relight', ablate_hdq_mode='hdq', bruteforce_st=False))
+    for k, v in (('bruteforce_st', True), ('smpl_distance', True), ('ablate_hdq_mode', 'world'), ('check_bound_sdf', True), ('zero_roughness', True)):
+        with pytest.raises(NotImplementedError, match=k):
+            config.check_supported(make_cfg('relight', **{k: v}))
+    from relightableavatar_amd.networks import make_network
+    with pytest.raises(NotImplementedError):
+        make_network(make_cfg('relight', smpl_distance=True))
