@@ -150,17 +150,24 @@ def shift_envmap(image: torch.Tensor, shift: float):
     return F.grid_sample(image.permute(2, 0, 1)[None], grid, align_corners=False, mode='bilinear', padding_mode='border')[0].permute(1, 2, 0)
 
 
-def rotate_envmap(novel_lights, index, repeat, probe_width):
-    """rotate_envmap relight_utils.py:57-103 (probe only): (name, rotated probe (eH,eW,3))."""
+def rotate_envmap(novel_lights, index, repeat, probe_width, with_image=False):
+    """rotate_envmap relight_utils.py:57-103: (name, rotated probe (eH,eW,3)) — with_image: (name, probe, rotated image or None)."""
     keys = list(novel_lights.keys())
-    pr = lambda e: e['probe'][0] if e['probe'].ndim == 4 else e['probe']
+    pr = lambda e, k='probe': e[k][0] if e[k].ndim == 4 else e[k]
     if repeat <= 0:
-        return keys[index], pr(novel_lights[keys[index]])
+        e = novel_lights[keys[index]]
+        return (keys[index], pr(e), pr(e, 'image') if 'image' in e else None) if with_image else (keys[index], pr(e))
     n_rotation = probe_width * repeat
     i, j = index // n_rotation, index % n_rotation
-    probe = pr(novel_lights[keys[i]])
+    e = novel_lights[keys[i]]
+    probe = pr(e)
     eW = probe.shape[1]
-    return f'{keys[i]}-{j:04d}', shift_envmap(probe, eW / (eW * repeat) * j)
+    uW = eW * repeat
+    name, rot = f'{keys[i]}-{j:04d}', shift_envmap(probe, eW / uW * j)
+    if not with_image:
+        return name, rot
+    image = pr(e, 'image') if 'image' in e else None
+    return name, rot, (shift_envmap(image, image.shape[1] / uW * j) if image is not None else None)
 
 
 def probe_axes(cam_R):
@@ -1096,7 +1103,14 @@ def render_novel_light(net: OracleNet, batch, ground_inds=None):
         if grd is not None:
             m = blend_output_(grd.acc_map, grd.inds, grd, odict({k: v[0] for k, v in relight.main.items()}))
             relight.main = odict({k: v[None] for k, v in m.items()})
-    for name, env in batch['novel_lights'].items():
+    lights = batch['novel_lights']
+    if c.get('vis_rotate_light', False) and len(lights):      # :163-171: every probe at rotate_ratio * env_w headings
+        rot = odict()
+        for i in range(len(lights) * c.rotate_ratio * c.env_w):
+            name, probe, image = rotate_envmap(lights, i, c.rotate_ratio, c.env_w, with_image=True)
+            rot[name] = odict(probe=probe[None], **({'image': image[None]} if image is not None else {}))
+        lights = rot
+    for name, env in lights.items():
         probe = env['probe'][0].float()
         rgbs, shades, specs = [], [], []
         P = main.ray_o.shape[1]
@@ -1114,7 +1128,12 @@ def render_novel_light(net: OracleNet, batch, ground_inds=None):
             full = odict({k: main[k][0] for k in visual if k in main})
             full.update(human)
             human = blend_output_(grd.acc_map, grd.inds, ground, full)
+        else:
+            full = odict({k: main[k][0] for k in visual if k in main})          # human = dotdict({**main, **human}) (:188)
+            full.update(human)
+            human = full
         relight[name] = odict({k: v[None] for k, v in human.items()})
+        relight[name].envmap = odict(probe=env['probe'])
     relight._main_full = main
     return relight
 

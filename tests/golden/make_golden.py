@@ -13,6 +13,7 @@ One process per mode, because the reference binds cfg values as default argument
 (SURVEY.md §5 "config / flags" gotcha).
 """
 import argparse
+import json
 import os
 import sys
 import types
@@ -152,6 +153,29 @@ SWITCH_VARIANTS.update({
     'g_plain_ground': {'ground_attach_envmap': False, 'ground_albedo': [0.3, 0.2, 0.1], 'ground_shading_multiplier': 2.0},
     'g_env_lvis': {'env_lvis.iter': 8, 'env_lvis.offset': 0.02, 'env_lvis.dist_th': 0.01, 'env_lvis.bbox_margin': 0.3, 'env_lvis.near_offset': 0.03},
 })
+# and for the volume path (base_renderer.py:17,72,120-121): names start with v_, AniSDF network, an 8 x 8 window, 64 samples unless overridden
+SWITCH_VARIANTS.update({
+    'v_bg': {'bg_brightness': 0.5},
+    'v_clip': {'clip_near': 1.7, 'clip_far': 2.4},
+    'v_s16_chunks': {'n_samples': 16, 'render_chunk_size': 24},
+})
+VOLUME_H, VOLUME_CROP = 128, 8
+# and the novel-light renderer's rotating-light sequence (novel_light_sphere_tracing.py:163-171, relight_utils.py:55-110): names start with
+# n_; one probe with a full-resolution image, rotate_ratio * env_w headings re-shaded from one traced frame, four of them stored
+SWITCH_VARIANTS.update({
+    'n_rotate': {'vis_novel_light': True, 'vis_rotate_light': True, 'rotate_ratio': 1, 'test_light': ['main']},
+    'n_rotate_ground': dict(GROUND_BASE, **{'vis_novel_light': True, 'vis_rotate_light': True, 'rotate_ratio': 2, 'test_light': []}),
+})
+NOVEL_H, NOVEL_CROP, NOVEL_GROUND_H = 128, 6, 16
+NOVEL_HEADINGS = (0, 5, 16, 31)
+
+
+def novel_light_with_image(synthetic, env_image_w):
+    """one synthetic probe + a full-resolution image of it (the dataset delivers both; rotate_envmap shifts both)"""
+    lights = synthetic.make_novel_lights(1, 0)
+    g = torch.Generator().manual_seed(5)
+    lights['probe00'].image = torch.rand(1, env_image_w // 2, env_image_w, 3, generator=g) * 2.0
+    return lights
 for _k in [k for k in SWITCH_VARIANTS if k.startswith('g_')]:
     SWITCH_VARIANTS[_k] = dict(GROUND_BASE, **SWITCH_VARIANTS[_k])
 SWITCH_H, SWITCH_CROP = 128, 10
@@ -199,6 +223,7 @@ def main():
         import tempfile
         import json
         merged = dict(H=np.asarray(SWITCH_H), crop=np.asarray(SWITCH_CROP), ground_H=np.asarray(GROUND_H), ground_crop=np.asarray(GROUND_CROP),
+                      volume_H=np.asarray(VOLUME_H), volume_crop=np.asarray(VOLUME_CROP),
                       variants_json=np.asarray(json.dumps(SWITCH_VARIANTS)))
         with tempfile.TemporaryDirectory() as tmp:
             for name in SWITCH_VARIANTS:
@@ -225,7 +250,7 @@ def main():
     if mode == 'visual':
         gen_visual(cfg, synthetic)
         return
-    set_cfg(cfg, 'relight' if mode == 'switch' else mode)
+    set_cfg(cfg, ('anisdf' if args.variant.startswith('v_') else 'relight') if mode == 'switch' else mode)
     if mode == 'switch':
         cfg.vis_specular_map = True
         apply_overrides(cfg, SWITCH_VARIANTS[args.variant])
@@ -344,6 +369,48 @@ def gen_switch(cfg, synthetic, variant, out_path):
     """one relit frame of the reference under SWITCH_VARIANTS[variant] (cfg already carries the overrides; nothing of the reference's
     hot path is imported yet, so values bound as default arguments see them too)"""
     from relightableavatar_amd.config import make_cfg
+    if variant.startswith('n_'):
+        from lib.networks.renderer import novel_light_sphere_tracing
+        from lib.networks.relight.relight_network import Network
+        my_cfg = make_cfg('novel_light')
+        cfg.env_image_w = 64
+        net = Network()
+        missing, unexpected = net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=my_cfg), strict=False)
+        assert not unexpected and not [m for m in missing if 'embedder' not in m], (missing, unexpected)
+        net.eval()
+        ground = 'ground' in variant
+        H = NOVEL_GROUND_H if ground else NOVEL_H
+        batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=NOVEL_CROP, skin_noise=0.0))
+        batch.novel_lights = to_ref_batch(novel_light_with_image(synthetic, 64))
+        with torch.no_grad():
+            out = novel_light_sphere_tracing.Renderer(net).render(batch)
+        names = [k for k in out if k != 'diff']
+        arrs = {'names': np.asarray(json.dumps(names))}
+        keep = (['main'] if 'main' in out else []) + [f'probe00-{j:04d}' for j in NOVEL_HEADINGS]
+        for name in keep:
+            for k in ('rgb_map', 'shade_map', 'spec_map', 'albedo_map', 'acc_map'):
+                if k in out[name]:
+                    arrs[f'{name}/{k}'] = out[name][k].detach().cpu().numpy()
+            arrs[f'{name}/probe'] = out[name].envmap.probe.detach().cpu().numpy()
+        np.savez_compressed(out_path, **arrs)
+        print('switch', variant, len(names), 'outputs;', {k: a.shape for k, a in arrs.items() if k.startswith('probe00-0005')})
+        return
+    if variant.startswith('v_'):
+        my_cfg = make_cfg('anisdf', n_samples=64)
+        sd = synthetic.make_state_dict(0, relight=False, cfg=my_cfg)
+        from lib.networks.deform.base_network import Network
+        from lib.networks.renderer import base_renderer
+        net = Network()
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected and not [m for m in missing if 'embedder' not in m], (missing, unexpected)
+        net.eval()
+        batch = to_ref_batch(synthetic.make_batch(VOLUME_H, VOLUME_H, seed=0, posed=True, crop=VOLUME_CROP, skin_noise=0.0))
+        with torch.no_grad():
+            out = base_renderer.Renderer(net).render(batch)
+        arrs = {k: out[k].detach().cpu().numpy() for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'cpts_map', 'resd_map')}
+        np.savez_compressed(out_path, **arrs)
+        print('switch', variant, {k: a.shape for k, a in arrs.items()})
+        return
     my_cfg = make_cfg('relight')
     for k, v in SWITCH_VARIANTS[variant].items():
         node = my_cfg

@@ -490,7 +490,8 @@ def test_frame_relight_smooth_meets_the_contract(golden):
 
 # ---- the hot path's configuration switches: the reference under each override (tests/golden/switches.npz, one process per variant;
 # tests/test_oracle_frames.py pins the oracle on the same file)
-from test_oracle_frames import GROUND_SWITCH_NAMES, SWITCH_NAMES, switch_cfg, switch_variants      # noqa: E402
+from test_oracle_frames import (GROUND_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, novel_switch_case, switch_cfg,      # noqa: E402
+                                switch_variants, volume_switch_cfg)
 
 
 @pytest.mark.parametrize('name', SWITCH_NAMES)
@@ -561,6 +562,64 @@ def test_ground_switch_matrix(golden, name):
     assert float((err(out.shade_map, sub['shade_map']) < 5e-3).float().mean()) > 0.99
     assert float((err(out.spec_map, sub['spec_map']) < 5e-3).float().mean()) > 0.99
     assert float(err(out.acc_map, sub['acc_map']).max()) < 3e-2
+
+
+@pytest.mark.parametrize('name', VOLUME_SWITCH_NAMES)
+def test_volume_switch_matrix(golden, name):
+    """the volume renderer's switches (base_renderer.py:17,72,120-121) against the reference: background brightness, an active near / far
+    clip (ra_config.clip_near / clip_far), another sample count over several render chunks"""
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('switches.npz')
+    dev = _dev()
+    cfg = volume_switch_cfg(switch_variants(ref)[name], mlp_dtype='f16')
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=False, cfg=cfg))
+    net = net.to(dev).eval()
+    H = int(ref['volume_H'])
+    batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['volume_crop']), skin_noise=0.0), dev)
+    out = make_renderer(cfg, net).render(batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    # v_bg: volume_rendering adds (1 - acc) * bg_brightness to EVERY composited channel (net_utils.py:970-999: cpts, resd, norm too), so
+    # each map carries the f16 path's alpha error (<= 5e-4) times 0.5
+    bg = name == 'v_bg'
+    for k, tol in (('acc_map', 5e-4), ('depth_map', 1e-3), ('cpts_map', 5e-4 if bg else 2e-4), ('resd_map', 5e-4 if bg else 1e-5), ('norm_map', 2e-3),
+                   ('rgb_map', 5e-4 if bg else 3e-4)):
+        within(out, sub, k, tol, 1.0)
+    assert psnr(out.rgb_map, sub['rgb_map']) > (70 if bg else 80)
+
+
+@pytest.mark.parametrize('name', NOVEL_SWITCH_NAMES)
+def test_novel_switch_matrix(golden, name):
+    """cfg.vis_rotate_light (novel_light_sphere_tracing.py:163-171, relight_utils.py:55-110) against the reference: the sequence of names,
+    the rotated probe of every stored heading and its re-shaded frame; with the ground pass the rotated IMAGE colours the ground and
+    every heading is blended on its own"""
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('switches.npz')
+    cfg, mk, want, names = novel_switch_case(ref, name)
+    cfg.mlp_dtype = 'f16'
+    dev = _dev()
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg))
+    net = net.to(dev).eval()
+    batch = synthetic.to_device(mk(), dev)
+    rend = make_renderer(cfg, net)
+    m = batch.mask_at_box.reshape(1, -1).cpu()
+    if 'ground' in name:
+        rend.ground_inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]
+    out = rend.render(batch)
+    assert [k for k in out if k != 'diff'] == names
+    for out_name, maps in want.items():
+        if out_name != 'main':
+            assert float(err(out[out_name].envmap.probe.reshape(maps['probe'].shape), maps['probe']).max()) < 1e-5
+        e = err(out[out_name].rgb_map, maps['rgb_map'])
+        p = float(-10 * torch.log10(torch.mean(e ** 2)))
+        print(f'{name} / {out_name}: rgb PSNR {p:.1f} dB, max {float(e.max()):.2e}')
+        assert p >= 50.0 and float(e.max()) <= 1e-2, (out_name, p, float(e.max()))
+        assert float((err(out[out_name].shade_map, maps['shade_map']) < 5e-3).float().mean()) > 0.99
+        assert float((err(out[out_name].spec_map, maps['spec_map']) < 5e-3).float().mean()) > 0.97
+        assert float(err(out[out_name].albedo_map, maps['albedo_map']).max()) < 1e-2
 
 
 def test_only_visibility_refuses_the_layers_it_does_not_cover():

@@ -1,4 +1,6 @@
 """Oracle vs whole-frame outputs of the reference renderers (tests/golden/frame_*.npz). CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -222,8 +224,9 @@ SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibi
 GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis']
 
 
-# the oracle's ground pass takes 40 s per frame: two variants here (the restated visibility map, the plain ground), all eight in the GPU suite
-@pytest.mark.parametrize('name', ['g_vis_lvis_map', 'g_plain_ground'])
+# the oracle's ground pass takes 40 s per frame: ONE variant in the CPU suite (the restated visibility map; RA_ALL_GROUND_VARIANTS=1 runs all
+# eight, 5 minutes — done once when the fixture was made), all eight in the GPU suite against the reference's frames directly
+@pytest.mark.parametrize('name', GROUND_SWITCH_NAMES if os.environ.get('RA_ALL_GROUND_VARIANTS') else ['g_vis_lvis_map'])
 def test_ground_switch_matrix(golden, name):
     """the same switches through the ground-plane pass (render_ground :463-548, blend_output_): frame_ground.npz's frame on the smooth body"""
     ref = golden('switches.npz')
@@ -245,11 +248,78 @@ def test_ground_switch_matrix(golden, name):
     assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > 60
 
 
+VOLUME_SWITCH_NAMES = ['v_bg', 'v_clip', 'v_s16_chunks']
+NOVEL_SWITCH_NAMES = ['n_rotate', 'n_rotate_ground']
+
+
+def novel_switch_case(ref, name):
+    """(cfg, batch factory, {output name: {map: array}}) of a rotating-light variant"""
+    import json
+    cfg = make_cfg('novel_light', env_image_w=64, vis_specular_map=True)      # the generator's switch mode sets vis_specular_map
+    cfg.update(switch_variants(ref)[name])
+    H = int(ref['novel_ground_H'] if 'ground' in name else ref['novel_H'])
+
+    def mk():
+        b = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['novel_crop']), skin_noise=0.0)
+        b.novel_lights = synthetic.make_novel_lights(1, 0)
+        g = torch.Generator().manual_seed(5)
+        b.novel_lights['probe00'].image = torch.rand(1, 32, 64, 3, generator=g) * 2.0
+        return b
+    want = {}
+    for k, v in ref.items():
+        if k.startswith(name + '.') and '/' in k:
+            out_name, key = k[len(name) + 1:].split('/')
+            want.setdefault(out_name, {})[key] = v
+    return cfg, mk, want, json.loads(str(ref[name + '.names']))
+
+
+@pytest.mark.parametrize('name', NOVEL_SWITCH_NAMES)
+def test_novel_switch_matrix(golden, name):
+    """cfg.vis_rotate_light (novel_light_sphere_tracing.py:163-171, relight_utils.py:55-110): every heading's name, rotated probe and
+    re-shaded frame — human layer alone, and blended per light with the re-shaded ground (the rotated IMAGE colours the ground)"""
+    ref = golden('switches.npz')
+    cfg, mk, want, names = novel_switch_case(ref, name)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg)
+    batch = mk()
+    m = batch.mask_at_box.reshape(1, -1)
+    inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]
+    out = O.render_novel_light(net, batch, ground_inds=inds if 'ground' in name else None)
+    assert [k for k in out if not k.startswith('_')] == names
+    for out_name, maps in want.items():
+        np.testing.assert_allclose(out[out_name].envmap.probe.numpy() if out_name != 'main' else maps['probe'], maps['probe'], atol=2e-6)
+        for k, tol in (('rgb_map', 4e-4), ('shade_map', 1e-3), ('spec_map', 2e-3), ('albedo_map', 2e-4)):
+            if k in maps:
+                _cmp(out[out_name], maps, k, tol, frac_ok=0.999)
+
+
+def volume_switch_cfg(overrides, **kw):
+    cfg = make_cfg('anisdf', n_samples=64, **kw)
+    cfg.update(overrides)
+    return cfg
+
+
+@pytest.mark.parametrize('name', VOLUME_SWITCH_NAMES)
+def test_volume_switch_matrix(golden, name):
+    """the volume renderer's switches (base_renderer.py:17,72,120-121): background brightness, an active near / far clip, another sample
+    count over several render chunks"""
+    ref = golden('switches.npz')
+    cfg = volume_switch_cfg(switch_variants(ref)[name])
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=False, cfg=cfg), cfg)
+    H = int(ref['volume_H'])
+    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['volume_crop']), skin_noise=0.0)
+    out = O.render_volume(net, batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    for k in ('acc_map', 'depth_map', 'cpts_map', 'resd_map'):
+        _cmp(out, sub, k, 2e-5)
+    _cmp(out, sub, 'norm_map', 2e-4)
+    _cmp(out, sub, 'rgb_map', 2e-5)
+
+
 @pytest.mark.parametrize('name', SWITCH_NAMES)
 def test_switch_matrix(golden, name):
     ref = golden('switches.npz')
     variants = switch_variants(ref)
-    assert sorted(variants) == sorted(SWITCH_NAMES + GROUND_SWITCH_NAMES)
+    assert sorted(variants) == sorted(SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES)
     cfg = switch_cfg(variants[name])
     net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg)
     batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0)
