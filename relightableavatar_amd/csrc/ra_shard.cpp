@@ -2,9 +2,14 @@
 // one node, in ONE pass over the frame's mask instead of a dozen numpy passes (1.1-2.8 ms of Python per frame and rank were a quarter of
 // a 4.5 ms frame at eight ranks).  No device work; the index vectors are written straight into the caller's (pinned) staging block.
 // The reference has no multi-GPU inference (run.py is single-process): SURVEY.md 8e.
-#include "ra_common.hpp"
 #include <cstring>
+#include <string>
 #include <vector>
+
+#include "../../include/relightableavatar.h"
+
+// plain host C++ (no HIP header): tests/native/shard_fuzz.cpp compiles this file with g++ -fsanitize=address,undefined
+void ra_set_error(const std::string& msg);
 
 extern "C" int ra_shard_plan(const unsigned char* mask, int H, int W, int world, int ground, long long P, const long long* ground_pos,
                              const long long* edges, int n_edges, unsigned char* owner, long long* order, long long* src, long long* inds,
