@@ -139,6 +139,13 @@ SWITCH_VARIANTS = {
     'no_specular_vis': {'vis_specular_map': False, 'bg_brightness': 0.5},
     'no_geodesic_filter': {'use_geodesic_filter': False},
     'maps_only': {'vis_rendering_map': False, 'vis_specular_map': False},      # render_human's early return (:702-705): no shading at all
+    # structural parameters: one material sample per hit (zval = 0.5, :608-609), five; light sets of other sizes (45 lights: not a multiple
+    # of a wavefront; the learned map at 1x / 3x the probe's size); a single shadow iteration from iteration 0
+    'one_sample': {'n_samples': 1},
+    'five_samples': {'n_samples': 5, 'surf_sample_range': 0.02},
+    'small_probe': {'env_h': 8, 'env_w': 16, 'envmap_upscale': 1},
+    'odd_probe': {'env_h': 5, 'env_w': 9, 'envmap_upscale': 3},
+    'one_shadow_iter': {'obj_lvis.iter': 1, 'sphere_tracing.shadow_skip_iter': 0},
 }
 # the same for the ground-plane pass (render_ground :463-548 + blend_output_): names start with g_, the frame is frame_ground.npz's
 # (24 x 24, 10 x 10 window, two ground chunks) on the smooth body

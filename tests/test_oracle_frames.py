@@ -218,7 +218,8 @@ def switch_cfg(overrides, **kw):
 
 
 SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibility', 'lambert_only', 'glossy_only', 'linear', 'only_visibility',
-                'vis_lvis_map', 'vis_ldot_map', 'chromatic', 'material_params', 'trace_params', 'no_specular_vis', 'no_geodesic_filter', 'maps_only']
+                'vis_lvis_map', 'vis_ldot_map', 'chromatic', 'material_params', 'trace_params', 'no_specular_vis', 'no_geodesic_filter', 'maps_only',
+                'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter']
 
 
 GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis']
