@@ -149,12 +149,13 @@ def _rodrigues(rvec: np.ndarray) -> np.ndarray:
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise: float = 2.0) -> dotdict:
+def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise: float = 2.0, n_bones: int = None, n_verts: int = None) -> dotdict:
     """SMPL-shaped frame state with the §8b batch keys (leading batch dim 1).
     skin_noise: std of the per-vertex white noise in the skinning logits.  The default (2.0) makes
     neighbouring vertices follow different bones, so the world -> big-pose warp jumps by ~1 cm wherever the nearest
     vertices change and the reference's own sphere trace ends in a limit cycle on ~9 % of the hit rays; 0.0 gives a spatially smooth
     skinning field like a real SMPL body's (the trace converges) — the well-conditioned case of the parity tests."""
+    N_VERTS, N_BONES = (n_verts or globals()['N_VERTS']), (n_bones or globals()['N_BONES'])      # another body model (SMPL: 24 bones)
     i = np.arange(N_VERTS, dtype=np.float64) + 0.5
     phi = np.arccos(1 - 2 * i / N_VERTS)
     theta = math.pi * (1 + 5 ** 0.5) * i
@@ -280,10 +281,10 @@ def make_skeleton(seed: int = 0):
 
 
 def make_batch(H: int, W: int, seed: int = 0, posed: bool = True, n_novel_lights: int = 0,
-               crop: int = 0, skin_noise: float = 2.0, cam_dist: float = 2.0) -> dotdict:
+               crop: int = 0, skin_noise: float = 2.0, cam_dist: float = 2.0, n_bones: int = None, n_verts: int = None) -> dotdict:
     """Full §8b batch on CPU. ``crop``>0 keeps only a centred crop x crop window of pixels.  ``cam_dist``: distance of the camera from
     the body's centre (2 m, the body then covers ~8 % of the frame; 0.96 m: ~35 %, a frame-filling subject)."""
-    b = make_body(seed, posed, skin_noise=skin_noise)
+    b = make_body(seed, posed, skin_noise=skin_noise, n_bones=n_bones, n_verts=n_verts)
     K, R, T = make_camera(H, W, origin=(0.0, 0.0, -float(cam_dist)))
     ro, rd, near, far, mask = rays_within_bounds(H, W, K, R, T, b.wbounds[0].numpy().astype(np.float64))
     if crop:

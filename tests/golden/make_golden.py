@@ -146,6 +146,8 @@ SWITCH_VARIANTS = {
     'small_probe': {'env_h': 8, 'env_w': 16, 'envmap_upscale': 1},
     'odd_probe': {'env_h': 5, 'env_w': 9, 'envmap_upscale': 3},
     'one_shadow_iter': {'obj_lvis.iter': 1, 'sphere_tracing.shadow_skip_iter': 0},
+    # another body model: 24 bones (SMPL; cond_dim 72) on a 5 023-vertex mesh — keys starting with @ are arguments of synthetic.make_batch
+    'smpl24': {'n_bones': 24, 'cond_dim': 72, '@n_bones': 24, '@n_verts': 5023},
 }
 # the same for the ground-plane pass (render_ground :463-548 + blend_output_): names start with g_, the frame is frame_ground.npz's
 # (24 x 24, 10 x 10 window, two ground chunks) on the smooth body
@@ -192,6 +194,8 @@ SWITCH_KEYS = ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'albed
 
 def apply_overrides(cfg, overrides):
     for k, v in overrides.items():
+        if k.startswith('@'):
+            continue
         node = cfg
         parts = k.split('.')
         for q in parts[:-1]:
@@ -419,7 +423,10 @@ def gen_switch(cfg, synthetic, variant, out_path):
         print('switch', variant, {k: a.shape for k, a in arrs.items()})
         return
     my_cfg = make_cfg('relight')
+    batch_kw = {k[1:]: v for k, v in SWITCH_VARIANTS[variant].items() if k.startswith('@')}
     for k, v in SWITCH_VARIANTS[variant].items():
+        if k.startswith('@'):
+            continue
         node = my_cfg
         parts = k.split('.')
         for q in parts[:-1]:
@@ -434,7 +441,7 @@ def gen_switch(cfg, synthetic, variant, out_path):
     assert not [m for m in missing if 'embedder' not in m], missing
     net.eval()
     H, crop = (GROUND_H, GROUND_CROP) if variant.startswith('g_') else (SWITCH_H, SWITCH_CROP)
-    batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop, skin_noise=0.0))
+    batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop, skin_noise=0.0, **batch_kw))
     with torch.no_grad():
         out = sphere_tracing_renderer.Renderer(net).render(batch)
     arrs = {k: out[k].detach().cpu().numpy() for k in SWITCH_KEYS if k in out}

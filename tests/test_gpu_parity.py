@@ -490,8 +490,8 @@ def test_frame_relight_smooth_meets_the_contract(golden):
 
 # ---- the hot path's configuration switches: the reference under each override (tests/golden/switches.npz, one process per variant;
 # tests/test_oracle_frames.py pins the oracle on the same file)
-from test_oracle_frames import (GROUND_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, novel_switch_case, switch_cfg,      # noqa: E402
-                                switch_variants, volume_switch_cfg)
+from test_oracle_frames import (GROUND_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, novel_switch_case, switch_batch_kw,      # noqa: E402
+                                switch_cfg, switch_variants, volume_switch_cfg)
 
 
 @pytest.mark.parametrize('name', SWITCH_NAMES)
@@ -507,13 +507,14 @@ def test_switch_matrix(golden, name):
     net = make_network(cfg)
     net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg))
     net = net.to(dev).eval()
-    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), dev)
+    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0,
+                                                     **switch_batch_kw(switch_variants(ref)[name])), dev)
     out = make_renderer(cfg, net).render(batch)
     sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
     for k in ('rgb_map', 'shade_map', 'spec_map'):      # maps_only: render_human's early return (:702-705) leaves none of them
         assert (k in sub) == (k in out), (name, k)
     assert bool(((out.acc_map.cpu() > 0) == (T(sub['acc_map']) > 0)).all())
-    case = 'switches.npz:' + (name if name in ('trace_params', 'no_geodesic_filter') else 'base')
+    case = 'switches.npz:' + (name if name in ('trace_params', 'no_geodesic_filter', 'smpl24') else 'base')
     assert float(err(out.surf_map, sub['surf_map']).max()) < 1e-4
     assert float(err(out.albedo_map, sub['albedo_map']).max()) < 1e-3 and float(err(out.roughness_map, sub['roughness_map']).max()) < 1e-3
     assert float((err(out.norm_map, sub['norm_map']) < 2e-2).float().mean()) > 0.97

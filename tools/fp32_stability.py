@@ -46,6 +46,7 @@ CASES = {
     'switches.npz:base': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0)),
     'switches.npz:trace_params': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'trace_params'),
     'switches.npz:no_geodesic_filter': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'no_geodesic_filter'),
+    'switches.npz:smpl24': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0, n_bones=24, n_verts=5023), 'smpl24'),
 }
 
 
@@ -53,6 +54,8 @@ def switch_overrides(cfg, variant):
     import numpy as np
     v = json.loads(str(np.load(os.path.join(ROOT, 'tests', 'golden', 'switches.npz'))['variants_json']))[variant]
     for k, val in v.items():
+        if k.startswith('@'):          # an argument of synthetic.make_batch (the case's factory passes it)
+            continue
         node = cfg
         parts = k.split('.')
         for q in parts[:-1]:
