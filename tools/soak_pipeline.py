@@ -13,7 +13,11 @@ GROUND = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_or
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 # round 5: + sphere tracing, + a multi-chunk frame with 8 probes (config-5-like: merged render chunks, several boxes per launch sequence)
 for mode, kw in (('relight', {}), ('relight', GROUND), ('novel_light', dict(GROUND, novel_light_timing=False)), ('anisdf', {}),
-                 ('sphere_tracing', {}), ('novel_light', dict(novel_light_timing=False, render_chunk_size=4096, n_probes=8))):
+                 ('sphere_tracing', {}), ('novel_light', dict(novel_light_timing=False, render_chunk_size=4096, n_probes=8)),
+                 # + the switches the round-5 matrix added to the product: hard shadows (the shadow rays carry the surface trace's state), the
+                 # K-NN rule without the geodesic filter, the one-channel visibility debug output
+                 ('relight', dict(GROUND, no_dfss=True)), ('relight', dict(use_geodesic_filter=False, vis_lvis_map=True)),
+                 ('relight', dict(only_visibility=True, n_samples=1))):
     kw = dict(kw)
     relight = mode in ('relight', 'novel_light')
     nl = kw.pop('n_probes', 2) if mode == 'novel_light' else 0
