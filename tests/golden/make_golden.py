@@ -148,6 +148,9 @@ SWITCH_VARIANTS = {
     'one_shadow_iter': {'obj_lvis.iter': 1, 'sphere_tracing.shadow_skip_iter': 0},
     # another body model: 24 bones (SMPL; cond_dim 72) on a 5 023-vertex mesh — keys starting with @ are arguments of synthetic.make_batch
     'smpl24': {'n_bones': 24, 'cond_dim': 72, '@n_bones': 24, '@n_verts': 5023},
+    # other synthetic weights (@weights_seed: synthetic.make_state_dict's seed), another body in its rest pose, another camera distance
+    'other_weights': {'@weights_seed': 7, '@seed': 3, '@posed': False, '@cam_dist': 1.6},
+    'all_shadowed': {'@weights_seed': 5, '@seed': 3, '@posed': False, '@cam_dist': 1.6},      # this field shadows the whole window: shade = rgb = 0
 }
 # the same for the ground-plane pass (render_ground :463-548 + blend_output_): names start with g_, the frame is frame_ground.npz's
 # (24 x 24, 10 x 10 window, two ground chunks) on the smooth body
@@ -432,7 +435,7 @@ def gen_switch(cfg, synthetic, variant, out_path):
         for q in parts[:-1]:
             node = node[q]
         node[parts[-1]] = v
-    sd = synthetic.make_state_dict(0, relight=True, cfg=my_cfg)
+    sd = synthetic.make_state_dict(batch_kw.pop('weights_seed', 0), relight=True, cfg=my_cfg)
     from lib.networks.relight.relight_network import Network
     from lib.networks.renderer import sphere_tracing_renderer
     net = Network()
@@ -441,7 +444,7 @@ def gen_switch(cfg, synthetic, variant, out_path):
     assert not [m for m in missing if 'embedder' not in m], missing
     net.eval()
     H, crop = (GROUND_H, GROUND_CROP) if variant.startswith('g_') else (SWITCH_H, SWITCH_CROP)
-    batch = to_ref_batch(synthetic.make_batch(H, H, seed=0, posed=True, crop=crop, skin_noise=0.0, **batch_kw))
+    batch = to_ref_batch(synthetic.make_batch(H, H, **{**dict(seed=0, posed=True, crop=crop, skin_noise=0.0), **batch_kw}))
     with torch.no_grad():
         out = sphere_tracing_renderer.Renderer(net).render(batch)
     arrs = {k: out[k].detach().cpu().numpy() for k in SWITCH_KEYS if k in out}

@@ -504,17 +504,17 @@ def test_switch_matrix(golden, name):
     ref = golden('switches.npz')
     dev = _dev()
     cfg = switch_cfg(switch_variants(ref)[name], mlp_dtype='f16')
+    bkw = switch_batch_kw(switch_variants(ref)[name])
     net = make_network(cfg)
-    net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg))
+    net.load_state_dict(synthetic.make_state_dict(bkw.pop('weights_seed', 0), relight=True, cfg=cfg))
     net = net.to(dev).eval()
-    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0,
-                                                     **switch_batch_kw(switch_variants(ref)[name])), dev)
+    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), **{**dict(seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), **bkw}), dev)
     out = make_renderer(cfg, net).render(batch)
     sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
     for k in ('rgb_map', 'shade_map', 'spec_map'):      # maps_only: render_human's early return (:702-705) leaves none of them
         assert (k in sub) == (k in out), (name, k)
     assert bool(((out.acc_map.cpu() > 0) == (T(sub['acc_map']) > 0)).all())
-    case = 'switches.npz:' + (name if name in ('trace_params', 'no_geodesic_filter', 'smpl24') else 'base')
+    case = 'switches.npz:' + (name if name in ('trace_params', 'no_geodesic_filter', 'smpl24', 'other_weights', 'all_shadowed') else 'base')
     assert float(err(out.surf_map, sub['surf_map']).max()) < 1e-4
     assert float(err(out.albedo_map, sub['albedo_map']).max()) < 1e-3 and float(err(out.roughness_map, sub['roughness_map']).max()) < 1e-3
     assert float((err(out.norm_map, sub['norm_map']) < 2e-2).float().mean()) > 0.97

@@ -225,7 +225,7 @@ def switch_batch_kw(overrides):
 
 SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibility', 'lambert_only', 'glossy_only', 'linear', 'only_visibility',
                 'vis_lvis_map', 'vis_ldot_map', 'chromatic', 'material_params', 'trace_params', 'no_specular_vis', 'no_geodesic_filter', 'maps_only',
-                'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter', 'smpl24']
+                'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter', 'smpl24', 'other_weights', 'all_shadowed']
 
 
 GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis']
@@ -328,9 +328,9 @@ def test_switch_matrix(golden, name):
     variants = switch_variants(ref)
     assert sorted(variants) == sorted(SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES)
     cfg = switch_cfg(variants[name])
-    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg)
-    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0,
-                                 **switch_batch_kw(variants[name]))
+    bkw = switch_batch_kw(variants[name])
+    net = O.OracleNet(synthetic.make_state_dict(bkw.pop('weights_seed', 0), relight=True, cfg=cfg), cfg)
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), **{**dict(seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), **bkw})
     out = O.render_sphere_tracing(net, batch)
     sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
     for k in ('rgb_map', 'shade_map', 'spec_map'):      # maps_only: render_human's early return leaves none of them

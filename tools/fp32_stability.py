@@ -46,6 +46,8 @@ CASES = {
     'switches.npz:base': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0)),
     'switches.npz:trace_params': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'trace_params'),
     'switches.npz:no_geodesic_filter': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'no_geodesic_filter'),
+    'switches.npz:other_weights': ('relight', lambda: MB(128, 128, seed=3, posed=False, crop=10, skin_noise=0.0, cam_dist=1.6), 'other_weights', 7),
+    'switches.npz:all_shadowed': ('relight', lambda: MB(128, 128, seed=3, posed=False, crop=10, skin_noise=0.0, cam_dist=1.6), 'all_shadowed', 5),
     'switches.npz:smpl24': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0, n_bones=24, n_verts=5023), 'smpl24'),
 }
 
@@ -77,7 +79,7 @@ def main():
         if len(CASES[name]) > 2:
             switch_overrides(cfg, CASES[name][2])
         relight = mode in ('relight', 'novel_light')
-        net = O.OracleNet(synthetic.make_state_dict(0, relight=relight, cfg=cfg), cfg)
+        net = O.OracleNet(synthetic.make_state_dict(CASES[name][3] if len(CASES[name]) > 3 else 0, relight=relight, cfg=cfg), cfg)
         t0 = time.time()
         b = mk()
         if probs_only and name in res:
