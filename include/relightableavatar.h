@@ -429,6 +429,9 @@ int ra_map_to_image(ra_ctx* ctx, const ra_image_params* p, const float* a_dev, c
 int ra_debug_mlp(ra_ctx* ctx, const float* bpts_dev, int n, float* resd, float* sdf, float* feat, void* stream);
 /* full kernel with identity warp: d sdf/d bpts n x 3, sdf n, feat n x 256, raw n x C */
 int ra_debug_full(ra_ctx* ctx, const float* bpts_dev, int n, float* grad, float* sdf, float* feat, float* raw, void* stream);
+/* the vertex ids of the current frame's box structure in leaf order (32 per leaf; the padding of the last leaf is 0x7fffffff) to a HOST array
+ * of `capacity` ints; *n_out = 32 x leaves (0 without a structure: brute-force mode or a mesh beyond its limit).  Synchronises the stream. */
+int ra_debug_bvh_ids(ra_ctx* ctx, int* ids_host, int capacity, int* n_out, void* stream);
 /* coarse level: per-point coarse sdf n, sdf_batch n x 3, nn_batch n x 3 (int32), filtered d2 n x 3, and for fine points
  * bpts/tpts n x 3, blended (A|big_A) rows n x 24 (zeros elsewhere); fine_count_host receives the count (synchronises) */
 int ra_debug_hdq(ra_ctx* ctx, const float* x_dev, int n, float dist_th, float* sdf_coarse, float* sdf_batch, int* nn_batch,

@@ -138,6 +138,7 @@ SYMBOLS = {
     'ra_debug_lvis': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(ra_trace_params), C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_debug_brdf': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'ra_debug_bvh_ids': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     'ra_debug_hdq': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 7 + [C.POINTER(C.c_int), C.c_void_p]),
 }
 

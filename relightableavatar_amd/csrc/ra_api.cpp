@@ -1354,6 +1354,21 @@ int ra_debug_brdf(ra_ctx* c, const float* p2l, const float* p2c, const float* no
     return 0;
 }
 
+int ra_debug_bvh_ids(ra_ctx* c, int* ids_host, int capacity, int* n_out, void* stream) {
+    if (check_ready(c, "ra_debug_bvh_ids")) return 1;
+    RA_CHECK(ids_host && n_out && capacity >= 0, "ra_debug_bvh_ids: bad arguments");
+    const int nleaf = c->fr.bvh_leaves;
+    *n_out = nleaf * 32;
+    if (nleaf == 0) return 0;
+    RA_CHECK(capacity >= nleaf * 32, "ra_debug_bvh_ids: capacity too small");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> leaves((size_t)nleaf * 128);
+    RA_HIP(hipMemcpyAsync(leaves.data(), c->fr.bvh_soa, leaves.size() * 4, hipMemcpyDeviceToHost, s));
+    RA_HIP(hipStreamSynchronize(s));
+    for (int l = 0; l < nleaf; ++l) memcpy(ids_host + (size_t)l * 32, leaves.data() + (size_t)l * 128 + 96, 32 * 4);
+    return 0;
+}
+
 int ra_debug_hdq(ra_ctx* c, const float* x, int n, float th, float* sdf_coarse, float* sdf_batch, int* nn_batch, float* d2,
                  float* bpts, float* tpts, float* mats, int* fine_count_host, void* stream) {
     if (check_ready(c, "ra_debug_hdq")) return 1;

@@ -76,13 +76,18 @@ __global__ void pack_verts_kernel(const float* __restrict__ pv, int n, float4* _
     if (v < n) out[v] = make_float4(pv[3 * v], pv[3 * v + 1], pv[3 * v + 2], 0.f);
 }
 
-__global__ void fold_bias_kernel(const float* __restrict__ W, int ld, int col0, int ncond, const float* __restrict__ cond,
-                                 const float* __restrict__ bias, float* __restrict__ out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output row: coalesced reads of the row's ncond weights, lane-strided partial sums, one shuffle reduction
+// (round 5: a thread per row walked its 156 weights alone, 40 us per launch, three launches per frame)
+__global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict__ W, int ld, int col0, int ncond, const float* __restrict__ cond,
+                                                        const float* __restrict__ bias, float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= 256) return;
-    float a = bias[r];
-    for (int c = 0; c < ncond; ++c) a += W[(size_t)r * ld + col0 + c] * cond[c];
-    out[r] = a;
+    const float* row = W + (size_t)r * ld + col0;
+    float a = 0.f;
+    for (int c = lane; c < ncond; c += 64) a = fmaf(row[c], cond[c], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) out[r] = bias[r] + a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -105,6 +110,69 @@ __device__ __forceinline__ unsigned expand10(unsigned v) {
     v = (v * 0x00000011u) & 0xC30C30C3u;
     v = (v * 0x00000005u) & 0x49249249u;
     return v;
+}
+
+// Bitonic sort of 1024 * EPT 64-bit keys (unique: the vertex index is in the low bits, so every correct sort gives the same order) held
+// EPT per thread in registers, element i = tid * EPT + m in r[m]: a compare step whose partner distance j is below EPT stays inside the
+// thread, below 64 * EPT inside the wave (two 32-bit shuffles), and only the log2(16) top distances cross waves through LDS — 10 barrier
+// steps instead of the 91 of the plain LDS loop for 8 192 keys.  Round 5, same box: the kernel 131 -> 100 us per frame, of which the sort is
+// still 78 (7 500 wave instructions x 4 cycles x 4 waves per SIMD: ONE CU sorts; without the sort the kernel takes 22 us).
+template <int EPT, int J>
+__device__ __forceinline__ void bitonic_in_thread(unsigned long long (&r)[EPT], int k, int tid) {
+    if constexpr (J < EPT) {
+#pragma unroll
+        for (int m = 0; m < EPT; ++m)
+            if ((m & J) == 0) {
+                const unsigned long long a = r[m], b = r[m | J];
+                const bool up = ((tid * EPT + m) & k) == 0;
+                const bool sw = (a > b) == up;          // selects, not branches: the lanes of a wave disagree on every compare
+                r[m] = sw ? b : a;
+                r[m | J] = sw ? a : b;
+            }
+    }
+}
+
+template <int EPT>
+__device__ __forceinline__ void bitonic_sort_1024(unsigned long long* keys, int tid) {
+    constexpr int NP2 = BVH_THREADS * EPT;
+    unsigned long long r[EPT];
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) r[m] = keys[tid * EPT + m];
+    __syncthreads();                                  // keys[] becomes the exchange buffer (transposed: m * 1024 + tid, conflict-free)
+    for (int k = 2; k <= NP2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < EPT) {
+                if (j == 8) bitonic_in_thread<EPT, 8>(r, k, tid);
+                else if (j == 4) bitonic_in_thread<EPT, 4>(r, k, tid);
+                else if (j == 2) bitonic_in_thread<EPT, 2>(r, k, tid);
+                else bitonic_in_thread<EPT, 1>(r, k, tid);
+            } else {
+                const int dt = j / EPT;                 // partner thread = tid ^ dt, same m
+                const bool lower = (tid & dt) == 0;
+                if (dt >= 64) {
+#pragma unroll
+                    for (int m = 0; m < EPT; ++m) keys[m * BVH_THREADS + tid] = r[m];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int m = 0; m < EPT; ++m) {
+                    unsigned long long o;
+                    if (dt >= 64) o = keys[m * BVH_THREADS + (tid ^ dt)];
+                    else {
+                        const unsigned lo = __shfl_xor((unsigned)r[m], dt), hi = __shfl_xor((unsigned)(r[m] >> 32), dt);
+                        o = ((unsigned long long)hi << 32) | lo;
+                    }
+                    const bool up = ((tid * EPT + m) & k) == 0;
+                    const bool keep_min = lower == up;          // the lower index of a pair keeps the minimum in an ascending run
+                    const bool take = keep_min ? (o < r[m]) : (o > r[m]);
+                    r[m] = take ? o : r[m];
+                }
+                if (dt >= 64) __syncthreads();
+            }
+        }
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) keys[tid * EPT + m] = r[m];
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __restrict__ pv, int n, float* __restrict__ leaves,
@@ -150,50 +218,55 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         keys[i] = k;
     }
     __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += BVH_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+    if (np2 == 16 * BVH_THREADS) bitonic_sort_1024<16>(keys, tid);
+    else if (np2 == 8 * BVH_THREADS) bitonic_sort_1024<8>(keys, tid);          // SMPL / SMPL-H: 6 890 vertices
+    else if (np2 == 4 * BVH_THREADS) bitonic_sort_1024<4>(keys, tid);
+    else if (np2 == 2 * BVH_THREADS) bitonic_sort_1024<2>(keys, tid);
+    else if (np2 == BVH_THREADS) bitonic_sort_1024<1>(keys, tid);
+    else                                                                         // meshes below 513 vertices: the plain LDS loop
+        for (int k = 2; k <= np2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np2; i += BVH_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = keys[i], b = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-        }
     // the sorted points per leaf as x[32] | y[32] | z[32] | id[32] (the leaf scan reads groups of candidates with wave-uniform addresses),
-    // padded with +inf points: (p - inf)^2 = inf never beats a finite bound
-    for (int i = tid; i < nl * BVH_LEAF; i += BVH_THREADS) {
+    // padded with +inf points: (p - inf)^2 = inf never beats a finite bound; 32 lanes per leaf, the leaf's box by a half-wave reduction
+    // (round 5: one thread per leaf walked its 32 gathered points alone)
+    __shared__ float lb[BVH_MAXL][6];
+    const int e = tid & 31;
+    for (int l = tid >> 5; l < nl; l += BVH_THREADS / 32) {
+        const int i = l * BVH_LEAF + e;
         float4 v = make_float4(__int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7fffffff));
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
         if (i < n) {
             const unsigned id = (unsigned)(keys[i] & 0xffffffffull);
             v = pv[id];
             v.w = __int_as_float((int)id);
+            lo[0] = hi[0] = v.x; lo[1] = hi[1] = v.y; lo[2] = hi[2] = v.z;
         }
-        float* soa = leaves + (size_t)(i >> 5) * (4 * BVH_LEAF) + (i & 31);
+        float* soa = leaves + (size_t)l * (4 * BVH_LEAF) + e;
         soa[0] = v.x; soa[BVH_LEAF] = v.y; soa[2 * BVH_LEAF] = v.z; soa[3 * BVH_LEAF] = v.w;
-    }
-    // leaf boxes into LDS scratch (reuse red-sized arrays is too small -> reuse keys' tail? keep simple: global + LDS copy)
-    __shared__ float lb[BVH_MAXL][6];
-    for (int l = tid; l < nl; l += BVH_THREADS) {
-        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-        for (int e = 0; e < BVH_LEAF; ++e) {
-            const int i = l * BVH_LEAF + e;
-            if (i < n) {
-                const float4 v = pv[(unsigned)(keys[i] & 0xffffffffull)];
-                lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
-                hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
-            }
-        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { lb[l][c] = lo[c]; lb[l][3 + c] = hi[c]; }
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+        if (e == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lb[l][c] = lo[c]; lb[l][3 + c] = hi[c]; }
+        }
     }
     __syncthreads();
     for (int sidx = tid; sidx < ns; sidx += BVH_THREADS) {
         float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-        for (int e = 0; e < BVH_FAN; ++e) {
-            const int l = sidx * BVH_FAN + e;
+        for (int k = 0; k < BVH_FAN; ++k) {
+            const int l = sidx * BVH_FAN + k;
             if (l < nl)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], lb[l][c]); hi[c] = fmaxf(hi[c], lb[l][3 + c]); }
@@ -203,10 +276,10 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         // the super box's 8 leaf boxes as 4 PAIR records of 12 floats (lo.x[2] lo.y[2] lo.z[2] hi.x[2] hi.y[2] hi.z[2]): the sweep tests two
         // leaf boxes per packed instruction.  Missing leaves of the last super box: an inverted box, infinitely far from everything.
         float* rec = reinterpret_cast<float*>(sbox + 2 * (size_t)ns) + (size_t)sidx * (6 * BVH_FAN);
-        for (int e = 0; e < BVH_FAN; ++e) {
-            const int l = sidx * BVH_FAN + e;
+        for (int k = 0; k < BVH_FAN; ++k) {
+            const int l = sidx * BVH_FAN + k;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) rec[12 * (e >> 1) + 2 * c + (e & 1)] = l < nl ? lb[l][c] : (c < 3 ? 3e38f : -3e38f);
+            for (int c = 0; c < 6; ++c) rec[12 * (k >> 1) + 2 * c + (k & 1)] = l < nl ? lb[l][c] : (c < 3 ? 3e38f : -3e38f);
         }
     }
 }
@@ -623,7 +696,7 @@ void launch_pack_verts(const float* pverts, int n_verts, float4* out, hipStream_
 
 void launch_fold_bias(const float* W, int ld, int col0, int ncond, const float* cond, const float* bias, float* out,
                       hipStream_t s) {
-    hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, s, W, ld, col0, ncond, cond, bias, out);
+    hipLaunchKernelGGL(fold_bias_kernel, dim3(64), dim3(256), 0, s, W, ld, col0, ncond, cond, bias, out);
 }
 
 int bvh_leaf_count(int n_verts) {

@@ -483,6 +483,15 @@ class Engine:
         check(self.lib.ra_debug_brdf(self.ctx, *[_ptr(t) for t in a], L, N, _ptr(out), self.stream), 'ra_debug_brdf')
         return out
 
+    def debug_bvh_ids(self):
+        """vertex ids of the frame's box structure in leaf order (numpy int32; padding 0x7fffffff), empty without a structure"""
+        import numpy as np
+        cap = 32 * 1024
+        ids = np.empty(cap, dtype=np.int32)
+        n = C.c_int()
+        check(self.lib.ra_debug_bvh_ids(self.ctx, ids.ctypes.data_as(C.c_void_p), cap, C.byref(n), self.stream), 'ra_debug_bvh_ids')
+        return ids[:n.value].copy()
+
     def debug_hdq(self, x, dist_th):
         d = self.device
         x = _f32(x.reshape(-1, 3), d)

@@ -275,6 +275,44 @@ def test_bvh_equals_brute_force_on_other_mesh_sizes(relight):
         eng.set_frame(body, force=True)
 
 
+def test_box_structure_is_morton_sorted(relight):
+    """the per-frame vertex order of the box structure IS the ascending (30-bit Morton code of the posed vertex, vertex index) order, for
+    every path of the builder's sort: the plain LDS loop (below 513 vertices) and the register / shuffle bitonic sort with 1, 2, 4, 8, 16
+    keys per thread — recomputed here in numpy with the kernel's float32 arithmetic"""
+    from relightableavatar_amd.base_utils import dotdict
+    _, _, dev, body, eng = relight
+    n0 = body.pverts.shape[1]
+
+    def expand10(v):
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+        return v
+    try:
+        for n in (3, 37, 512, 513, 1000, 1500, 3000, 4096, 6890, 9500, 16384):
+            rep = (n + n0 - 1) // n0
+            b = dotdict(body)
+            for k in ('pverts', 'pnorm', 'tverts', 'weights'):
+                v = body[k][0]
+                v = torch.cat([v + (0.003 * j if k in ('pverts', 'tverts') else 0.0) for j in range(rep)])[:n]
+                b[k] = v[None].contiguous()
+            eng.set_knn_mode(True)
+            eng.set_frame(b, force=True)
+            ids = eng.debug_bvh_ids()
+            nl = (n + 31) // 32
+            assert ids.shape[0] == 32 * nl and bool((ids[n:] == 0x7fffffff).all()), n
+            pv = b.pverts[0].cpu().numpy().astype(np.float32)
+            lo, hi = pv.min(0), pv.max(0)
+            e = np.maximum(hi - lo, np.float32(1e-12))
+            q = np.minimum(np.maximum((pv - lo) / e * np.float32(1023.0), np.float32(0.0)), np.float32(1023.0)).astype(np.uint32)
+            code = (expand10(q[:, 0]) << np.uint32(2)) | (expand10(q[:, 1]) << np.uint32(1)) | expand10(q[:, 2])
+            key = (code.astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+            assert np.array_equal(ids[:n].astype(np.int64), np.argsort(key, kind='stable')), n
+    finally:
+        eng.set_frame(body, force=True)
+
+
 def test_hinted_search_equals_brute_force_in_whole_frames():
     """advisor (round 3): the HINT variants of the coarse kernel (a tracing loop's queries start from the neighbours of the iteration before;
     dedup insert; split-wave merge with hints) are claimed exact but no test compared them bit for bit — debug_hdq never hints.  The O(N)
