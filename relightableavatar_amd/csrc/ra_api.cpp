@@ -84,7 +84,7 @@ int ra_ctx_destroy(ra_ctx* c) {
     hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->sarena, &c->sarena_pairs, &c->sarena_c, &c->fwd_arena, &c->bwd_arena, &c->shead_row, &c->barena, &c->cond_r0, &c->cond_r4, &c->cond_c3, &c->b_r0, &c->b_r4, &c->b_c3, &c->light_xyz,
                       &c->light_area, &c->light_sharp, &c->light_dir, &c->fR, &c->fTh, &c->fvertA, &c->fpverts4, &c->fpnorm, &c->ftverts,
-                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs,
+                      &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs, &c->fbvh_order,
                       &c->adj_start, &c->adj_list, &c->adj_dfaces};
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : c->scratch) kv.second.release();
@@ -228,8 +228,8 @@ int ra_set_frame(ra_ctx* c, const ra_frame* f, void* stream) {
     const int nsuper = bvh_super_count(nleaf);
     if (nleaf > 0) {
         // leaves: 512 B each; boxes: super boxes (lo | hi), then per super box the four pair records of its leaf boxes
-        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * 16) || c->fbvh_pairs.ensure((size_t)nsuper * (32 + 192))) return 1;
-        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_pts.as<float>(), c->fbvh_pairs.as<float4>(), nleaf, nsuper, s);
+        if (c->fbvh_pts.ensure((size_t)nleaf * 32 * 16) || c->fbvh_pairs.ensure((size_t)nsuper * (32 + 192)) || c->fbvh_order.ensure((size_t)nv * 4)) return 1;
+        launch_bvh_build(c->fpverts4.as<float4>(), nv, c->fbvh_order.as<int>(), c->fbvh_pts.as<float>(), c->fbvh_pairs.as<float4>(), nleaf, nsuper, s);
         RA_HIP(hipGetLastError());
     }
     launch_fold_bias(c->cond_r0.as<float>(), cond, 0, cond, f->poses, c->b_r0.as<float>(), c->fbias_r0.as<float>(), s);

@@ -78,7 +78,7 @@ struct ra_ctx {
     int n_lights = 0;
     // frame
     FrameState fr{};
-    DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond, fbvh_pts, fbvh_pairs;
+    DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond, fbvh_pts, fbvh_pairs, fbvh_order;
     bool use_bvh = true;
     // N3: vertex -> incident corners of the template mesh (built once per faces array)
     DevBuf adj_start, adj_list, adj_dfaces;

@@ -112,77 +112,23 @@ __device__ __forceinline__ unsigned expand10(unsigned v) {
     return v;
 }
 
-// Bitonic sort of 1024 * EPT 64-bit keys (unique: the vertex index is in the low bits, so every correct sort gives the same order) held
-// EPT per thread in registers, element i = tid * EPT + m in r[m]: a compare step whose partner distance j is below EPT stays inside the
-// thread, below 64 * EPT inside the wave (two 32-bit shuffles), and only the log2(16) top distances cross waves through LDS — 10 barrier
-// steps instead of the 91 of the plain LDS loop for 8 192 keys.  Round 5, same box: the kernel 131 -> 100 us per frame, of which the sort is
-// still 78 (7 500 wave instructions x 4 cycles x 4 waves per SIMD: ONE CU sorts; without the sort the kernel takes 22 us).
-template <int EPT, int J>
-__device__ __forceinline__ void bitonic_in_thread(unsigned long long (&r)[EPT], int k, int tid) {
-    if constexpr (J < EPT) {
-#pragma unroll
-        for (int m = 0; m < EPT; ++m)
-            if ((m & J) == 0) {
-                const unsigned long long a = r[m], b = r[m | J];
-                const bool up = ((tid * EPT + m) & k) == 0;
-                const bool sw = (a > b) == up;          // selects, not branches: the lanes of a wave disagree on every compare
-                r[m] = sw ? b : a;
-                r[m | J] = sw ? a : b;
-            }
-    }
-}
+// Per frame, two launches.
+// 1. bvh_rank_kernel: the ORDER of the posed vertices — ascending (30-bit Morton code, vertex index) — by RANKING instead of sorting: every
+//    workgroup computes the box of all vertices and all n keys itself (7 loads per thread: cheaper than a launch in between), then ranks its
+//    own 64 vertices, rank = number of smaller keys, the n comparisons of a vertex dealt to the 16 waves of the workgroup (each key is read
+//    once per wave, from LDS with a wave-uniform address).  O(n^2) work, 47 M comparisons for SMPL, but on all CUs: the single-workgroup
+//    bitonic sorts this replaced (round 2: 91 barrier steps in LDS, 100 us of a 131 us build; round 5 first try: registers + shuffles, 78 us —
+//    7 500 wave instructions on ONE CU) were the largest fixed cost of a frame.  Keys are unique (the index is in the low bits), so the
+//    order is THE sorted order, whatever computes it (test_box_structure_is_morton_sorted).
+// 2. bvh_boxes_kernel: leaf records, leaf boxes, super boxes in that order (one workgroup, 32 lanes per leaf).
+constexpr int RANK_WAVES = BVH_THREADS / 64;      // 16
 
-template <int EPT>
-__device__ __forceinline__ void bitonic_sort_1024(unsigned long long* keys, int tid) {
-    constexpr int NP2 = BVH_THREADS * EPT;
-    unsigned long long r[EPT];
-#pragma unroll
-    for (int m = 0; m < EPT; ++m) r[m] = keys[tid * EPT + m];
-    __syncthreads();                                  // keys[] becomes the exchange buffer (transposed: m * 1024 + tid, conflict-free)
-    for (int k = 2; k <= NP2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j < EPT) {
-                if (j == 8) bitonic_in_thread<EPT, 8>(r, k, tid);
-                else if (j == 4) bitonic_in_thread<EPT, 4>(r, k, tid);
-                else if (j == 2) bitonic_in_thread<EPT, 2>(r, k, tid);
-                else bitonic_in_thread<EPT, 1>(r, k, tid);
-            } else {
-                const int dt = j / EPT;                 // partner thread = tid ^ dt, same m
-                const bool lower = (tid & dt) == 0;
-                if (dt >= 64) {
-#pragma unroll
-                    for (int m = 0; m < EPT; ++m) keys[m * BVH_THREADS + tid] = r[m];
-                    __syncthreads();
-                }
-#pragma unroll
-                for (int m = 0; m < EPT; ++m) {
-                    unsigned long long o;
-                    if (dt >= 64) o = keys[m * BVH_THREADS + (tid ^ dt)];
-                    else {
-                        const unsigned lo = __shfl_xor((unsigned)r[m], dt), hi = __shfl_xor((unsigned)(r[m] >> 32), dt);
-                        o = ((unsigned long long)hi << 32) | lo;
-                    }
-                    const bool up = ((tid * EPT + m) & k) == 0;
-                    const bool keep_min = lower == up;          // the lower index of a pair keeps the minimum in an ascending run
-                    const bool take = keep_min ? (o < r[m]) : (o > r[m]);
-                    r[m] = take ? o : r[m];
-                }
-                if (dt >= 64) __syncthreads();
-            }
-        }
-#pragma unroll
-    for (int m = 0; m < EPT; ++m) keys[tid * EPT + m] = r[m];
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __restrict__ pv, int n, float* __restrict__ leaves,
-                                                                float4* __restrict__ sbox, int nl, int ns) {
+__global__ __launch_bounds__(BVH_THREADS) void bvh_rank_kernel(const float4* __restrict__ pv, int n, int* __restrict__ order) {
     __shared__ unsigned long long keys[BVH_MAXN];     // code << 32 | index (static: 128 KB of the CU's 160 KB)
     __shared__ float red[6][BVH_THREADS / 64];
     __shared__ float bb[6];
+    __shared__ int cnt[RANK_WAVES][64];
     const int tid = threadIdx.x;
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
     float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
     for (int i = tid; i < n; i += BVH_THREADS) {
         const float4 v = pv[i];
@@ -201,7 +147,8 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         bb[tid] = a;
     }
     __syncthreads();
-    for (int i = tid; i < np2; i += BVH_THREADS) {
+    const int n4 = (n + 3) & ~3;                       // the ranking loop reads four keys at a time: pad with keys larger than any real one
+    for (int i = tid; i < n4; i += BVH_THREADS) {
         unsigned long long k = ~0ull;
         if (i < n) {
             const float4 v = pv[i];
@@ -218,37 +165,42 @@ __global__ __launch_bounds__(BVH_THREADS) void bvh_build_kernel(const float4* __
         keys[i] = k;
     }
     __syncthreads();
-    if (np2 == 16 * BVH_THREADS) bitonic_sort_1024<16>(keys, tid);
-    else if (np2 == 8 * BVH_THREADS) bitonic_sort_1024<8>(keys, tid);          // SMPL / SMPL-H: 6 890 vertices
-    else if (np2 == 4 * BVH_THREADS) bitonic_sort_1024<4>(keys, tid);
-    else if (np2 == 2 * BVH_THREADS) bitonic_sort_1024<2>(keys, tid);
-    else if (np2 == BVH_THREADS) bitonic_sort_1024<1>(keys, tid);
-    else                                                                         // meshes below 513 vertices: the plain LDS loop
-        for (int k = 2; k <= np2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < np2; i += BVH_THREADS) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const unsigned long long a = keys[i], b = keys[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                    }
-                }
-                __syncthreads();
-            }
-    // the sorted points per leaf as x[32] | y[32] | z[32] | id[32] (the leaf scan reads groups of candidates with wave-uniform addresses),
-    // padded with +inf points: (p - inf)^2 = inf never beats a finite bound; 32 lanes per leaf, the leaf's box by a half-wave reduction
-    // (round 5: one thread per leaf walked its 32 gathered points alone)
+    const int lane = tid & 63, g = tid >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const unsigned long long mine = e < n ? keys[e] : 0ull;
+    // wave g compares against keys [j0, j1): a quarter-aligned sixteenth of the array
+    const int chunk = ((n4 / 4 + RANK_WAVES - 1) / RANK_WAVES) * 4;
+    const int j0 = g * chunk, j1 = min(n4, j0 + chunk);
+    int c = 0;
+    for (int j = j0; j < j1; j += 4) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&keys[j]);
+        const ulonglong2 b = *reinterpret_cast<const ulonglong2*>(&keys[j + 2]);
+        c += (a.x < mine) + (a.y < mine) + (b.x < mine) + (b.y < mine);
+    }
+    cnt[g][lane] = c;
+    __syncthreads();
+    if (g == 0 && e < n) {
+        int r = 0;
+#pragma unroll
+        for (int w = 0; w < RANK_WAVES; ++w) r += cnt[w][lane];
+        order[r] = e;
+    }
+}
+
+__global__ __launch_bounds__(BVH_THREADS) void bvh_boxes_kernel(const float4* __restrict__ pv, const int* __restrict__ order, int n,
+                                                                float* __restrict__ leaves, float4* __restrict__ sbox, int nl, int ns) {
     __shared__ float lb[BVH_MAXL][6];
-    const int e = tid & 31;
+    const int tid = threadIdx.x, e = tid & 31;
+    // the points of a leaf as x[32] | y[32] | z[32] | id[32] (the leaf scan reads groups of candidates with wave-uniform addresses),
+    // padded with +inf points: (p - inf)^2 = inf never beats a finite bound; the leaf's box by a half-wave reduction
     for (int l = tid >> 5; l < nl; l += BVH_THREADS / 32) {
         const int i = l * BVH_LEAF + e;
         float4 v = make_float4(__int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7f800000), __int_as_float(0x7fffffff));
         float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
         if (i < n) {
-            const unsigned id = (unsigned)(keys[i] & 0xffffffffull);
+            const int id = order[i];
             v = pv[id];
-            v.w = __int_as_float((int)id);
+            v.w = __int_as_float(id);
             lo[0] = hi[0] = v.x; lo[1] = hi[1] = v.y; lo[2] = hi[2] = v.z;
         }
         float* soa = leaves + (size_t)l * (4 * BVH_LEAF) + e;
@@ -705,8 +657,9 @@ int bvh_leaf_count(int n_verts) {
 }
 int bvh_super_count(int n_leaves) { return (n_leaves + BVH_FAN - 1) / BVH_FAN; }
 
-void launch_bvh_build(const float4* pverts4, int n_verts, float* leaves, float4* sbox, int n_leaves, int n_supers, hipStream_t s) {
-    hipLaunchKernelGGL(bvh_build_kernel, dim3(1), dim3(BVH_THREADS), 0, s, pverts4, n_verts, leaves, sbox, n_leaves, n_supers);
+void launch_bvh_build(const float4* pverts4, int n_verts, int* order, float* leaves, float4* sbox, int n_leaves, int n_supers, hipStream_t s) {
+    hipLaunchKernelGGL(bvh_rank_kernel, dim3((n_verts + 63) / 64), dim3(BVH_THREADS), 0, s, pverts4, n_verts, order);
+    hipLaunchKernelGGL(bvh_boxes_kernel, dim3(1), dim3(BVH_THREADS), 0, s, pverts4, order, n_verts, leaves, sbox, n_leaves, n_supers);
 }
 
 void launch_hdq_coarse(const FrameState& fr, const RaySet& rs, int n, float th, float blend_radius, const HdqOut& out,
