@@ -231,9 +231,7 @@ SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibi
 GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis']
 
 
-# the oracle's ground pass takes 40 s per frame: ONE variant in the CPU suite (the restated visibility map; RA_ALL_GROUND_VARIANTS=1 runs all
-# eight, 5 minutes — done once when the fixture was made), all eight in the GPU suite against the reference's frames directly
-@pytest.mark.parametrize('name', GROUND_SWITCH_NAMES if os.environ.get('RA_ALL_GROUND_VARIANTS') else ['g_vis_lvis_map'])
+@pytest.mark.parametrize('name', GROUND_SWITCH_NAMES)
 def test_ground_switch_matrix(golden, name):
     """the same switches through the ground-plane pass (render_ground :463-548, blend_output_): frame_ground.npz's frame on the smooth body"""
     ref = golden('switches.npz')
