@@ -42,8 +42,8 @@ CASES = {
     'full_size_sample': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=0.0), 1024)[0]),
     'bench_sample': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=2.0), 512)[0]),
     'bench_sample_smooth': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=0.0), 512)[0]),
-    'bench_sample_1536': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=2.0), 1536)[0]),      # bench.py N_SAMPLE
-    'bench_sample_smooth_1536': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=0.0), 1536)[0]),
+    'bench_sample_3072': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=2.0), 3072)[0]),      # bench.py N_SAMPLE
+    'bench_sample_smooth_3072': ('relight', lambda: synthetic.sample_rays(MB(512, 512, seed=0, posed=True, skin_noise=0.0), 3072)[0]),
     # tests/golden/switches.npz: one window, traced under three different settings (the other variants trace like 'base')
     'switches.npz:base': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0)),
     'switches.npz:trace_params': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0), 'trace_params'),
