@@ -20,6 +20,10 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
       from 64 to 51 dB, which is why the all-ray PSNR is only a sanity bound there.
       * through assert_contract: frame_relight, frame_relight_smooth, frame_novel (three probes), frame_ground, the multi-chunk and
         other-pose cases, the full-size sample, the volume frames (> 80 dB);
+      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 38 configuration overrides, one process per variant):
+        25 relit windows, 8 ground-pass frames, 3 volume frames, 2 rotating-light sequences; rgb through assert_contract over ALL rays
+        (no fp32-unstable ray on these windows: 60-96 dB, max 1.5e-4 .. 7.8e-3), the other maps to their tolerances;
+        test_box_structure_is_morton_sorted pins the per-frame vertex order of the box structure against numpy;
       * NOT through it: frame_novel_ground (max <= 2e-2 and at most 3 elements over 1e-2: one interior pixel of `main` sits at 1.1e-2, the
         plain-f16 shadow rays' error amplified by sharp / (2 t), see below) and the full 512 x 512 frame against its all-compensated twin
         (test_full_frame_shadow_tier_is_harmless: 2 of 19 929 hit pixels over 1e-2, max 1.3e-2).  Round 5 built the adaptive re-query
