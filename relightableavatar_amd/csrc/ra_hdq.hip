@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void fold_bias_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Vertex boxes for the exact 3-NN, rebuilt per frame on the stream by ONE workgroup:
-//   bbox -> 30-bit Morton codes -> bitonic sort in LDS -> sorted float4 (xyz, index) ->
+// Vertex boxes for the exact 3-NN, rebuilt per frame on the stream (bvh_rank_kernel + bvh_boxes_kernel below):
+//   bbox -> 30-bit Morton codes -> the vertices' rank in (code, index) order -> sorted float4 (xyz, index) ->
 //   leaf boxes (32 consecutive points) -> super boxes (8 consecutive leaves).
 // A flat, wide, 3-level structure on purpose: queries are swept through it with wave-uniform
 // control flow (hdq_coarse_kernel), so there are no dependent-load chains to wait on.
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
         const unsigned long long lm = __ballot(live);
         const int first = lm ? __ffsll((long long)lm) - 1 : 0;
         const int lane = threadIdx.x & 63;
-        // Leaf scan on packed fp32: a leaf is stored as x[32] | y[32] | z[32] (bvh_build_kernel), a PAIR of candidates is three 8-byte
+        // Leaf scan on packed fp32: a leaf is stored as x[32] | y[32] | z[32] (bvh_boxes_kernel), a PAIR of candidates is three 8-byte
         // reads at wave-uniform addresses (scalar loads: the operands arrive in SGPR pairs) and 3 v_pk_add + v_pk_mul + 2 v_pk_fma for
         // 2 x 64 distances, one min + compare + not-taken branch per pair: ~4.5 issue slots per candidate (the earlier scan — leaf in
         // two float4 registers per lane, coordinates as DPP row broadcasts of the subtraction — took 11: a DPP op costs two slots).

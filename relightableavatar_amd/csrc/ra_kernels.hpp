@@ -50,7 +50,7 @@ void launch_vert_blend(const float* weights, const float* A, const float* big_A,
 void launch_pack_verts(const float* pverts, int n_verts, float4* out, hipStream_t s);
 void launch_fold_bias(const float* W, int ld, int col0, int ncond, const float* cond, const float* bias, float* out,
                       hipStream_t s);   // out[r] = bias[r] + sum_c W[r*ld + col0 + c] * cond[c], r < 256
-// single-workgroup build of the vertex BVH (bbox, Morton codes, bitonic sort, boxes); n_verts <= 16384
+// per-frame build of the vertex box structure (bbox, Morton codes, ranks, boxes: two launches); n_verts <= 16384
 // order: scratch of n_verts ints (the vertices' Morton order, recomputed every frame)
 void launch_bvh_build(const float4* pverts4, int n_verts, int* order, float* leaves, float4* sbox, int n_leaves, int n_supers, hipStream_t s);
 int bvh_leaf_count(int n_verts);

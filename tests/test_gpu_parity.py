@@ -281,8 +281,8 @@ def test_bvh_equals_brute_force_on_other_mesh_sizes(relight):
 
 def test_box_structure_is_morton_sorted(relight):
     """the per-frame vertex order of the box structure IS the ascending (30-bit Morton code of the posed vertex, vertex index) order, for
-    every path of the builder's sort: the plain LDS loop (below 513 vertices) and the register / shuffle bitonic sort with 1, 2, 4, 8, 16
-    keys per thread — recomputed here in numpy with the kernel's float32 arithmetic"""
+    every mesh size class (a handful of vertices, counts around the 512 / 4096 / 16384 boundaries of earlier sort variants, the builder's
+    limit): bvh_rank_kernel ranks every vertex against all keys — recomputed here in numpy with the kernel's float32 arithmetic"""
     from relightableavatar_amd.base_utils import dotdict
     _, _, dev, body, eng = relight
     n0 = body.pverts.shape[1]
