@@ -582,7 +582,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
                                   const int* hit_count, int P, const float* bbox, float near_offset, const ra_trace_params& shadow,
                                   int no_visibility, int local_visibility, float** lvis_out, float** ldot_out, hipStream_t s,
                                   int n_boxes = 0, const float* boxes = nullptr, const int* box_start = nullptr, const int* pix_nn = nullptr,
-                                  const int* perm = nullptr) {
+                                  const int* perm = nullptr, bool split_wide_groups = false) {
     int err = 0;
     const int L = c->n_lights;
     const size_t NR = (size_t)P * L;
@@ -599,6 +599,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
     if (g.n_boxes) g.box_start[g.n_boxes] = box_start[g.n_boxes];
     g.perm = g.n_boxes ? perm : nullptr;
     g.near_offset = near_offset; g.L = L; g.no_visibility = no_visibility; g.local_visibility = local_visibility;
+    g.split_wide_groups = split_wide_groups ? 1 : 0;
     g.lvis = lvis; g.ldot = ldot;
     const bool traced = !(no_visibility || local_visibility);
     if (traced) {
@@ -740,7 +741,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     float *lvis = nullptr, *ldot = nullptr, *shade = nullptr, *spec = nullptr;
     if (relit) {
         if (light_visibility_stage(c, surf, m.norm, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow,
-                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s, p->n_boxes, p->boxes, p->box_start, rs.nn_hint, perm)) return 1;
+                                   p->no_visibility, p->local_visibility, &lvis, &ldot, s, p->n_boxes, p->boxes, p->box_start, rs.nn_hint, perm, true)) return 1;
         m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
         shade = c->buf<float>("mp_shade", (size_t)P * 3, &err);
         spec = c->buf<float>("mp_spec", (size_t)P * 3, &err);

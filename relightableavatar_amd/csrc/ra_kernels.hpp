@@ -112,6 +112,7 @@ struct ShadowGen {
     float near_offset;
     int L;
     int no_visibility, local_visibility;
+    int split_wide_groups;   // a group of 64 hit slots wider than 15 cm emits its rays half by half (the human layer; see shadow_gen_kernel)
     // out
     float* lvis;          // slot x L
     float* ldot;          // slot x L

@@ -312,6 +312,7 @@ __global__ void debug_aabb_kernel(const float* __restrict__ o, const float* __re
 }
 
 constexpr int SG_LIGHTS = 32;
+constexpr float SG_SPLIT_EXTENT = 0.15f;      // metres: a group of 64 Morton-neighbour hit pixels wider than this lies in two places
 __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
     __shared__ float t_ldot[64][SG_LIGHTS + 1], t_lvis[64][SG_LIGHTS + 1];
     const int nh = *g.hit_count;
@@ -338,9 +339,29 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
         acc = g.acc[r];
     }
     constexpr int ROUNDS = SG_LIGHTS / (TPB / 64);
-    __shared__ int cnt[ROUNDS * (TPB / 64) + 1];
+    constexpr int NL = ROUNDS * (TPB / 64);               // lights per workgroup (= SG_LIGHTS)
+    __shared__ int cnt[2][NL + 1];                        // traced rays per light among slots 0..31 / 32..63 of the group, then their offsets
     float nrv[ROUNDS], frv[ROUNDS];
     unsigned tmask = 0;
+    // A group is 64 hit pixels that are neighbours in the Morton order of the surface points: a patch of a few centimetres in a whole frame.
+    // In ONE RANK's share of a sharded frame (8 x 8 pixel tiles dealt round robin) a group that is not aligned with a tile holds pixels of two
+    // tiles 25 cm apart, and every wave of the coarse level then sweeps the boxes of both places (profiles/r05_shard_tile_size.txt).  Such a
+    // group emits its rays half by half — the first 32 slots for all lights, then the other 32 — so that a wave of 64 consecutive rays stays in
+    // one place (4 lights x ~16 surviving pixels instead of 2 x ~32).  Only the order of the ray list changes; results are scattered by slot.
+    float ext = 0.f;
+    {
+        float lo3[3], hi3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo3[k] = hv ? o[k] : 3e38f; hi3[k] = hv ? o[k] : -3e38f; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) { lo3[k] = fminf(lo3[k], __shfl_xor(lo3[k], sh)); hi3[k] = fmaxf(hi3[k], __shfl_xor(hi3[k], sh)); }
+        ext = fmaxf(fmaxf(hi3[0] - lo3[0], hi3[1] - lo3[1]), hi3[2] - lo3[2]);
+    }
+    // (not for the ground pass: its groups are metres wide anyway and four lights per wave cost more than they save there: + 9 % on its coarse
+    // launches, measured)
+    const bool halves = g.split_wide_groups && ext > SG_SPLIT_EXTENT;            // uniform over the workgroup: its four waves hold the same 64 slots
 #pragma unroll
     for (int round = 0; round < ROUNDS; ++round) {
         const int ll = round * (TPB / 64) + wv;            // light within the chunk (wave-uniform)
@@ -371,25 +392,35 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
         nrv[round] = nr; frv[round] = fr;
         if (trace) tmask |= 1u << round;
         const unsigned long long m = __ballot(trace);
-        if (lane == 0) cnt[ll] = __popcll(m);
+        if (lane == 0) { cnt[0][ll] = __popcll(m & 0xffffffffull); cnt[1][ll] = __popcll(m >> 32); }
     }
     __syncthreads();
     // ONE atomic per workgroup for the traced-ray list (same-address atomics serialise: per wave they were the whole kernel
-    // time); a wave's rays (one light x 64 neighbouring slots) stay contiguous
+    // time); a wave's rays (one light x 64 neighbouring slots — or, for a group in two places, 32) stay contiguous
     if (threadIdx.x == 0) {
         int tot = 0;
-        for (int k = 0; k < ROUNDS * (TPB / 64); ++k) { const int c = cnt[k]; cnt[k] = tot; tot += c; }
-        cnt[ROUNDS * (TPB / 64)] = tot ? atomicAdd(g.ray_count, tot) : 0;
+        if (halves) {
+            for (int hf = 0; hf < 2; ++hf)
+                for (int k = 0; k < NL; ++k) { const int c = cnt[hf][k]; cnt[hf][k] = tot; tot += c; }
+        } else {
+            for (int k = 0; k < NL; ++k) {
+                const int c0 = cnt[0][k], c1 = cnt[1][k];
+                cnt[0][k] = tot; cnt[1][k] = tot + c0; tot += c0 + c1;
+            }
+        }
+        cnt[0][NL] = tot ? atomicAdd(g.ray_count, tot) : 0;
     }
     __syncthreads();
-    const int gbase = cnt[ROUNDS * (TPB / 64)];
+    const int gbase = cnt[0][NL];
 #pragma unroll
     for (int round = 0; round < ROUNDS; ++round) {
         const int ll = round * (TPB / 64) + wv;
         const bool trace = (tmask >> round) & 1u;
         const unsigned long long m = __ballot(trace);
         if (trace) {
-            const int s = gbase + cnt[ll] + __popcll(m & ((1ull << lane) - 1ull));
+            const int hf = lane >> 5;
+            const unsigned mh = hf ? (unsigned)(m >> 32) : (unsigned)m;
+            const int s = gbase + cnt[hf][ll] + __popc(mh & ((1u << (lane & 31)) - 1u));
             const int l = lc * SG_LIGHTS + ll;
             g.ray_pix[s] = r;
             g.ray_light[s] = l;
