@@ -958,8 +958,6 @@ def render_ground(net: OracleNet, ray_o, ray_d, acc, probe, fr, bbox):
     eps), DFSS shadows of the avatar onto the plane with cfg.env_lvis, Lambert ground lit by the probe, distance fade.
     ray_o, ray_d (P,3); acc (P) = 1 - human acc; returns per-pixel maps."""
     c = net.cfg
-    if c.get('only_visibility', False):
-        raise NotImplementedError('only_visibility in the ground pass (one-channel shade / spec maps, :516-519) is not restated')
     n = normalize(torch.tensor(c.ground_normal, dtype=torch.float32))
     orig = torch.tensor(c.ground_origin, dtype=torch.float32)
     t = -((ray_o - orig) @ n) / ((ray_d @ n) + 1e-8)
@@ -975,6 +973,9 @@ def render_ground(net: OracleNet, ray_o, ray_d, acc, probe, fr, bbox):
     ldot = (ldir @ n)[:, None].expand(-1, surf.shape[0])                   # (L,P): NOT clamped (:504)
     lvis = lvis * (1 - weight)[None] + weight[None]
     light = sample_envmap_image(probe, ldir)                               # (L,3)
+    if c.get('only_visibility', False):                                    # :516-519 (debugging option): uniform cosine, one-channel light:
+        ldot = torch.ones_like(ldot)                                       # shade / spec come out with ONE channel and broadcast in the blend
+        light = light.mean(dim=-1, keepdim=True)
     shade = lvis[..., None] * ldot[..., None] * area[:, None, None] * light[:, None, :]
     rgb = ((albedo / math.pi)[None] * shade).sum(0)
     if c.tonemapping_rendering:

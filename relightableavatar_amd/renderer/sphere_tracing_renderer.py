@@ -67,10 +67,10 @@ class Renderer(nn.Module):
             raise NotImplementedError('vis_rendering_map / vis_shading_map / vis_specular_map all off leaves no rgb_map for the ground pass / '
                                       'the novel-light re-shade (the reference fails there too)')
         only_vis = bool(cfg.get('only_visibility', False)) and bool(cfg.relighting)
-        if only_vis and (ground or cfg.vis_novel_light):
-            # the reference's debugging option (:516-519, :720-723) turns shade / spec of the ground layer into one-channel maps that its
-            # blend then broadcasts against the human layer's three; not reproduced — refuse instead of returning something else
-            raise NotImplementedError('cfg.only_visibility is supported for the human layer only (not with vis_ground_shading / vis_novel_light)')
+        if only_vis and cfg.vis_novel_light:
+            # the reference's debugging option (:720-723) also replaces the cosines the novel-light re-shade caches (ldot_map = 1): not
+            # reproduced — refuse instead of returning something else
+            raise NotImplementedError('cfg.only_visibility is not supported together with vis_novel_light')
         eng = self.net.set_frame(batch)
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
@@ -148,7 +148,9 @@ class Renderer(nn.Module):
         if relit:
             # only_visibility: a one-channel light (:723, :749-751); vis_lvis_map / vis_ldot_map expand to three (:756-757)
             one_ch = only_vis and not (cfg.get('vis_lvis_map', False) or cfg.get('vis_ldot_map', False))
-            ret.shade_map = full.shade[None, :, :1] if one_ch else full.shade[None]
+            # (with the ground pass the cut comes after the blend: both layers' shade maps have one channel in the reference, :516-519, and the
+            # kernels write it three times)
+            ret.shade_map = full.shade[None, :, :1] if (one_ch and not ground) else full.shade[None]
             if 'spec' in full:
                 ret.spec_map = full.spec[None]
             if 'lvis' in full:
@@ -160,6 +162,8 @@ class Renderer(nn.Module):
                 ret.ground = grd             # the novel-light renderer re-shades both layers per probe, then blends (:1106-1107)
             else:
                 ret = self.blend_output_(grd.acc_map, grd.inds, grd, ret, eng)
+                if relit and only_vis and not (cfg.get('vis_lvis_map', False) or cfg.get('vis_ldot_map', False)):
+                    ret.shade_map = ret.shade_map[..., :1]
         return ret
 
     BLEND_KEYS = ('rgb_map', 'rfl_map', 'surf_map', 'albedo_map', 'roughness_map', 'norm_map', 'cpts_map', 'bpts_map', 'spec_map',

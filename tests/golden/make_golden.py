@@ -163,6 +163,7 @@ SWITCH_VARIANTS.update({
     'g_linear': {'tonemapping_rendering': False},
     'g_local_visibility': {'local_visibility': True},
     'g_plain_ground': {'ground_attach_envmap': False, 'ground_albedo': [0.3, 0.2, 0.1], 'ground_shading_multiplier': 2.0},
+    'g_only_visibility': {'only_visibility': True},      # one-channel shade / spec maps of the ground blended against the human layer's (:516-519)
     'g_env_lvis': {'env_lvis.iter': 8, 'env_lvis.offset': 0.02, 'env_lvis.dist_th': 0.01, 'env_lvis.bbox_margin': 0.3, 'env_lvis.near_offset': 0.03},
 })
 # and for the volume path (base_renderer.py:17,72,120-121): names start with v_, AniSDF network, an 8 x 8 window, 64 samples unless overridden

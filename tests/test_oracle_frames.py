@@ -228,7 +228,8 @@ SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibi
                 'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter', 'smpl24', 'other_weights', 'all_shadowed']
 
 
-GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis']
+GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis',
+                       'g_only_visibility']
 
 
 @pytest.mark.parametrize('name', GROUND_SWITCH_NAMES)
