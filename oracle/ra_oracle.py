@@ -765,7 +765,7 @@ def light_visibility(net: OracleNet, surf, norm, acc, fr, bbox, lvis_cfg, sdf_fn
     return lvis, ldot
 
 
-def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, ldot, want_spec=False):
+def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, ldot, want_spec=False, main_pass=True):
     """Shading block sphere_tracing_renderer.py:715-755 / novel_light_sphere_tracing.py:21-66.
     probe (H,W,3); per-pixel tensors (P,*); lvis/ldot (L,P). Returns rgb (sRGB), shade, spec (or None)."""
     c = net.cfg
@@ -774,7 +774,8 @@ def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, 
     surf2light = normalize(xyz[:, None] - surf[None])                 # (L,P,3)
     surf2cam = normalize(ray_o - surf)
     light = sample_envmap_image(probe, surf2light)                    # (L,P,3)
-    if c.get('only_visibility', False):                               # :720-723 (debugging option): uniform cosine, one-channel light
+    # (main_pass False: the novel-light re-shade, novel_light_sphere_tracing.py:21-66, which knows none of the debugging switches below)
+    if main_pass and c.get('only_visibility', False):                 # :720-723 (debugging option): uniform cosine, one-channel light
         ldot = torch.ones_like(ldot)
         light = light.mean(dim=-1, keepdim=True)
     ones = torch.ones_like(ldot)
@@ -793,9 +794,9 @@ def shade_pixels(net: OracleNet, probe, ray_o, surf, norm, albedo, rough, lvis, 
         spec = (sb * (ones[..., None] * sl[..., None] * area[:, None, None] * light)).sum(0)
     shade_map = (lvis[..., None] * ldot[..., None] * area[:, None, None] * light).sum(0) * c.shading_albedo / math.pi
     eH = c.env_h                                                      # :756-757: mean over the probe's rows, then over its columns
-    if c.get('vis_lvis_map', False):
+    if main_pass and c.get('vis_lvis_map', False):
         shade_map = lvis.view(eH, -1, lvis.shape[-1]).mean(0).mean(0)[:, None].expand(-1, 3)
-    if c.get('vis_ldot_map', False):
+    if main_pass and c.get('vis_ldot_map', False):
         shade_map = ldot.view(eH, -1, ldot.shape[-1]).mean(0).mean(0)[:, None].expand(-1, 3)
     return rgb, shade_map, spec
 
@@ -862,7 +863,8 @@ def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
         if spec is not None:
             ret.spec_map = spec
         if c.vis_novel_light:
-            ret.lvis_map, ret.ldot_map = lvis.T.contiguous(), ldot.T.contiguous()     # (P,512)
+            ldot_kept = torch.ones_like(ldot) if c.get('only_visibility', False) else ldot          # :758-759: the cosines as the shading used them
+            ret.lvis_map, ret.ldot_map = lvis.T.contiguous(), ldot_kept.T.contiguous()     # (P,512)
     else:
         ret.rgb_map = rgb
     full = odict()
@@ -1125,7 +1127,7 @@ def render_novel_light(net: OracleNet, batch, ground_inds=None):
         for (a, b) in _chunks(P, c.render_chunk_size):
             rgb, shade, spec = shade_pixels(net, probe, main.ray_o[0, a:b], main.surf_map[0, a:b], main.norm_map[0, a:b],
                                             main.albedo_map[0, a:b], main.roughness_map[0, a:b, None],
-                                            main.lvis_map[0, a:b].T, main.ldot_map[0, a:b].T, want_spec=True)
+                                            main.lvis_map[0, a:b].T, main.ldot_map[0, a:b].T, want_spec=True, main_pass=False)
             rgbs.append(rgb), shades.append(shade), specs.append(spec)
         human = odict(rgb_map=torch.cat(rgbs), shade_map=torch.cat(shades), spec_map=torch.cat(specs))
         if grd is not None:

@@ -922,6 +922,8 @@ int ra_reshade(ra_ctx* c, const float* ray_o, const float* surf, const float* no
         in.spec = spec ? spec + (size_t)q0 * P * 3 : nullptr;
         ra_config cfg = c->cfg;
         cfg.tonemapping = 1;      // novel_light_sphere_tracing.py:47 applies linear2srgb unconditionally
+        cfg.only_visibility = 0;  // ... and knows none of render_human's debugging switches (:21-66): it shades with the cosines and probes it is given
+        cfg.vis_shade_map = 0;
         launch_shade(in, cfg, s);
     }
     c->n_shaded += (uint64_t)P * n_probes;

@@ -67,10 +67,6 @@ class Renderer(nn.Module):
             raise NotImplementedError('vis_rendering_map / vis_shading_map / vis_specular_map all off leaves no rgb_map for the ground pass / '
                                       'the novel-light re-shade (the reference fails there too)')
         only_vis = bool(cfg.get('only_visibility', False)) and bool(cfg.relighting)
-        if only_vis and cfg.vis_novel_light:
-            # the reference's debugging option (:720-723) also replaces the cosines the novel-light re-shade caches (ldot_map = 1): not
-            # reproduced — refuse instead of returning something else
-            raise NotImplementedError('cfg.only_visibility is not supported together with vis_novel_light')
         eng = self.net.set_frame(batch)
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
@@ -155,6 +151,11 @@ class Renderer(nn.Module):
                 ret.spec_map = full.spec[None]
             if 'lvis' in full:
                 ret.lvis_map, ret.ldot_map = full.lvis[None], full.ldot[None]
+                if only_vis:
+                    # the debugging option replaces the cosines the novel-light re-shade caches too (:720-722, :758-759): 1 on the hit rays —
+                    # times acc where the maps are premultiplied (alpha_output_, no ground pass), 0 elsewhere (multi_scatter_zeros)
+                    one = ret.acc_map if not ground else (ret.acc_map > 0).to(ret.ldot_map.dtype)
+                    ret.ldot_map = one[..., None].expand_as(ret.ldot_map).contiguous()
         ret.envmap = envmap
         if ground:
             grd = self._ground(batch, ret, eng, probe)

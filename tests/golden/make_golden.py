@@ -177,6 +177,7 @@ VOLUME_H, VOLUME_CROP = 128, 8
 # n_; one probe with a full-resolution image, rotate_ratio * env_w headings re-shaded from one traced frame, four of them stored
 SWITCH_VARIANTS.update({
     'n_rotate': {'vis_novel_light': True, 'vis_rotate_light': True, 'rotate_ratio': 1, 'test_light': ['main']},
+    'n_only_visibility': {'vis_novel_light': True, 'only_visibility': True, 'test_light': ['main']},      # the cached cosines become 1 (:720-722, :758-759)
     'n_rotate_ground': dict(GROUND_BASE, **{'vis_novel_light': True, 'vis_rotate_light': True, 'rotate_ratio': 2, 'test_light': []}),
 })
 NOVEL_H, NOVEL_CROP, NOVEL_GROUND_H = 128, 6, 16
@@ -401,7 +402,7 @@ def gen_switch(cfg, synthetic, variant, out_path):
             out = novel_light_sphere_tracing.Renderer(net).render(batch)
         names = [k for k in out if k != 'diff']
         arrs = {'names': np.asarray(json.dumps(names))}
-        keep = (['main'] if 'main' in out else []) + [f'probe00-{j:04d}' for j in NOVEL_HEADINGS]
+        keep = (['main'] if 'main' in out else []) + [f'probe00-{j:04d}' for j in NOVEL_HEADINGS] if cfg.vis_rotate_light else names
         for name in keep:
             for k in ('rgb_map', 'shade_map', 'spec_map', 'albedo_map', 'acc_map'):
                 if k in out[name]:

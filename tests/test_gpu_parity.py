@@ -665,14 +665,6 @@ def test_novel_switch_matrix(golden, name):
         assert float(err(out[out_name].albedo_map, maps['albedo_map']).max()) < 1e-2
 
 
-def test_only_visibility_refuses_the_layers_it_does_not_cover():
-    from relightableavatar_amd.renderer import make_renderer
-    cfg, net, dev = build('novel_light', only_visibility=True)
-    batch = synthetic.to_device(synthetic.make_batch(24, 24, seed=0, posed=True, crop=6, n_novel_lights=1), dev)
-    with pytest.raises(NotImplementedError):
-        make_renderer(cfg, net).render(batch)
-
-
 def test_frame_relight(golden):
     out, ref, batch, net = _frame('relight', 'frame_relight.npz', golden, vis_specular_map=True)
     # the SURVEY 8d body (white noise in the skinning logits): the contract itself, no emulation-derived floor (round 3 asserted floor - 3 dB;

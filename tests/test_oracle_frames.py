@@ -255,7 +255,7 @@ def test_ground_switch_matrix(golden, name):
 
 
 VOLUME_SWITCH_NAMES = ['v_bg', 'v_clip', 'v_s16_chunks']
-NOVEL_SWITCH_NAMES = ['n_rotate', 'n_rotate_ground']
+NOVEL_SWITCH_NAMES = ['n_rotate', 'n_rotate_ground', 'n_only_visibility']
 
 
 def novel_switch_case(ref, name):
