@@ -138,6 +138,7 @@ SWITCH_VARIANTS = {
                      'obj_lvis.iter': 6, 'obj_lvis.offset': 0.02, 'obj_lvis.near_offset': 0.03, 'obj_lvis.relax': 0.1, 'surf_sample_range': 0.01},
     'no_specular_vis': {'vis_specular_map': False, 'bg_brightness': 0.5},
     'no_geodesic_filter': {'use_geodesic_filter': False},
+    'env_r': {'env_r': 3.0},        # lights on a sphere of 3 m: directions and the shadow rays' far end change
     'maps_only': {'vis_rendering_map': False, 'vis_specular_map': False},      # render_human's early return (:702-705): no shading at all
     # structural parameters: one material sample per hit (zval = 0.5, :608-609), five; light sets of other sizes (45 lights: not a multiple
     # of a wavefront; the learned map at 1x / 3x the probe's size); a single shadow iteration from iteration 0
@@ -163,6 +164,7 @@ SWITCH_VARIANTS.update({
     'g_linear': {'tonemapping_rendering': False},
     'g_local_visibility': {'local_visibility': True},
     'g_plain_ground': {'ground_attach_envmap': False, 'ground_albedo': [0.3, 0.2, 0.1], 'ground_shading_multiplier': 2.0},
+    'g_env_r': {'env_r': 1.5},      # the light sphere's radius: the ground's distance fade (:497-505) and depth clip (:540) become active inside the frame
     'g_only_visibility': {'only_visibility': True},      # one-channel shade / spec maps of the ground blended against the human layer's (:516-519)
     'g_env_lvis': {'env_lvis.iter': 8, 'env_lvis.offset': 0.02, 'env_lvis.dist_th': 0.01, 'env_lvis.bbox_margin': 0.3, 'env_lvis.near_offset': 0.03},
 })

@@ -225,11 +225,11 @@ def switch_batch_kw(overrides):
 
 SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibility', 'lambert_only', 'glossy_only', 'linear', 'only_visibility',
                 'vis_lvis_map', 'vis_ldot_map', 'chromatic', 'material_params', 'trace_params', 'no_specular_vis', 'no_geodesic_filter', 'maps_only',
-                'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter', 'smpl24', 'other_weights', 'all_shadowed']
+                'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter', 'smpl24', 'other_weights', 'all_shadowed', 'env_r']
 
 
 GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis',
-                       'g_only_visibility']
+                       'g_only_visibility', 'g_env_r']
 
 
 @pytest.mark.parametrize('name', GROUND_SWITCH_NAMES)
