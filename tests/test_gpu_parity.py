@@ -5,7 +5,7 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
   coarse level / LBS warp ............ 1e-6 absolute (fp32, different summation order only), exact 3-NN indices
   resd, sdf, feat (MLP outputs) ...... 3e-4 abs (sdf), 2e-4 (feat); measured mean 4.5e-5 / 1.6e-5
   HDQ sdf ............................ 3e-4 abs
-  normals (forward-mode tangents) .... 8e-3 abs per component, mean < 6e-4
+  normals (reverse-mode, K4 backward) .. 8e-3 abs per component, mean < 6e-4
   albedo / roughness / occ ........... 1e-4 abs
   traced surfaces .................... median |st err| < 2e-4; rays whose 16-iteration trace has not converged
                                        amplify sdf noise (occ = 500 d / t), so frame maps are judged by the
@@ -20,7 +20,7 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
       from 64 to 51 dB, which is why the all-ray PSNR is only a sanity bound there.
       * through assert_contract: frame_relight, frame_relight_smooth, frame_novel (three probes), frame_ground, the multi-chunk and
         other-pose cases, the full-size sample, the volume frames (> 80 dB);
-      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 38 configuration overrides, one process per variant):
+      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 42 configuration overrides, one process per variant):
         25 relit windows, 8 ground-pass frames, 3 volume frames, 2 rotating-light sequences; rgb through assert_contract over ALL rays
         (no fp32-unstable ray on these windows: 60-96 dB, max 1.5e-4 .. 7.8e-3), the other maps to their tolerances;
         test_box_structure_is_morton_sorted pins the per-frame vertex order of the box structure against numpy;
