@@ -61,10 +61,39 @@ def freq_bands(multires: int) -> torch.Tensor:
     return fb[:, None, None].expand(multires, 2, 1).clone()
 
 
-def make_state_dict(seed: int = 0, relight: bool = True, cfg=None) -> dict:
-    """state_dict with the reference's key names."""
+# 'sharp' weights: relative scale (to the coordinate columns' sqrt(2)/sqrt(out)) of the SDF net's encoding columns per frequency band
+# 2^0 .. 2^7.  The geometric init leaves them at ~0 (net_utils.py:1310-1318: zero; here 0.02 so the path is exercised); a trained net
+# uses them: this profile puts 1.5x .. 4x that energy on the 78 cm .. 5 cm bands and gives centimetre-scale surface detail (11.7 mm rms /
+# 47 mm peak-to-peak over a 21 cm arc after removing a cubic, |grad sdf| = 1.33 +- 0.54 near the zero set instead of 0.94 +- 0.30, 1.14
+# zero crossings per radial line: overhangs).  The SAME scale on every band (1.0, "the hidden columns' scale") is not a distance field
+# at all: |grad| ~ 20 and sin^2 + cos^2 = 1 adds a constant 24 rho^2 under the root of the geometric init's |W x| — no zero set is left.
+SHARP_BANDS = (0.02, 0.02, 0.02, 0.05, 0.08, 0.06, 0.04, 0.03)
+SHARP_SDF_BIAS = -0.559         # keeps the zero set's mean radius at 0.42 m under SHARP_BANDS (the constant above moves it inwards)
+SHARP_RESD_GAIN = 16.0          # residual deformation of ~1.5 cm instead of the default init's ~1 mm
+
+
+FRONT_LIGHT_DIR = (-0.80, -0.30, -0.52)
+
+
+def _env_pixel(d, eh, ew):
+    """(row, column) of the light map's texel that direction d samples (relight_utils.py:106-127: theta = acos(d_z), phi = atan2(d_y, d_x),
+    grid (-phi / pi, 2 theta / pi - 1), align_corners=False)"""
+    n = math.sqrt(sum(c * c for c in d))
+    theta, phi = math.acos(d[2] / n), math.atan2(d[1], d[0])
+    return ((2 * theta / math.pi) * eh / 2 - 0.5, (1 - phi / math.pi) * ew / 2 - 0.5)
+
+
+def make_state_dict(seed: int = 0, relight: bool = True, cfg=None, kind: str = 'init', env: str = 'back') -> dict:
+    """state_dict with the reference's key names.  kind: 'init' — the reference initialisers' statistics; 'sharp' —
+    trained-like: live high-frequency encoding columns in the SDF net (SHARP_BANDS) and a centimetre-scale residual deformation.
+    env: where the learned light map's lobes sit — 'back' (behind / beside the body as seen from the synthetic camera: the
+    self-shadowing of a convex body is all penumbra) or 'front' (one strong lobe on the camera's side, so that a body part in front
+    of another casts a shadow the camera sees)."""
     from .config import default_cfg
     cfg = cfg or default_cfg()
+    assert kind in ('init', 'sharp') and env in ('back', 'front'), (kind, env)
+    bands = SHARP_BANDS if kind == 'sharp' else (0.02,) * 8
+    band_scale = torch.tensor([bands[min(k, len(bands) - 1)] / 0.02 for k in range(cfg.sdf_res)]).repeat_interleave(6)
     sd = {}
     xyz_dim = 3 + 6 * cfg.xyz_res        # 63
     sdf_dim = 3 + 6 * cfg.sdf_res        # 51
@@ -79,6 +108,8 @@ def make_state_dict(seed: int = 0, relight: bool = True, cfg=None) -> dict:
         O = 3 if i == 8 else W
         _linear(sd, seed, f'{p}.mlp.linears.{i}', I, O)
     sd[f'{p}.mlp.linears.8.bias'] = torch.zeros(3)
+    if kind == 'sharp':
+        sd[f'{p}.mlp.linears.8.weight'] = sd[f'{p}.mlp.linears.8.weight'] * SHARP_RESD_GAIN
     # signed distance net (net_utils.py:1276-1352), geometric init, weight-normed
     p = 'signed_distance_network'
     sd[p + '._beta'] = torch.tensor(float(cfg.sdf_beta_init_value))
@@ -91,17 +122,17 @@ def make_state_dict(seed: int = 0, relight: bool = True, cfg=None) -> dict:
             w = _normal(seed, name + '.w', (out_dim, dims[l]), math.sqrt(math.pi) / math.sqrt(dims[l]), 1e-4)
             # feature rows: small random so feat is not a copy of sdf
             w[1:] = _normal(seed, name + '.wf', (out_dim - 1, dims[l]), 0.0, 1.0 / math.sqrt(dims[l]))
-            b = torch.full((out_dim,), -0.5)
+            b = torch.full((out_dim,), SHARP_SDF_BIAS if kind == 'sharp' else -0.5)
             b[1:] = _uniform(seed, name + '.bf', (out_dim - 1,), 0.1)
         elif l == 0:
             w = torch.zeros(out_dim, dims[l])
             w[:, :3] = _normal(seed, name + '.w', (out_dim, 3), 0.0, math.sqrt(2) / math.sqrt(out_dim))
             # a little energy on the encoded inputs so the PE path is exercised
-            w[:, 3:] = _normal(seed, name + '.wpe', (out_dim, dims[l] - 3), 0.0, 0.02 / math.sqrt(out_dim))
+            w[:, 3:] = _normal(seed, name + '.wpe', (out_dim, dims[l] - 3), 0.0, 0.02 / math.sqrt(out_dim)) * band_scale
             b = torch.zeros(out_dim)
         elif l == 4:
             w = _normal(seed, name + '.w', (out_dim, dims[l]), 0.0, math.sqrt(2) / math.sqrt(out_dim))
-            w[:, -(dims[0] - 3):] = _normal(seed, name + '.wpe', (out_dim, dims[0] - 3), 0.0, 0.02 / math.sqrt(out_dim))
+            w[:, -(dims[0] - 3):] = _normal(seed, name + '.wpe', (out_dim, dims[0] - 3), 0.0, 0.02 / math.sqrt(out_dim)) * band_scale
             b = torch.zeros(out_dim)
         else:
             w = _normal(seed, name + '.w', (out_dim, dims[l]), 0.0, math.sqrt(2) / math.sqrt(out_dim))
@@ -128,7 +159,12 @@ def make_state_dict(seed: int = 0, relight: bool = True, cfg=None) -> dict:
         r = _rng(seed, 'global_env_map_')
         base = r.uniform(0, 1, size=(eh, ew, ch)) * cfg.envmap_init_intensity
         yy, xx = np.mgrid[0:eh, 0:ew]
-        for (cy, cx, amp) in ((eh * 0.3, ew * 0.25, 4.0), (eh * 0.45, ew * 0.7, 2.0)):
+        lobes = ((eh * 0.3, ew * 0.25, 4.0), (eh * 0.45, ew * 0.7, 2.0))
+        if env == 'front':      # a key light towards (-0.80, -0.30, -0.52) — left of and above the synthetic camera's axis, on the camera's
+            # side of the body — over a dim ambient (softplus(-2.4) = 0.09): ~85 % of the light's power sits in ~20 of the 512 lights
+            base = base - 2.5
+            lobes = (_env_pixel(FRONT_LIGHT_DIR, eh, ew) + (14.0,), (eh * 0.45, ew * 0.7, 2.0))
+        for (cy, cx, amp) in lobes:
             base += amp * np.exp(-(((yy - cy) / 3.0) ** 2 + ((xx - cx) / 4.0) ** 2))[..., None]
         sd['global_env_map_'] = torch.from_numpy(base.astype(np.float32))
         xyz, area = gen_light_xyz(cfg.env_h, cfg.env_w, cfg.env_r)
@@ -149,12 +185,17 @@ def _rodrigues(rvec: np.ndarray) -> np.ndarray:
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise: float = 2.0, n_bones: int = None, n_verts: int = None) -> dotdict:
+def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise: float = 2.0, n_bones: int = None, n_verts: int = None,
+              split_axis=None, split_offset=None, split_cos: float = 0.0, skin_sharpness: float = 6.0) -> dotdict:
     """SMPL-shaped frame state with the §8b batch keys (leading batch dim 1).
     skin_noise: std of the per-vertex white noise in the skinning logits.  The default (2.0) makes
     neighbouring vertices follow different bones, so the world -> big-pose warp jumps by ~1 cm wherever the nearest
     vertices change and the reference's own sphere trace ends in a limit cycle on ~9 % of the hit rays; 0.0 gives a spatially smooth
-    skinning field like a real SMPL body's (the trace converges) — the well-conditioned case of the parity tests."""
+    skinning field like a real SMPL body's (the trace converges) — the well-conditioned case of the parity tests.
+    split_axis / split_offset: the bones that own the side of the template facing `split_axis` (their skinning plane's normal has a
+    positive component along it) are additionally translated by `split_offset` (metres, pose space): the posed body comes apart into
+    two pieces decimetres apart — an arm held in front of the trunk —, so that light-visibility rays leaving one piece meet the other
+    at distance (sphere_tracing_renderer.py:265-344).  LBS only: the canonical distance field stays one zero set."""
     N_VERTS, N_BONES = (n_verts or globals()['N_VERTS']), (n_bones or globals()['N_BONES'])      # another body model (SMPL: 24 bones)
     i = np.arange(N_VERTS, dtype=np.float64) + 0.5
     phi = np.arccos(1 - 2 * i / N_VERTS)
@@ -169,7 +210,7 @@ def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise
     weights = r.standard_normal((N_VERTS, N_BONES)) * 4.0
     # smooth the skinning field a little: weight depends on position through random planes
     planes = r.standard_normal((N_BONES, 3))
-    weights = 6.0 * (nrm @ planes.T) + (skin_noise / 4.0) * weights
+    weights = skin_sharpness * (nrm @ planes.T) + (skin_noise / 4.0) * weights
     weights = np.exp(weights - weights.max(-1, keepdims=True))
     weights /= weights.sum(-1, keepdims=True)
     A = np.tile(np.eye(4), (N_BONES, 1, 1))
@@ -180,11 +221,25 @@ def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise
             A[j, :3, 3] = r.uniform(-0.05, 0.05, 3)
             big_A[j, :3, :3] = _rodrigues(r.uniform(-1, 1, 3) * 0.2 / math.sqrt(3))
             big_A[j, :3, 3] = r.uniform(-0.03, 0.03, 3)
+    if split_axis is not None:
+        ax = np.asarray(split_axis, dtype=np.float64)
+        moved = planes @ ax > split_cos * np.linalg.norm(planes, axis=-1) * np.linalg.norm(ax)
+        A[moved, :3, 3] += np.asarray(split_offset, dtype=np.float64)
     # posed verts / normals by forward LBS of the T-pose mesh (what the dataset does on CPU)
     Av = np.einsum('nj,jab->nab', weights, A)
     pverts = np.einsum('nab,nb->na', Av[:, :3, :3], tverts) + Av[:, :3, 3]
     pnorm = np.einsum('nab,nb->na', Av[:, :3, :3], tnorm)
     pnorm /= np.linalg.norm(pnorm, axis=-1, keepdims=True)
+    if split_axis is not None:
+        # a deformation this large is not near-rigid: rotating the template's normals no longer gives the posed surface's.  Vertex
+        # normals of the posed mesh instead, as the dataset computes them (base_dataset.py:222-241: face normals weighted by area,
+        # summed per vertex), on the convex hull's triangulation of the template
+        faces = _template_faces(nrm)
+        fn = np.cross(pverts[faces[:, 1]] - pverts[faces[:, 0]], pverts[faces[:, 2]] - pverts[faces[:, 0]])
+        pnorm = np.zeros_like(pverts)
+        for k in range(3):
+            np.add.at(pnorm, faces[:, k], fn)
+        pnorm /= np.maximum(np.linalg.norm(pnorm, axis=-1, keepdims=True), 1e-12)
     if posed:
         R = _rodrigues(np.array([0.1, -0.2, 0.15]))
         Th = np.array([[0.03, -0.02, 0.05]])
@@ -207,6 +262,16 @@ def make_body(seed: int = 0, posed: bool = True, radius: float = 0.4, skin_noise
     b.tbounds = f(np.stack([tverts.min(0) - margin, tverts.max(0) + margin]))      # big-pose box (visualiser's Surface type)
     b.train_motion = dotdict(poses=f(train_poses))
     return b
+
+
+def _template_faces(nrm: np.ndarray) -> np.ndarray:
+    """outward-oriented triangulation of the template: the convex hull of its points on the unit sphere"""
+    from scipy.spatial import ConvexHull
+    faces = ConvexHull(nrm).simplices.astype(np.int64)
+    c = np.cross(nrm[faces[:, 1]] - nrm[faces[:, 0]], nrm[faces[:, 2]] - nrm[faces[:, 0]])
+    flip = (c * nrm[faces].mean(1)).sum(-1) < 0
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    return faces
 
 
 def make_camera(H: int, W: int, origin=(0.0, 0.0, -2.0), focal_ratio: float = 0.8):
@@ -281,15 +346,18 @@ def make_skeleton(seed: int = 0):
 
 
 def make_batch(H: int, W: int, seed: int = 0, posed: bool = True, n_novel_lights: int = 0,
-               crop: int = 0, skin_noise: float = 2.0, cam_dist: float = 2.0, n_bones: int = None, n_verts: int = None) -> dotdict:
+               crop: int = 0, skin_noise: float = 2.0, cam_dist: float = 2.0, n_bones: int = None, n_verts: int = None,
+               split_axis=None, split_offset=None, split_cos: float = 0.0, skin_sharpness: float = 6.0, crop_at=None) -> dotdict:
     """Full §8b batch on CPU. ``crop``>0 keeps only a centred crop x crop window of pixels.  ``cam_dist``: distance of the camera from
-    the body's centre (2 m, the body then covers ~8 % of the frame; 0.96 m: ~35 %, a frame-filling subject)."""
-    b = make_body(seed, posed, skin_noise=skin_noise, n_bones=n_bones, n_verts=n_verts)
+    the body's centre (2 m, the body then covers ~8 % of the frame; 0.96 m: ~35 %, a frame-filling subject).
+    ``crop_at``: (row, column) of the window's top-left pixel instead of the centred one."""
+    b = make_body(seed, posed, skin_noise=skin_noise, n_bones=n_bones, n_verts=n_verts, split_axis=split_axis, split_offset=split_offset, split_cos=split_cos,
+                  skin_sharpness=skin_sharpness)
     K, R, T = make_camera(H, W, origin=(0.0, 0.0, -float(cam_dist)))
     ro, rd, near, far, mask = rays_within_bounds(H, W, K, R, T, b.wbounds[0].numpy().astype(np.float64))
     if crop:
         win = np.zeros((H, W), dtype=bool)
-        y0, x0 = (H - crop) // 2, (W - crop) // 2
+        y0, x0 = ((H - crop) // 2, (W - crop) // 2) if crop_at is None else (int(crop_at[0]), int(crop_at[1]))
         win[y0:y0 + crop, x0:x0 + crop] = True
         keep = win[mask]
         ro, rd, near, far = ro[keep], rd[keep], near[keep], far[keep]

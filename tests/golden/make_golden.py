@@ -153,6 +153,24 @@ SWITCH_VARIANTS = {
     'other_weights': {'@weights_seed': 7, '@seed': 3, '@posed': False, '@cam_dist': 1.6},
     'all_shadowed': {'@weights_seed': 5, '@seed': 3, '@posed': False, '@cam_dist': 1.6},      # this field shadows the whole window: shade = rgb = 0
 }
+# the hard cases (round 6).  Every variant above renders a convex blob with near-initialisation weights: a shadow ray that leaves it towards a
+# front-facing light never meets the body again, and the SDF net's high-frequency encoding columns are ~0.  These do not:
+#  * split_body — a bone group (the cap of the template around @split_axis) is pulled 0.57 m out of the body (LBS only: the canonical
+#    field stays one zero set): a horn over the shoulder with a gap under it; the key light (@env front: ~2/3 of the power in ~20 lights, on
+#    the camera's side) throws its shadow onto the body.  The window lies in that cast shadow and across its penumbra.  obj_lvis.iter = 12:
+#    with the default 4 iterations (offset 1 cm) a shadow ray is 10 cm long at most and no part ever shadows another at distance —
+#    split_body_iter4 keeps the default for comparison;
+#  * sharp_weights — trained-like weights (synthetic.SHARP_BANDS: live encoding columns up to 2^7, centimetre-scale surface detail,
+#    |grad sdf| = 1.3 +- 0.5, a 1.5 cm residual deformation) on the base window, with the distance field on 3 000 points around the body;
+#  * sharp_split — both, with white noise in the skinning logits (skin_noise 2.0: the world -> big-pose warp jumps between neighbours).
+SPLIT_BODY = {'@split_axis': [-0.25, -0.94, -0.26], '@split_offset': [-0.45, 0.0, -0.35], '@split_cos': 0.8, '@skin_sharpness': 6.0, '@env': 'front'}
+SPLIT_WINDOW = {'@crop': 12, '@crop_at': [64, 46]}
+SWITCH_VARIANTS.update({
+    'split_body': dict(SPLIT_BODY, **SPLIT_WINDOW, **{'obj_lvis.iter': 12}),
+    'split_body_iter4': dict(SPLIT_BODY, **SPLIT_WINDOW),
+    'sharp_weights': {'@weights_kind': 'sharp'},
+    'sharp_split': dict(SPLIT_BODY, **SPLIT_WINDOW, **{'obj_lvis.iter': 12, '@weights_kind': 'sharp', '@skin_noise': 2.0}),
+})
 # the same for the ground-plane pass (render_ground :463-548 + blend_output_): names start with g_, the frame is frame_ground.npz's
 # (24 x 24, 10 x 10 window, two ground chunks) on the smooth body
 GROUND_BASE = {'vis_ground_shading': True, 'ground_normal': [0.0, -1.0, 0.0], 'ground_origin': [0.0, 0.45, 0.0], 'render_chunk_size': 384}
@@ -166,6 +184,7 @@ SWITCH_VARIANTS.update({
     'g_plain_ground': {'ground_attach_envmap': False, 'ground_albedo': [0.3, 0.2, 0.1], 'ground_shading_multiplier': 2.0},
     'g_env_r': {'env_r': 1.5},      # the light sphere's radius: the ground's distance fade (:497-505) and depth clip (:540) become active inside the frame
     'g_only_visibility': {'only_visibility': True},      # one-channel shade / spec maps of the ground blended against the human layer's (:516-519)
+    'g_split_body': dict(SPLIT_BODY),      # the horn's and the body's shadows on the ground, metres long under the low key light
     'g_env_lvis': {'env_lvis.iter': 8, 'env_lvis.offset': 0.02, 'env_lvis.dist_th': 0.01, 'env_lvis.bbox_margin': 0.3, 'env_lvis.near_offset': 0.03},
 })
 # and for the volume path (base_renderer.py:17,72,120-121): names start with v_, AniSDF network, an 8 x 8 window, 64 samples unless overridden
@@ -234,6 +253,7 @@ def main():
                                                    'relight_smooth', 'novel_ground', 'anisdf128', 'fields', 'fixmat', 'visual', 'switches', 'switch'])
     ap.add_argument('--variant', default='base')
     ap.add_argument('--out', default='')
+    ap.add_argument('--only', default='', help='--mode switches: regenerate only these variants (comma separated) inside the existing switches.npz')
     args = ap.parse_args()
     mode = args.mode
     if mode == 'switches':          # the reference binds cfg values as default arguments at import: one child process per variant
@@ -241,10 +261,17 @@ def main():
         import tempfile
         import json
         merged = dict(H=np.asarray(SWITCH_H), crop=np.asarray(SWITCH_CROP), ground_H=np.asarray(GROUND_H), ground_crop=np.asarray(GROUND_CROP),
-                      volume_H=np.asarray(VOLUME_H), volume_crop=np.asarray(VOLUME_CROP),
+                      volume_H=np.asarray(VOLUME_H), volume_crop=np.asarray(VOLUME_CROP), novel_H=np.asarray(NOVEL_H), novel_crop=np.asarray(NOVEL_CROP),
+                      novel_ground_H=np.asarray(NOVEL_GROUND_H), novel_headings=np.asarray(NOVEL_HEADINGS),
                       variants_json=np.asarray(json.dumps(SWITCH_VARIANTS)))
+        only = [n for n in args.only.split(',') if n]
+        if only:          # keep every other variant's arrays as they are in the committed file
+            with np.load(os.path.join(HERE, 'switches.npz')) as z:
+                for k in z.files:
+                    if k != 'variants_json' and k.split('.')[0] not in only:
+                        merged.setdefault(k, z[k])
         with tempfile.TemporaryDirectory() as tmp:
-            for name in SWITCH_VARIANTS:
+            for name in (only or SWITCH_VARIANTS):
                 out = os.path.join(tmp, name + '.npz')
                 subprocess.run([sys.executable, os.path.abspath(__file__), '--mode', 'switch', '--variant', name, '--out', out], check=True)
                 with np.load(out) as z:
@@ -439,7 +466,8 @@ def gen_switch(cfg, synthetic, variant, out_path):
         for q in parts[:-1]:
             node = node[q]
         node[parts[-1]] = v
-    sd = synthetic.make_state_dict(batch_kw.pop('weights_seed', 0), relight=True, cfg=my_cfg)
+    sd = synthetic.make_state_dict(batch_kw.pop('weights_seed', 0), relight=True, cfg=my_cfg, kind=batch_kw.pop('weights_kind', 'init'),
+                                   env=batch_kw.pop('env', 'back'))
     from lib.networks.relight.relight_network import Network
     from lib.networks.renderer import sphere_tracing_renderer
     net = Network()
@@ -454,7 +482,7 @@ def gen_switch(cfg, synthetic, variant, out_path):
     arrs = {k: out[k].detach().cpu().numpy() for k in SWITCH_KEYS if k in out}
     if variant.startswith('g_'):
         arrs['wbounds_after'] = batch.wbounds.numpy()
-    if variant in ('base', 'no_geodesic_filter'):
+    if variant in ('base', 'no_geodesic_filter', 'sharp_weights'):
         # the distance field itself on points all around the body (where the neighbour rule matters: between the arms and the trunk,
         # between the legs), the frame's window being a patch of the chest
         body = to_ref_batch(synthetic.make_body(0, posed=True, skin_noise=0.0))

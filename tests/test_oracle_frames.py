@@ -223,13 +223,27 @@ def switch_batch_kw(overrides):
     return {k[1:]: v for k, v in overrides.items() if k.startswith('@')}
 
 
+def switch_state_dict(bkw, cfg):
+    """the synthetic weights a variant asks for (removes @weights_seed / @weights_kind / @env from the make_batch arguments)"""
+    return synthetic.make_state_dict(bkw.pop('weights_seed', 0), relight=True, cfg=cfg, kind=bkw.pop('weights_kind', 'init'), env=bkw.pop('env', 'back'))
+
+
+def switch_batch(ref, bkw, ground=False):
+    H = int(ref['ground_H' if ground else 'H'])
+    return synthetic.make_batch(H, H, **{**dict(seed=0, posed=True, crop=int(ref['ground_crop' if ground else 'crop']), skin_noise=0.0), **bkw})
+
+
 SWITCH_NAMES = ['base', 'no_dfss', 'no_claybook', 'no_visibility', 'local_visibility', 'lambert_only', 'glossy_only', 'linear', 'only_visibility',
                 'vis_lvis_map', 'vis_ldot_map', 'chromatic', 'material_params', 'trace_params', 'no_specular_vis', 'no_geodesic_filter', 'maps_only',
                 'one_sample', 'five_samples', 'small_probe', 'odd_probe', 'one_shadow_iter', 'smpl24', 'other_weights', 'all_shadowed', 'env_r']
 
 
+# round 6, the hard cases: a body part that shadows another at distance (12 shadow iterations; the default 4 for comparison), trained-like
+# weights with live high-frequency encoding columns, both on the noisy skinning field (tests/golden/make_golden.py: SPLIT_BODY, SHARP_BANDS)
+HARD_SWITCH_NAMES = ['split_body', 'split_body_iter4', 'sharp_weights', 'sharp_split']
+
 GROUND_SWITCH_NAMES = ['g_base', 'g_no_dfss', 'g_vis_lvis_map', 'g_vis_ldot_map', 'g_linear', 'g_local_visibility', 'g_plain_ground', 'g_env_lvis',
-                       'g_only_visibility', 'g_env_r']
+                       'g_only_visibility', 'g_env_r', 'g_split_body']
 
 
 @pytest.mark.parametrize('name', GROUND_SWITCH_NAMES)
@@ -237,9 +251,9 @@ def test_ground_switch_matrix(golden, name):
     """the same switches through the ground-plane pass (render_ground :463-548, blend_output_): frame_ground.npz's frame on the smooth body"""
     ref = golden('switches.npz')
     cfg = switch_cfg(switch_variants(ref)[name])
-    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg), cfg)
-    H = int(ref['ground_H'])
-    batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['ground_crop']), skin_noise=0.0)
+    bkw = switch_batch_kw(switch_variants(ref)[name])
+    net = O.OracleNet(switch_state_dict(bkw, cfg), cfg)
+    batch = switch_batch(ref, bkw, ground=True)
     m = batch.mask_at_box.reshape(1, -1)
     inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]      # the order the (CPU) reference run scattered with
     out = O.render_sphere_tracing(net, batch, ground_inds=inds)
@@ -248,8 +262,9 @@ def test_ground_switch_matrix(golden, name):
     _cmp(out, sub, 'acc_map', 5e-3)
     _cmp(out, sub, 'albedo_map', 2e-4)
     tol = 1e-3 if name == 'g_no_dfss' else 3e-4      # hard shadows: visibility = clip(500 d / t), fp32 re-association x 500
-    _cmp(out, sub, 'rgb_map', tol, frac_ok=0.999)
-    _cmp(out, sub, 'shade_map', tol, frac_ok=0.999)
+    frac = 0.998 if name == 'g_split_body' else 0.999      # one ground pixel of 576 at the horn's shadow edge: 8.3e-4
+    _cmp(out, sub, 'rgb_map', tol, frac_ok=frac)
+    _cmp(out, sub, 'shade_map', tol, frac_ok=frac)
     _cmp(out, sub, 'spec_map', 5e-4, frac_ok=0.999)
     assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > 60
 
@@ -325,11 +340,11 @@ def test_volume_switch_matrix(golden, name):
 def test_switch_matrix(golden, name):
     ref = golden('switches.npz')
     variants = switch_variants(ref)
-    assert sorted(variants) == sorted(SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES)
+    assert sorted(variants) == sorted(SWITCH_NAMES + HARD_SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES)
     cfg = switch_cfg(variants[name])
     bkw = switch_batch_kw(variants[name])
-    net = O.OracleNet(synthetic.make_state_dict(bkw.pop('weights_seed', 0), relight=True, cfg=cfg), cfg)
-    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), **{**dict(seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), **bkw})
+    net = O.OracleNet(switch_state_dict(bkw, cfg), cfg)
+    batch = switch_batch(ref, bkw)
     out = O.render_sphere_tracing(net, batch)
     sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
     for k in ('rgb_map', 'shade_map', 'spec_map'):      # maps_only: render_human's early return leaves none of them
@@ -353,3 +368,40 @@ def test_switch_matrix(golden, name):
         base = {k[5:]: v for k, v in ref.items() if k.startswith('base.')}
         differs = any(sub[k].shape != base[k].shape or not np.array_equal(sub[k], base[k]) for k in sub if k in base) or set(sub) != set(base)
         assert differs, name
+
+
+@pytest.mark.parametrize('name', HARD_SWITCH_NAMES)
+def test_hard_case_switch_matrix(golden, name):
+    """the reference's own hard cases (sphere_tracing_renderer.py:157-179 the penumbra estimate at distance, :265-344 light visibility of one
+    body part on another; net_utils.py:1303-1352 an SDF net that uses its encoding columns; sample_utils.py:103-162 the neighbour rule
+    where parts come close).  On the noisy skinning field (sharp_split) single rays carry fp32 re-association noise of 1e-3 in rgb / 2e-2
+    in the normal (the reference's trace ends in limit cycles there): fraction bounds, and PSNR > 75 dB."""
+    ref = golden('switches.npz')
+    variants = switch_variants(ref)
+    cfg = switch_cfg(variants[name])
+    bkw = switch_batch_kw(variants[name])
+    net = O.OracleNet(switch_state_dict(bkw, cfg), cfg)
+    batch = switch_batch(ref, bkw)
+    out = O.render_sphere_tracing(net, batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    noisy = name == 'sharp_split'
+    assert bool(((out.acc_map > 0) == (T(sub['acc_map']) > 0)).all())
+    for k in ('surf_map', 'albedo_map', 'roughness_map'):
+        _cmp(out, sub, k, 3e-4 if noisy else 1e-4)
+    _cmp(out, sub, 'norm_map', 2e-3, frac_ok=0.98 if noisy else 1.0)      # sharp_split: 2 of 144 rays (6 elements), max 2.1e-2
+    _cmp(out, sub, 'rgb_map', 3e-4, frac_ok=0.99 if noisy else 1.0)
+    _cmp(out, sub, 'shade_map', 3e-4)
+    _cmp(out, sub, 'spec_map', 1e-3)
+    assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > (75 if noisy else 100)
+    if name + '.hdq_x' in ref:       # sharp_weights: the distance field all around the body
+        fr = O._frame(synthetic.make_body(0, posed=True, skin_noise=0.0))
+        parts = O.hdq_sdf(net, T(ref[name + '.hdq_x']), fr, cfg.dist_th, True, return_parts=True)
+        np.testing.assert_allclose(parts.sdf.numpy(), ref[name + '.hdq_sdf'], atol=2e-5)
+        base = ref['base.hdq_sdf']
+        assert float(np.abs(ref[name + '.hdq_sdf'] - base).max()) > 0.05      # another field than the near-initialisation one
+    # the cases are what they claim to be: the window holds umbra, penumbra and lit pixels / the weights change the frame
+    if name.startswith('split_body'):      # (sharp_split's sharper surface leaves the same window mostly in the umbra)
+        sh = sub['shade_map'][0].mean(-1)[sub['acc_map'][0] > 0]
+        assert (sh < 0.02 * sh.max()).mean() > 0.1 and (sh > 0.5 * sh.max()).mean() > 0.05 and ((sh > 0.1 * sh.max()) & (sh < 0.5 * sh.max())).mean() > 0.1, name
+    if name == 'split_body':         # ... and the long shadow rays matter: the default 4 iterations give another frame
+        assert float(np.abs(sub['shade_map'] - ref['split_body_iter4.shade_map']).max()) > 0.05
