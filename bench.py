@@ -48,16 +48,20 @@ def cam_dist_of(coverage):
 N_SAMPLE = 3072
 
 
+BODY_KW = {}          # --body split: synthetic.SPLIT_BODY_KW (a body part that shadows the body at distance)
+WEIGHTS_KW = {}       # --weights sharp / --body split: make_state_dict(kind=, env=)
+
+
 def sample_batch(H, skin_noise, n_target, cam_dist=2.0):
     """the bounded sample of the benchmarked frame: every stride-th of its in-box rays (rays are independent: one render chunk)."""
-    return synthetic.sample_rays(synthetic.make_batch(H, H, seed=0, posed=True, skin_noise=skin_noise, cam_dist=cam_dist), n_target)
+    return synthetic.sample_rays(synthetic.make_batch(H, H, seed=0, posed=True, skin_noise=skin_noise, cam_dist=cam_dist, **BODY_KW), n_target)
 
 
 def fp32_unstable(net, batch, H, skin_noise, cam_dist, n_target):
     """rays of the sample whose traced surface the reference's own fp32 arithmetic does not pin (oracle.fp32_unstable_rays, tools/fp32_stability.py).
     The default samples' lists are committed (tests/golden/fp32_unstable_rays.json, 32 trials); any other sample is classified here with 8."""
     from oracle import ra_oracle as O
-    case = {2.0: 'bench_sample_3072', 0.0: 'bench_sample_smooth_3072'}.get(float(skin_noise)) if (H == 512 and cam_dist == 2.0 and n_target == N_SAMPLE) else None
+    case = {2.0: 'bench_sample_3072', 0.0: 'bench_sample_smooth_3072'}.get(float(skin_noise)) if (H == 512 and cam_dist == 2.0 and n_target == N_SAMPLE and not BODY_KW and not WEIGHTS_KW) else None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'fp32_unstable_rays.json')
     n = batch.ray_o.shape[1]
     if case and os.path.exists(path):
@@ -76,7 +80,7 @@ def cpu_baseline(cfg, H, skin_noise, n_target=N_SAMPLE, threads=16, cam_dist=2.0
     torch.set_num_threads(min(os.cpu_count() or 1, threads))   # more threads than this only add sync overhead here
     batch, P, stride = sample_batch(H, skin_noise, n_target, cam_dist)
     n = batch.ray_o.shape[1]
-    net = O.OracleNet(synthetic.make_state_dict(0, relight=bool(cfg.relighting), cfg=cfg), cfg)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=bool(cfg.relighting), cfg=cfg, **WEIGHTS_KW), cfg)
     t0 = time.perf_counter()
     if cfg.renderer_module.endswith('base_renderer'):
         ref = O.render_volume(net, batch)
@@ -119,6 +123,11 @@ def psnr_vs_oracle(renderer, ref, H, skin_noise, dev, n_target=N_SAMPLE, cam_dis
                        'tools/fp32_stability.py, DESIGN.md section 2).  The surface trace runs in compensated arithmetic (config.trace_precision 1).'}
     res['contract_met'] = bool(res['rgb_fp32_stable'] >= 50.0 and res['max_abs_fp32_stable'] <= 1e-2)
     res['contract_met_all_rays'] = bool(res['rgb'] >= 50.0 and res['max_abs'] <= 1e-2)
+    # which arithmetic produced these figures: cfg.trace_precision 0 = plain 16-bit operands everywhere, 1 = the surface trace compensated
+    # (the shipped default), 2 = every distance query compensated (the tier that meets max <= 1e-2 on EVERY pixel of the full frame and
+    # on the hard cases, at 2 x the frame time: tests/test_gpu_parity.py test_full_frame_shadow_tier_is_harmless, test_hard_case_switch_matrix)
+    tp = int(renderer.cfg.get('trace_precision', 1))
+    res['contract_tier'] = {'trace_precision': tp, 'name': {0: 'plain f16 operands', 1: 'surface trace compensated, shadow rays plain f16', 2: 'all distance queries compensated'}[tp]}
     # every sampled ray over 1e-2, by name: its error, whether fp32 itself pins it, and (committed samples) how often the reference's own
     # arithmetic flips it at fp32's noise level (tests/golden/fp32_unstable_rays.json: a coin toss of the reference is not an error of this path)
     over = [int(i) for i in (per_ray > 1e-2).nonzero()[:, 0][:16]]
@@ -285,6 +294,8 @@ def main():
     ap.add_argument('--emulate-world', type=int, default=0, help='tuning aid: render only rank 0\'s shard of an N-rank job on one GPU (no collective); value is then NOT a whole-job rate')
     ap.add_argument('--emulate-rank', type=int, default=0, help='with --emulate-world: which rank\'s shard to render (load balance of the tile deal)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL on ROCm; gloo only with --dry')
+    ap.add_argument('--share-gpu', action='store_true', help='with --backend gloo: the REAL rank program (HIP engine, shard plan, frames in flight) as N processes that all render on GPU 0, the frame gather staged through pinned host memory over gloo (RCCL refuses two ranks on one device): the multi-process test of the N > 1 path on a 1-GPU box; not a performance mode')
+    ap.add_argument('--dump-frame', default='', help='rank 0 writes the last timed frame (the gathered maps, channels concatenated) to this .npy file')
     ap.add_argument('--dry', action='store_true', help='no HIP engine: launcher + process-group plumbing on CPU tensors (CPU test of the N > 1 path)')
     ap.add_argument('--static-frame', action='store_true', help='A/B: do not re-pose the body every step (round-1 behaviour: per-frame set-up outside the timed region)')
     ap.add_argument('--k4-batch', type=int, default=0, help='cfg.k4_batch_slots: full queries per forward+backward launch pair (0 = library default)')
@@ -294,6 +305,9 @@ def main():
     ap.add_argument('--coverage', type=float, default=0.0, help='fraction of the frame the body covers: moves the camera in (0 = SURVEY.md 8d camera at 2 m, ~8 %% hit pixels; 0.35 = a frame-filling subject, camera at 0.96 m)')
     ap.add_argument('--no-sequential', action='store_true', help='skip the strictly sequential leg (ms_per_step_sequential: one frame at a time, host sync after each, as the reference loop run.py:43-49)')
     ap.add_argument('--trace-precision', type=int, default=1, choices=[0, 1, 2], help='cfg.trace_precision: 1 = the surface trace in compensated arithmetic (default), 0 = plain 16-bit operands everywhere (round 3), 2 = compensated everywhere')
+    ap.add_argument('--body', default='blob', choices=['blob', 'split'], help='split: the hard-case body of tests/golden/switches.npz `split_body` (synthetic.SPLIT_BODY_KW: a horn pulled 0.57 m out of the body, shadowing it at distance) under the front key light, 12 shadow iterations unless --shadow-iters says otherwise')
+    ap.add_argument('--weights', default='init', choices=['init', 'sharp'], help='sharp: trained-like synthetic weights (synthetic.SHARP_BANDS: live high-frequency encoding columns, cm-scale surface detail)')
+    ap.add_argument('--shadow-iters', type=int, default=0, help='cfg.obj_lvis.iter (0 = the reference default 4; --body split: 12)')
     ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 
@@ -310,17 +324,24 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29577')
             os.environ.update(RANK='0', WORLD_SIZE='1')
         return dry_rank(args, rank, world)
-    if args.backend != 'nccl':
-        raise SystemExit('bench.py: the render path runs on MI355X GPUs over RCCL (backend nccl); gloo is for --dry')
+    if args.backend != 'nccl' and not args.share_gpu:
+        raise SystemExit('bench.py: the render path runs on MI355X GPUs over RCCL (backend nccl); gloo is for --dry and --share-gpu')
+    if args.share_gpu and args.backend != 'gloo':
+        raise SystemExit('bench.py --share-gpu: N ranks on one device need --backend gloo (RCCL refuses two ranks on a device)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs MI355X GPUs (the render path has no CPU fallback)')
+    local = 0 if args.share_gpu else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_dist = world > 1 or 'RANK' in os.environ       # under torchrun the RCCL path runs even at world size 1
+    sdev = torch.device('cpu') if args.share_gpu else dev          # where the job's statistics are reduced (gloo moves host tensors)
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     H = args.size
     kw = dict(vis_ground_shading=True, ground_normal=[0.0, -1.0, 0.0], ground_origin=[0.0, 0.45, 0.0]) if args.ground else {}
@@ -330,14 +351,22 @@ def main():
         kw['novel_light_timing'] = False     # nobody reads `diff` here: no host sync inside the frame
     kw['trace_precision'] = args.trace_precision
     cfg = make_cfg(args.mode, mlp_dtype=args.dtype, **kw)
+    if args.body == 'split':
+        BODY_KW.update(synthetic.SPLIT_BODY_KW)
+        WEIGHTS_KW['env'] = 'front'
+    if args.weights != 'init':
+        WEIGHTS_KW['kind'] = args.weights
+    shadow_iters = args.shadow_iters or (12 if args.body == 'split' else 0)
+    if shadow_iters and 'obj_lvis' in cfg:
+        cfg.obj_lvis.iter = shadow_iters
     relight = args.mode in ('relight', 'novel_light')
     D = max(1, args.frames_in_flight)
-    pipe = FramePipeline(cfg, synthetic.make_state_dict(0, relight=relight, cfg=cfg), dev, depth=D)
+    pipe = FramePipeline(cfg, synthetic.make_state_dict(0, relight=relight, cfg=cfg, **WEIGHTS_KW), dev, depth=D)
     net, renderer = pipe.networks[0], pipe.renderers[0]
     # one batch per replica: a frame in flight owns its body state and its in-place grown box until it has been consumed
     cam_dist = cam_dist_of(args.coverage)
     bases = [synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, n_novel_lights=args.probes if args.mode == 'novel_light' else 0,
-                                                      skin_noise=args.skin_noise, cam_dist=cam_dist), dev) for _ in range(D)]
+                                                      skin_noise=args.skin_noise, cam_dist=cam_dist, **BODY_KW), dev) for _ in range(D)]
     base = bases[0]
     P = base.ray_o.shape[1]
     wb0 = base.wbounds.clone()
@@ -449,7 +478,7 @@ def main():
         for _ in range(3):
             step()
         sync()
-        ns = torch.tensor([max(0, int(args.soak / max((time.perf_counter() - t_probe) / 3, 1e-4)))], device=dev)
+        ns = torch.tensor([max(0, int(args.soak / max((time.perf_counter() - t_probe) / 3, 1e-4)))], device=sdev)
         if use_dist:
             dist.broadcast(ns, 0)
         n_soak = int(ns.item())
@@ -475,6 +504,12 @@ def main():
     t_wait = anim.wait if anim is not None else 0.0
     for e in engs:
         e.enable_timing(False)
+    if args.dump_frame and rank == 0:          # the last timed frame as the job assembled it (the multi-process test compares it bit for bit)
+        import numpy as np
+        v = out.result()
+        v = v if isinstance(v, torch.Tensor) else torch.cat([v[k] if v[k].ndim == 3 else v[k][..., None] for k in ('rgb_map', 'acc_map')], dim=-1)
+        torch.cuda.synchronize(dev)
+        np.save(args.dump_frame, v.float().cpu().numpy())
     # the strictly sequential loop beside it: one frame at a time, the host waits for each (the reference's loop, run.py:43-49) — this is
     # also a frame's first-to-last-launch latency.  Counters / kernel timers are off: the roofline figures are the timed region's.
     dt_seq = None
@@ -506,7 +541,7 @@ def main():
         sync()
         dt_static = (time.perf_counter() - t2) / args.steps
     my_ms = dt / args.steps * 1e3
-    tt = torch.tensor([dt, dt_seq or 0.0], device=dev, dtype=torch.float64)
+    tt = torch.tensor([dt, dt_seq or 0.0], device=sdev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, dt_seq = float(tt[0].item()), (float(tt[1].item()) if dt_seq is not None else None)
@@ -524,10 +559,10 @@ def main():
     for e in engs:
         ms_e, n_e = e.kernel_time(kind)
         mlp_ms, mlp_launches = mlp_ms + ms_e, mlp_launches + n_e
-    cnts = torch.tensor([cnt.n_fine_sdf, cnt.n_fine_full, cnt.n_coarse, cnt.n_hit_pixels, cnt.n_shadow_rays], device=dev, dtype=torch.float64)
+    cnts = torch.tensor([cnt.n_fine_sdf, cnt.n_fine_full, cnt.n_coarse, cnt.n_hit_pixels, cnt.n_shadow_rays], device=sdev, dtype=torch.float64)
     # what makes the driver's SCALE record checkable: how many ranks really took part, and every rank's own time and share of the work
-    seen = torch.ones(1, device=dev, dtype=torch.float64)
-    mine = torch.tensor([my_ms, cnt.n_hit_pixels / max(args.steps, 1), cnt.n_fine_sdf / max(args.steps, 1)], device=dev, dtype=torch.float64)
+    seen = torch.ones(1, device=sdev, dtype=torch.float64)
+    mine = torch.tensor([my_ms, cnt.n_hit_pixels / max(args.steps, 1), cnt.n_fine_sdf / max(args.steps, 1)], device=sdev, dtype=torch.float64)
     per_rank = [mine.clone() for _ in range(world)]
     if use_dist:
         dist.all_reduce(cnts)
@@ -558,7 +593,8 @@ def main():
                        'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
                        'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'full_queries_per_frame': int(cnts[1].item() / args.steps),
                        'coarse_queries_per_frame': int(cnts[2].item() / args.steps),
-                       'shadow_rays_per_frame': int(cnts[4].item() / args.steps), 'parallelism': f'8x8 pixel tiles dealt over {world} GPU(s) + one all_gather'},
+                       'shadow_rays_per_frame': int(cnts[4].item() / args.steps),
+                       'parallelism': f'8x8 pixel tiles dealt over {world} ' + ('rank processes SHARING GPU 0 (multi-process test mode, not a rate)' if args.share_gpu else 'GPU(s)') + ' + one all_gather'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': 'offline' if traffic is not None else None,
                          'traffic_unit': f'B/launch; NOT measured in this run: rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), profiles/{traffic_src}',
@@ -575,7 +611,7 @@ def main():
             pl0 = shard.make_plan(P, world, base, dev, mask=mask_host, ground=args.ground, render_chunk_size=cfg.render_chunk_size, use_cache=False)
             g0 = pl0.ground if args.ground else pl0
             total = g0.F if args.ground else P
-            line['gather'] = {'collective': 'all_gather_into_tensor (RCCL), one per frame, shards padded to the largest',
+            line['gather'] = {'collective': f'all_gather_into_tensor ({"gloo, staged through pinned host memory: N ranks on ONE GPU" if args.share_gpu else "RCCL"}), one per frame, shards padded to the largest',
                               'bytes_received_per_rank': int(world * g0.n_max * C_g * 4), 'channels': C_g,
                               'pad_fraction': round((world * g0.n_max - total) / max(total, 1), 5)}
         line['hit_pixels_per_sec'] = cnts[3].item() / dt          # the 84 % of rays that miss the box cost nothing: rays/s flatters
@@ -586,6 +622,7 @@ def main():
         line['config']['frames_in_flight'] = D
         line['config']['camera_distance_m'] = round(cam_dist, 4)
         line['config']['trace_precision'] = args.trace_precision
+        line['config']['body'], line['config']['weights'], line['config']['shadow_iters'] = args.body, args.weights, int(cfg.obj_lvis.iter) if 'obj_lvis' in cfg else None
         line['config']['fine_queries_compensated_per_frame'] = int(cnt.get('n_fine_sdf_comp', 0) / args.steps)
         if args.emulate_world > 1:
             line['config']['emulate_world'], line['config']['emulate_rank'] = args.emulate_world, args.emulate_rank

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RA_ABI_VERSION 7
+#define RA_ABI_VERSION 8
 #define RA_N_LIGHTS_MAX 512 /* env_h * env_w = 16 * 32 (lib/config/config.py:111-112) */
 
 typedef struct ra_ctx ra_ctx;
@@ -81,10 +81,18 @@ typedef struct ra_config {
                                                  signed distances, neighbours farther than dist_th from the closest one ON THE CANONICAL BODY
                                                  replaced by it; 0: knn_with_filter (:164-194) — distance sqrt(mean d^2) with the sign of
                                                  max_k sign((x - v_k) . n_k), the three neighbours as found */
+    float key_light_share;                    /* 4.0 (default); with trace_precision 1: the light-visibility rays towards the frame's KEY LIGHTS are
+                                                 traced in compensated arithmetic like the surface trace.  A light is a key light when its share of
+                                                 the probe's power (radiance x solid angle) is at least key_light_share x the mean share 1 / L (at most
+                                                 64 per probe).  A DFSS penumbra value is d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): it
+                                                 amplifies the 5e-5 distance error of plain f16 operands up to 500 x per light.  Summed over 512 lights
+                                                 of comparable power the errors average out; under a key light that holds most of the power they do
+                                                 not (the reference-made hard cases of tests/golden/switches.npz: max |err| 1.2e-2 .. 4.4e-2).  The
+                                                 key lights are 2-3 % of the lights.  0: no key-light tier (round 5's behaviour) */
 } ra_config;
 /* A zero-initialised ra_config is NOT the default configuration (trace_precision 0 = plain operands, clip_far 0, ...): start from
  * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2,
- * clip_far <= clip_near (or NaN) and vis_shade_map outside 0..2. */
+ * clip_far <= clip_near (or NaN), vis_shade_map outside 0..2 and a negative key_light_share. */
 int ra_default_config(ra_config* out);
 int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
 
@@ -96,6 +104,10 @@ int ra_set_config(ra_ctx* ctx, const ra_config* cfg);
  * (lib/utils/net_utils.py:1514-1584). */
 int ra_set_weight(ra_ctx* ctx, const char* name, const float* host_data, size_t numel);
 int ra_finalize_weights(ra_ctx* ctx, void* stream);
+/* 1 when the cooperative 4-wave distance kernel for launches of <= 8 Ki points (K3CC, csrc/ra_k3cc.hpp) passed its self-test against the
+ * plain compensated kernel on this device at ra_finalize_weights (bit for bit; tested once per process and device) and is in use; 0: the
+ * context launches K3C's 4-wave tiles instead (slower small launches, same results) — or has no weights yet. */
+int ra_k3cc_enabled(const ra_ctx* ctx);
 
 /* ---- per-frame SMPL state: the batch keys world_to_bigpose consumes
  * (lib/networks/deform/base_network.py:238-336; schema lib/datasets/base_dataset.py:337-397).
@@ -216,6 +228,13 @@ int ra_render_sphere_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, 
                            const float* far_, int P, const float* bbox_host6,
                            const float* probe_dev, int probe_h, int probe_w,
                            const ra_sphere_params* p, const ra_render_out* out, void* stream);
+
+/* The key lights of the current frame (ra_config.key_light_share), named by the caller: n probes of probe_h x probe_w x 3 (device) — every
+ * probe the frame's cached visibility will be shaded with.  ra_render_sphere_chunk / ra_render_ground_chunk derive the key lights from the
+ * probe they shade with; a renderer that traces once and re-shades under OTHER probes afterwards (novel_light_sphere_tracing.py:163-213:
+ * ra_reshade, ra_reshade_ground) calls this before the frame's render calls, once per probe size (accumulate = 1 adds to the flags of the
+ * call before), and with n = 0 after them (back to per-call key lights).  No counterpart in the reference, whose arithmetic is fp32 throughout. */
+int ra_set_key_probes(ra_ctx* ctx, const float* probes_dev, int n, int probe_h, int probe_w, int accumulate, void* stream);
 
 /* base_renderer.Renderer.get_pixel_value (base_renderer.py:53-113): uniform samples,
  * Network.forward per sample, alpha compositing.  near / far as the dataset delivers them: the renderer's clip

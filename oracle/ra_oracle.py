@@ -331,9 +331,14 @@ class OracleNet:
         # fp32 arithmetic than the reference's BLAS sums: what it changes in a frame is what fp32 itself cannot pin (tools/precision_tiers.py).
         # 'f16x2': operands as f16 hi + lo pairs, three products hi*hi + lo*hi + hi*lo, fp32 accumulate — the compensated tier of
         # the HIP kernels (K3C / K4C).
+        # 'f16w2' / 'f16a2': only ONE operand side as a hi + lo pair (two products per k-step): the weights (a constant, systematic
+        # perturbation of the field when rounded) resp. the activations (rounding noise that is white from ray to ray) — which half of
+        # the plain-f16 error reaches the pixels (tools/precision_tiers.py)
         self.f64acc = emulate == 'f64acc'
         self.split = emulate == 'f16x2'
-        self.emulate = {None: None, 'f32': None, 'f64acc': None, 'f16': torch.float16, 'bf16': torch.bfloat16, 'f16x2': torch.float16}[emulate]
+        self.half_split = {'f16w2': 'w', 'f16a2': 'a'}.get(emulate)
+        self.emulate = {None: None, 'f32': None, 'f64acc': None, 'f16': torch.float16, 'bf16': torch.bfloat16, 'f16x2': torch.float16,
+                        'f16w2': torch.float16, 'f16a2': torch.float16}[emulate]
         self.kernel_like = bool(kernel_like) and self.emulate is not None
         self.shadow_net = None           # tiered precision: another OracleNet (same weights) that answers the light-visibility queries
         f = lambda k: sd[k].detach().float().clone()
@@ -407,6 +412,10 @@ class OracleNet:
         if self.kernel_like and scaled_w_cols is not None:
             wq = wq.clone()
             wq[:, scaled_w_cols] = self._q(w[:, scaled_w_cols] * S) / S
+        if self.half_split == 'w':          # weights as hi + lo: rounded twice (22 bits)
+            wq = wq + self._q(w - wq)
+        elif self.half_split == 'a':        # activations as hi + lo
+            xq = xq + self._q(x - xq)
         if self.kernel_like and hilo_cols is not None:
             xq = xq.clone()
             xq[..., hilo_cols] = xq[..., hilo_cols] + self._q(x[..., hilo_cols] - xq[..., hilo_cols])
@@ -730,6 +739,18 @@ def fp32_flip_probability(net: OracleNet, batch, rays, noise: float, trials: int
     return [float(v) / trials for v in flips.reshape(-1)]
 
 
+def key_lights(net: OracleNet, probes, share: float):
+    """the lights whose share of a probe's power (radiance x solid angle, channel mean) is at least `share` times the mean share 1 / L,
+    under any of `probes` (each (H, W, 3)): the rule of the key-light tier (csrc/ra_api.cpp key_light_mask)"""
+    d = normalize(net.light_xyz.reshape(-1, 3))
+    area = net.light_area.reshape(-1)
+    key = torch.zeros(d.shape[0], dtype=torch.bool)
+    for pr in probes:
+        w = sample_envmap_image(pr, d).mean(-1) * area
+        key |= w * d.shape[0] >= share * w.sum()
+    return key
+
+
 def light_visibility(net: OracleNet, surf, norm, acc, fr, bbox, lvis_cfg, sdf_fn_factory):
     """light_visibility sphere_tracing_renderer.py:265-344. surf,norm (P,3), acc (P) -> lvis, ldot (L,P)."""
     c = net.cfg
@@ -858,6 +879,10 @@ def render_human(net: OracleNet, ray_o, ray_d, near, far, probe, fr, bbox):
         snet = net.shadow_net or net                                   # tiered precision (tools/precision_tiers.py)
         lvis, ldot = light_visibility(net, surf, norm, acc, fr, bbox, c.obj_lvis,
                                       lambda th: (lambda x: hdq_sdf(snet, x, fr, th, True)))
+        key = getattr(net, 'key_lights', None)                         # emulation of cfg.trace_precision's key-light tier: the rays towards
+        if key is not None and snet is not net and bool(key.any()):    # the lights that carry the probe's power are traced by `net` itself
+            lvis_k, _ = light_visibility(net, surf, norm, acc, fr, bbox, c.obj_lvis, lambda th: (lambda x: hdq_sdf(net, x, fr, th, True)))
+            lvis = torch.where(key.reshape(-1, 1), lvis_k, lvis)
         rgb, shade, spec = shade_pixels(net, probe, ro, surf, norm, albedo, rough, lvis, ldot, want_spec=c.vis_specular_map)
         ret.rgb_map, ret.shade_map = rgb, shade
         if spec is not None:

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RA_LIB_PATH') or os.path.join(_HERE, 'librelightableavatar_hip.so')    # override: kernel experiments (tools/)
 _lib = None
-ABI_VERSION = 7          # RA_ABI_VERSION of include/relightableavatar.h
+ABI_VERSION = 8          # RA_ABI_VERSION of include/relightableavatar.h
 
 
 class RaError(RuntimeError):
@@ -24,7 +24,7 @@ class ra_config(C.Structure):
                 ('shading_albedo', C.c_float), ('albedo_multiplier', C.c_float), ('lambert_only', C.c_int),
                 ('glossy_only', C.c_int), ('tonemapping', C.c_int), ('bg_brightness', C.c_float), ('mlp_f16', C.c_int), ('query_skip', C.c_int),
                 ('k4_batch_slots', C.c_int), ('trace_precision', C.c_int), ('clip_near', C.c_float), ('clip_far', C.c_float),
-                ('only_visibility', C.c_int), ('vis_shade_map', C.c_int), ('use_geodesic_filter', C.c_int)]
+                ('only_visibility', C.c_int), ('vis_shade_map', C.c_int), ('use_geodesic_filter', C.c_int), ('key_light_share', C.c_float)]
 
 
 class ra_frame(C.Structure):
@@ -114,6 +114,8 @@ SYMBOLS = {
                                          C.POINTER(ra_ground_params), C.POINTER(ra_ground_out), C.c_void_p]),
     'ra_blend_ground': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'ra_reshade': (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    'ra_k3cc_enabled': (C.c_int, [C.c_void_p]),
+    'ra_set_key_probes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'ra_reshade_ground': (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] +
                           [C.c_void_p] * 5),
     'ra_get_counters': (C.c_int, [C.c_void_p, C.POINTER(ra_counters), C.c_void_p]),

@@ -3,6 +3,8 @@
 // (fine points, hit pixels, shadow rays) stay on the device and kernels size themselves from them.
 #include "ra_ctx.hpp"
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include <cstring>
@@ -106,6 +108,7 @@ int ra_default_config(ra_config* o) {
     o->tonemapping = 1; o->bg_brightness = 0.f; o->mlp_f16 = 1; o->query_skip = 1; o->k4_batch_slots = 0;
     o->trace_precision = 1; o->clip_near = 0.02f; o->clip_far = 10.f;
     o->only_visibility = 0; o->vis_shade_map = 0; o->use_geodesic_filter = 1;
+    o->key_light_share = 4.f;
     return 0;
 }
 
@@ -115,6 +118,7 @@ int ra_set_config(ra_ctx* c, const ra_config* cfg) {
     RA_CHECK(cfg->trace_precision >= 0 && cfg->trace_precision <= 2, "ra_set_config: trace_precision must be 0, 1 or 2 (a zero-initialised ra_config is not the default: ra_default_config)");
     RA_CHECK(cfg->clip_far > cfg->clip_near, "ra_set_config: clip_far must exceed clip_near (a zero-initialised ra_config is not the default: ra_default_config)");
     RA_CHECK(cfg->vis_shade_map >= 0 && cfg->vis_shade_map <= 2, "ra_set_config: vis_shade_map must be 0, 1 or 2");
+    RA_CHECK(cfg->key_light_share >= 0.f, "ra_set_config: key_light_share must be >= 0 (0 = no key-light tier)");
     c->cfg = *cfg;
     c->have_cfg = true;
     return 0;
@@ -137,7 +141,15 @@ static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
 // AGPR of its own in that kernel — checked on the shipped object's assembly at build time (csrc/Makefile, tools/check_k3cc_isa.py) and
 // HERE, on the device: a few hundred points through K3CC and through K3C's 4-wave tiles (the same arithmetic, weights through LDS) must
 // agree bit for bit.  On a mismatch the context never launches K3CC (launch_mlp_sdf_comp allow_coop = false) and says so once on stderr.
+// The answer is a property of the kernel's code on this device, not of the weights: one test per process and device.
+static std::mutex k3cc_mu;
+static std::map<int, bool> k3cc_result;
 static int k3cc_self_test(ra_ctx* c, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(k3cc_mu);
+        auto it = k3cc_result.find(c->device);
+        if (it != k3cc_result.end()) { c->k3cc_ok = it->second; return 0; }
+    }
     constexpr int N = 400;                    // 25 tiles of 16 points, the last tile of K3C's 64-point tiles partly filled
     std::vector<float> x(3 * N);
     unsigned u = 12345u;
@@ -169,9 +181,13 @@ static int k3cc_self_test(ra_ctx* c, hipStream_t s) {
     RA_HIP(hipGetLastError());
     c->k3cc_ok = a == b;
     if (!c->k3cc_ok)
-        fprintf(stderr, "relightableavatar: K3CC self-test failed (its distances differ from K3C's): the cooperative small-launch kernel is disabled for this context\n");
+        fprintf(stderr, "relightableavatar: K3CC self-test failed (its distances differ from K3C's): the cooperative small-launch kernel is disabled on device %d (ra_k3cc_enabled)\n", c->device);
+    std::lock_guard<std::mutex> lk(k3cc_mu);
+    k3cc_result[c->device] = c->k3cc_ok;
     return 0;
 }
+
+int ra_k3cc_enabled(const ra_ctx* c) { return c && c->have_weights && c->k3cc_ok ? 1 : 0; }
 
 int ra_finalize_weights(ra_ctx* c, void* stream) {
     RA_CHECK(c && c->have_cfg, "ra_finalize_weights: call ra_set_config first");
@@ -273,7 +289,7 @@ struct Timer {
 
 DevCounters* dcnt(ra_ctx* c) { return c->dcounters.as<DevCounters>(); }
 int* icnt(ra_ctx* c, int k) { return reinterpret_cast<int*>(c->dcounters.as<char>() + 128) + k; }   // small int counters
-enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
+enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_KRAYS = 4, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
 
 // Every hierarchical-distance pass compacts its fine points through a device counter that must start at zero.  Instead of one
 // 4-byte memset launch per pass (21 per relit chunk), the counters are a set that ONE memset zeroes per chunk; each pass takes
@@ -332,20 +348,39 @@ int fine_hint(const ra_ctx* c, int k) {
     return (h && !c->fc_wrapped && k < h->n_valid) ? h->vals[k] : -1;
 }
 // the size the variant choice of a fused MLP launch sees: the bound, or — with a hint — a quarter more than the earlier count
+// A hint comes from an EARLIER frame: after a camera cut the count can be many times larger.  Every variant is correct for every count
+// (persistent over tiles), but a narrow variant on a grid sized for the hint would be a cliff: the hint picks the workgroup WIDTH only.
 int variant_size(int n, int hint) {
     if (hint < 0) return n;
     const long long v = (long long)hint + hint / 4 + 1024;
     return v < n ? (int)v : n;
 }
+// ... and the size its grid is made for (mlp_grid, ra_common.hpp): never below an eighth of the bound, whatever the hint says
+int grid_size(int n, int nv) { return nv > n / 8 ? nv : n / 8; }
 
-void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s) {
-    if (c->cfg.mlp_f16) launch_mlp_sdf_stream_f16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s);
-    else launch_mlp_sdf_stream_bf16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s);
+void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s, int grid_slots = 0) {
+    if (c->cfg.mlp_f16) launch_mlp_sdf_stream_f16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s, grid_slots);
+    else launch_mlp_sdf_stream_bf16(c->host.geo, c->sarena.p, c->sarena_pairs.p, c->barena.as<float>(), c->fr, io, n, s, grid_slots);
 }
 
 // which distance queries run in compensated arithmetic (ra_config.trace_precision): the surface trace from 1 on, everything at 2
-enum { Q_OTHER = 0, Q_SURFACE = 1 };
-bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what == Q_SURFACE); }
+// (Q_KEY: the light-visibility rays towards the frame's key lights, ra_config.key_light_share)
+enum { Q_OTHER = 0, Q_SURFACE = 1, Q_KEY = 2 };
+bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what != Q_OTHER); }
+constexpr int KEY_LIGHTS_MAX = 64;       // per probe; bounds the second ray list of a light-visibility stage (rays <= pixels x this)
+bool key_tier(const ra_ctx* c) { return c->cfg.trace_precision == 1 && c->cfg.key_light_share > 0.f && c->n_lights > 0; }
+// the frame's key-light flags from the probe a render call shades with — unless the caller named the frame's probes itself (ra_set_key_probes)
+int key_mask_from(ra_ctx* c, const float* probe, int ph, int pw, hipStream_t s) {
+    if (c->key_external) return 0;
+    c->key_valid = false;
+    c->key_probes = 1;
+    if (!key_tier(c) || !probe) return 0;
+    if (c->key_mask.ensure((size_t)c->n_lights)) return 1;
+    launch_key_lights(probe, 1, ph, pw, c->light_dir.as<float>(), c->light_area.as<float>(), c->n_lights, c->cfg.key_light_share, KEY_LIGHTS_MAX, 0,
+                      c->key_mask.as<unsigned char>(), s);
+    c->key_valid = true;
+    return 0;
+}
 
 // the fine level of one query: K3, or K3C where the pass is in the precise tier
 // n: upper bound of the device-side count; hint: the count this pass found in an earlier frame (-1: none).  Every variant is correct for
@@ -354,10 +389,10 @@ void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s, int
     const int nv = variant_size(n, hint);
     if (comp) {
         Timer t(c, s, 3);
-        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, nv, s, c->k3cc_ok);
+        launch_mlp_sdf_comp(c->host.geo, c->sarena_c.p, c->barena.as<float>(), c->fr, io, nv, s, c->k3cc_ok, grid_size(n, nv));
     } else {
         Timer t(c, s, k3_waves(nv) == 8 ? 0 : 2);      // timed per kernel family: 0 = 8-wave K3, 2 = the narrow variants
-        k3_launch(c, io, nv, s);
+        k3_launch(c, io, nv, s, grid_size(n, nv));
     }
 }
 
@@ -616,6 +651,23 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         sh = alloc_trace(c, "sh_", (int)NR, shadow.soft_shadow != 0, &err);      // hard shadows (cfg.no_dfss) run the surface trace's state machine (:182-197)
         ssdf = c->buf<float>("sh_sdf", NR, &err);
     }
+    // the key-light tier: the rays towards the frame's key lights (at most KEY_LIGHTS_MAX per probe; flags on the device) form a second,
+    // short list that is traced in compensated arithmetic
+    const bool keyed = traced && key_tier(c) && c->key_valid;
+    const size_t NK = keyed ? (size_t)P * (size_t)(L < KEY_LIGHTS_MAX * c->key_probes ? L : KEY_LIGHTS_MAX * c->key_probes) : 0;
+    TraceState shk{};
+    float* ksdf = nullptr;
+    if (keyed) {
+        g.key = c->key_mask.as<unsigned char>();
+        g.k_ray_pix = c->buf<int>("lk_pix", NK, &err);
+        g.k_ray_light = c->buf<int>("lk_light", NK, &err);
+        g.k_ray_slot = c->buf<int>("lk_slot", NK, &err);
+        g.k_near = c->buf<float>("lk_near", NK, &err);
+        g.k_far = c->buf<float>("lk_far", NK, &err);
+        g.k_ray_count = icnt(c, CNT_KRAYS);
+        shk = alloc_trace(c, "shk_", (int)NK, shadow.soft_shadow != 0, &err);
+        ksdf = c->buf<float>("shk_sdf", NK, &err);
+    }
     if (err) return 1;
     // frames in flight: this stage (the frame's large launches) starts when the stage submitted before it through the same gate has ended
     if (c->gate && c->gate->armed) RA_HIP(hipStreamWaitEvent(s, c->gate->done, 0));
@@ -641,9 +693,45 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
         launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);
     }
+    if (keyed) {       // the same loop over the key lights' rays, distance queries compensated
+        shk.near_ = g.k_near; shk.far_ = g.k_far; shk.tan_i = c->light_sharp.as<float>(); shk.light = g.k_ray_light;
+        launch_trace_init(shk, (int)NK, g.k_ray_count, shadow, s);
+        RaySet r3{};
+        r3.mode = 2; r3.o = surf; r3.t = shk.t; r3.pix = g.k_ray_pix; r3.light = g.k_ray_light; r3.ldir = c->light_dir.as<float>();
+        r3.n_dev = g.k_ray_count;
+        r3.skip = c->cfg.query_skip ? shk.stuck : nullptr;
+        r3.nn_hint = c->buf<int>("lk_nn", NK * 3, &err);
+        if (err) return 1;
+        for (int it = 0; it < shadow.iters; ++it) {
+            r3.hint_valid = it > 0;
+            r3.hint_src = it == 0 ? pix_nn : nullptr;
+            r3.hint_src_index = it == 0 ? g.k_ray_pix : nullptr;
+            if (hdq_pass(c, r3, (int)NK, shadow.dist_th, 1, ksdf, s, Q_KEY)) return 1;
+            launch_trace_update(shk, ksdf, (int)NK, g.k_ray_count, it, shadow, s);
+        }
+        launch_shadow_scatter(shk.occ, g.k_ray_slot, g.k_ray_count, (int)NK, lvis, s);
+        launch_accumulate(g.k_ray_count, &dcnt(c)->n_shadow_rays, s);
+    }
     if (c->gate) { RA_HIP(hipEventRecord(c->gate->done, s)); c->gate->armed = true; }
     *lvis_out = lvis;
     *ldot_out = ldot;
+    return 0;
+}
+
+int ra_set_key_probes(ra_ctx* c, const float* probes, int n, int ph, int pw, int accumulate, void* stream) {
+    RA_CHECK(c && n >= 0 && (n == 0 || (probes && ph > 0 && pw > 0)), "ra_set_key_probes: bad arguments");
+    if (n == 0) { c->key_external = false; c->key_valid = false; c->key_probes = 1; return 0; }
+    RA_CHECK(c->have_weights && c->n_lights > 0, "ra_set_key_probes: needs the relight network's light set (ra_finalize_weights)");
+    RA_HIP(hipSetDevice(c->device));
+    const bool acc = accumulate && c->key_external && c->key_valid;
+    c->key_external = true;
+    if (!key_tier(c)) { c->key_valid = false; return 0; }
+    if (c->key_mask.ensure((size_t)c->n_lights)) return 1;
+    launch_key_lights(probes, n, ph, pw, c->light_dir.as<float>(), c->light_area.as<float>(), c->n_lights, c->cfg.key_light_share, KEY_LIGHTS_MAX,
+                      acc ? 1 : 0, c->key_mask.as<unsigned char>(), (hipStream_t)stream);
+    c->key_probes = (acc ? c->key_probes : 0) + n;
+    c->key_valid = true;
+    RA_HIP(hipGetLastError());
     return 0;
 }
 
@@ -740,6 +828,7 @@ int ra_render_sphere_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     // ---- light visibility + shading (HOT LOOP B)
     float *lvis = nullptr, *ldot = nullptr, *shade = nullptr, *spec = nullptr;
     if (relit) {
+        if (key_mask_from(c, probe, ph, pw, s)) return 1;
         if (light_visibility_stage(c, surf, m.norm, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow,
                                    p->no_visibility, p->local_visibility, &lvis, &ldot, s, p->n_boxes, p->boxes, p->box_start, rs.nn_hint, perm, true)) return 1;
         m.rgb = c->buf<float>("mp_rgb", (size_t)P * 3, &err);
@@ -836,6 +925,7 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
         if (launch_sort_hits(surf, acc, P, bmin, k0, k1, v0, hit_idx, tmp, tb, s)) { ra_set_error("ra_render_ground_chunk: radix sort failed"); return 1; }
     }
     float *lvis = nullptr, *ldot = nullptr;
+    if (key_mask_from(c, probe, ph, pw, s)) return 1;
     if (light_visibility_stage(c, surf, nslots, acc, hit_idx, hit_count, P, bbox, p->shadow_near_offset, p->shadow, p->no_visibility,
                                p->local_visibility, &lvis, &ldot, s, p->n_boxes, p->boxes, p->box_start)) return 1;
     auto zero = [&](void* dst, int C) { if (dst) hipMemsetAsync(dst, 0, (size_t)P * C * sizeof(float), s); };
@@ -1340,6 +1430,7 @@ int ra_debug_lvis(ra_ctx* c, const float* surf, const float* norm, const float* 
     if (err) return 1;
     launch_iota(hit_idx, n, icnt(c, CNT_HIT), s);          // every point is its own hit slot
     float *lvis = nullptr, *ldot = nullptr;
+    if (key_mask_from(c, nullptr, 0, 0, s)) return 1;       // no probe here: every ray in the plain tier (unless ra_set_key_probes named the key lights)
     if (light_visibility_stage(c, surf, norm, acc, hit_idx, icnt(c, CNT_HIT), n, bbox, near_offset, *shadow, 0, 0, &lvis, &ldot, s)) return 1;
     RA_HIP(hipMemcpyAsync(lvis_out, lvis, (size_t)n * c->n_lights * 4, hipMemcpyDeviceToDevice, s));
     RA_HIP(hipMemcpyAsync(ldot_out, ldot, (size_t)n * c->n_lights * 4, hipMemcpyDeviceToDevice, s));

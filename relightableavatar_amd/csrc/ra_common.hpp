@@ -114,10 +114,19 @@ struct FullIO {             // the full query: geometry with normal + material /
 // K3 workgroup width by the launch's upper bound of fine points (ra_k3.hpp launch_k3): 2 / 4 waves (one per SIMD) for launches that
 // cannot fill the 256 CUs with 256-point tiles, 8 waves otherwise
 inline int k3_waves(int max_slots) { return max_slots <= 256 * 64 ? 2 : (max_slots <= 256 * 256 ? 4 : 8); }
+// grid_slots (all fused distance launches): the size the GRID is made for when it is larger than max_slots, which then only picks the
+// workgroup width.  max_slots may come from an earlier frame's count (launch-variant hints): if this frame's count is many times larger —
+// a camera cut — a narrow variant on a grid sized for the hint would be a cliff (a few workgroups for millions of points); on a grid
+// sized for a fraction of the bound it is only the narrow variant's lower rate.  Workgroups beyond the real count find no tile and exit.
+inline int mlp_grid(int max_slots, int grid_slots, int tile) {
+    const int m = grid_slots > max_slots ? grid_slots : max_slots;
+    const int tiles = (m + tile - 1) / tile;
+    return tiles < 256 ? tiles : 256;     // one workgroup per CU (the weight ring fills its LDS), persistent over tiles
+}
 void launch_mlp_sdf_stream_f16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
-                               int max_slots, hipStream_t stream);
+                               int max_slots, hipStream_t stream, int grid_slots = 0);
 void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io,
-                                int max_slots, hipStream_t stream);
+                                int max_slots, hipStream_t stream, int grid_slots = 0);
 
 // K3C (ra_k3c.hpp): the same query in compensated arithmetic (f16 hi + lo operand pairs, three MFMAs per k-step) on the split stream
 // sarena_c, 16 points per wave: 4 waves per workgroup (64-point tiles, one wave per SIMD) for launches of at most 16 Ki points, else 8
@@ -127,11 +136,12 @@ void launch_mlp_sdf_stream_bf16(const GeoNet& net, const void* sarena, const voi
 // weight streams): 102 -> 56 us per launch.  All variants are bit-identical.
 inline int k3c_waves(int max_slots) { return max_slots <= 256 * 64 ? 4 : 8; }
 constexpr int k3c_coop_max = 256 * 32;
-void launch_mlp_sdf_coop(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream);
+void launch_mlp_sdf_coop(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream,
+                         int grid_slots = 0);
 // allow_coop = false: launches of at most k3c_coop_max points take K3C's 4-wave tiles instead of K3CC (the context's self-test of K3CC
 // failed at ra_finalize_weights: ra_ctx::k3cc_ok)
 void launch_mlp_sdf_comp(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream,
-                         bool allow_coop = true);
+                         bool allow_coop = true, int grid_slots = 0);
 
 // K4 (ra_k4.hpp): forward with tape + reverse-mode backward + heads, on the sub-batch io.slot0 / io.slot_cap of the fine list
 size_t mlp_full_rev_tape_bytes(int slots);

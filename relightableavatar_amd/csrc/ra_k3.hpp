@@ -237,9 +237,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_stream_kerne
 }  // namespace
 
 template <typename E, int NW>
-static void launch_nw(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
-    const int tiles = (max_slots + 32 * NW - 1) / (32 * NW);
-    const int grid = tiles < 256 ? tiles : 256;     // one workgroup per CU (the weight ring fills its LDS), persistent over tiles
+static void launch_nw(const GeoNet& net, const void* sarena, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream, int grid_slots) {
+    const int grid = mlp_grid(max_slots, grid_slots, 32 * NW);
     hipLaunchKernelGGL((mlp_sdf_stream_kernel<E, NW>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena, barena, fr, io);
 }
 
@@ -249,14 +248,14 @@ static void launch_nw(const GeoNet& net, const void* sarena, const float* barena
 // rounds that equal one 8-wave round, and one when the real count is below half.  All widths are bit-identical.
 template <typename E>
 static void launch_k3(const GeoNet& net, const void* sarena, const void* sarena_pairs, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots,
-                      hipStream_t stream) {
+                      hipStream_t stream, int grid_slots) {
     if (max_slots <= 0) return;
     int nw = k3_waves(max_slots);
 #ifdef RA_TESTING            // test / experiment builds only (tools/build_variant.sh): force the workgroup width
     static const int force = getenv("RA_STREAM_NW") ? atoi(getenv("RA_STREAM_NW")) : 0;
     if (force) nw = force;
 #endif
-    if (nw == 2) launch_nw<E, 2>(net, sarena_pairs, barena, fr, io, max_slots, stream);
-    else if (nw == 4) launch_nw<E, 4>(net, sarena_pairs, barena, fr, io, max_slots, stream);
-    else launch_nw<E, 8>(net, sarena, barena, fr, io, max_slots, stream);
+    if (nw == 2) launch_nw<E, 2>(net, sarena_pairs, barena, fr, io, max_slots, stream, grid_slots);
+    else if (nw == 4) launch_nw<E, 4>(net, sarena_pairs, barena, fr, io, max_slots, stream, grid_slots);
+    else launch_nw<E, 8>(net, sarena, barena, fr, io, max_slots, stream, grid_slots);
 }

@@ -165,9 +165,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void mlp_sdf_comp_kernel(
 }
 
 template <int NW>
-void launch_c_nw(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
-    const int tiles = (max_slots + 16 * NW - 1) / (16 * NW);
-    const int grid = tiles < 256 ? tiles : 256;     // one workgroup per CU (the weight ring fills its LDS), persistent over tiles
+void launch_c_nw(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream, int grid_slots = 0) {
+    const int grid = mlp_grid(max_slots, grid_slots, 16 * NW);
     hipLaunchKernelGGL((mlp_sdf_comp_kernel<NW>), dim3(grid), dim3(64 * NW), 0, stream, net, sarena_c, barena, fr, io);
 }
 

@@ -249,9 +249,8 @@ __global__ __launch_bounds__(64 * CC_W, 1) void mlp_sdf_coop_kernel(GeoNet net, 
     }
 }
 
-void launch_coop(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream) {
-    const int tiles = (max_slots + 15) / 16;
-    const int grid = tiles < 256 ? tiles : 256;
+void launch_coop(const GeoNet& net, const void* sarena_c, const float* barena, const FrameState& fr, const MlpIO& io, int max_slots, hipStream_t stream, int grid_slots) {
+    const int grid = mlp_grid(max_slots, grid_slots, 16);
     hipLaunchKernelGGL(mlp_sdf_coop_kernel, dim3(grid), dim3(64 * CC_W), 0, stream, net, reinterpret_cast<const char*>(sarena_c) + (size_t)STC_FRAGS * 1024, barena, fr, io);
 }
 

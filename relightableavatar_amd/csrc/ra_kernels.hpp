@@ -121,7 +121,16 @@ struct ShadowGen {
     int* ray_slot;        // ray -> slot*L + light (where occ lands)
     float *near_, *far_;
     int* ray_count;
+    // the key-light tier (ra_config.key_light_share): rays towards lights with key[l] != 0 go to a second list instead
+    const unsigned char* key;     // nullable: L flags
+    int *k_ray_pix, *k_ray_light, *k_ray_slot;
+    float *k_near, *k_far;
+    int* k_ray_count;
 };
+// key[l] = light l carries at least `share` x the mean share of a probe's power under any of the n probes (at most kmax per probe);
+// accumulate: OR into the existing flags instead of replacing them
+void launch_key_lights(const float* probes, int n, int ph, int pw, const float* ldir, const float* area, int L, float share, int kmax,
+                       int accumulate, unsigned char* key, hipStream_t s);
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s, bool counter_is_zero = false);
 void launch_debug_aabb(const float* o, const float* d, int n, const float* bbox6, float* nr, float* fr, hipStream_t s);
 void launch_debug_brdf(const float* p2l, const float* p2c, const float* nrm, const float* alb, const float* rough, int L, int N, const ra_config& cfg,

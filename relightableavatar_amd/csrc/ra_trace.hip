@@ -341,6 +341,7 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
     constexpr int ROUNDS = SG_LIGHTS / (TPB / 64);
     constexpr int NL = ROUNDS * (TPB / 64);               // lights per workgroup (= SG_LIGHTS)
     __shared__ int cnt[2][NL + 1];                        // traced rays per light among slots 0..31 / 32..63 of the group, then their offsets
+    __shared__ int kflag[NL + 1];                         // the light is a key light: its rays go to the second list (kflag[NL]: that list's base)
     float nrv[ROUNDS], frv[ROUNDS];
     unsigned tmask = 0;
     // A group is 64 hit pixels that are neighbours in the Morton order of the surface points: a patch of a few centimetres in a whole frame.
@@ -392,26 +393,29 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
         nrv[round] = nr; frv[round] = fr;
         if (trace) tmask |= 1u << round;
         const unsigned long long m = __ballot(trace);
-        if (lane == 0) { cnt[0][ll] = __popcll(m & 0xffffffffull); cnt[1][ll] = __popcll(m >> 32); }
+        if (lane == 0) { cnt[0][ll] = __popcll(m & 0xffffffffull); cnt[1][ll] = __popcll(m >> 32); kflag[ll] = (g.key && l < g.L) ? g.key[l] : 0; }
     }
     __syncthreads();
     // ONE atomic per workgroup for the traced-ray list (same-address atomics serialise: per wave they were the whole kernel
     // time); a wave's rays (one light x 64 neighbouring slots — or, for a group in two places, 32) stay contiguous
+    // (the rays towards key lights — ShadowGen::key — form a second list of the same layout, traced in compensated arithmetic)
     if (threadIdx.x == 0) {
-        int tot = 0;
+        int tot[2] = {0, 0};
         if (halves) {
             for (int hf = 0; hf < 2; ++hf)
-                for (int k = 0; k < NL; ++k) { const int c = cnt[hf][k]; cnt[hf][k] = tot; tot += c; }
+                for (int k = 0; k < NL; ++k) { int& t = tot[kflag[k] ? 1 : 0]; const int c = cnt[hf][k]; cnt[hf][k] = t; t += c; }
         } else {
             for (int k = 0; k < NL; ++k) {
+                int& t = tot[kflag[k] ? 1 : 0];
                 const int c0 = cnt[0][k], c1 = cnt[1][k];
-                cnt[0][k] = tot; cnt[1][k] = tot + c0; tot += c0 + c1;
+                cnt[0][k] = t; cnt[1][k] = t + c0; t += c0 + c1;
             }
         }
-        cnt[0][NL] = tot ? atomicAdd(g.ray_count, tot) : 0;
+        cnt[0][NL] = tot[0] ? atomicAdd(g.ray_count, tot[0]) : 0;
+        kflag[NL] = tot[1] ? atomicAdd(g.k_ray_count, tot[1]) : 0;
     }
     __syncthreads();
-    const int gbase = cnt[0][NL];
+    const int gbase = cnt[0][NL], kbase = kflag[NL];
 #pragma unroll
     for (int round = 0; round < ROUNDS; ++round) {
         const int ll = round * (TPB / 64) + wv;
@@ -420,13 +424,14 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
         if (trace) {
             const int hf = lane >> 5;
             const unsigned mh = hf ? (unsigned)(m >> 32) : (unsigned)m;
-            const int s = gbase + cnt[hf][ll] + __popc(mh & ((1u << (lane & 31)) - 1u));
+            const bool key = kflag[ll] != 0;                  // wave-uniform: a wave handles one light per round
+            const int s = (key ? kbase : gbase) + cnt[hf][ll] + __popc(mh & ((1u << (lane & 31)) - 1u));
             const int l = lc * SG_LIGHTS + ll;
-            g.ray_pix[s] = r;
-            g.ray_light[s] = l;
-            g.ray_slot[s] = h * g.L + l;
-            g.near_[s] = nrv[round];
-            g.far_[s] = frv[round];
+            (key ? g.k_ray_pix : g.ray_pix)[s] = r;
+            (key ? g.k_ray_light : g.ray_light)[s] = l;
+            (key ? g.k_ray_slot : g.ray_slot)[s] = h * g.L + l;
+            (key ? g.k_near : g.near_)[s] = nrv[round];
+            (key ? g.k_far : g.far_)[s] = frv[round];
         }
     }
     // rows of 32 lights: thread t -> (row = t / 32 + 8 k, light = t % 32)
@@ -491,6 +496,49 @@ __device__ __forceinline__ void sample_probe(const float* __restrict__ img, int 
     add(x1, y0, wx1 * wy0);
     add(x0, y1, wx0 * wy1);
     add(x1, y1, wx1 * wy1);
+}
+
+// The key lights of a frame: the lights whose share of a probe's power (radiance x solid angle, channel mean) is at least `share` times
+// the mean share 1 / L, under any of the n probes — at most kmax of them per probe, the strongest first.  The light-visibility rays towards
+// them are traced in compensated arithmetic (ra_config.key_light_share): a DFSS penumbra value is d * sharp / (2 t), which amplifies
+// the 5e-5 distance error of plain f16 operands up to 500 x per light; summed over a probe's 512 lights those errors average out — unless a
+// few lights carry the probe's power, whose rays leave a pixel in nearly the same direction and err together.  One workgroup; L floats of LDS.
+__global__ __launch_bounds__(TPB) void key_lights_kernel(const float* __restrict__ probes, int n, int ph, int pw, const float* __restrict__ ldir,
+                                                         const float* __restrict__ area, int L, float share, int kmax, int accumulate,
+                                                         unsigned char* __restrict__ key) {
+    extern __shared__ float kl_w[];
+    __shared__ float red[TPB / 64];
+    for (int q = 0; q < n; ++q) {
+        const float* img = probes + (size_t)q * ph * pw * 3;
+        float part = 0.f;
+        for (int l = threadIdx.x; l < L; l += TPB) {
+            const float d[3] = {ldir[3 * l], ldir[3 * l + 1], ldir[3 * l + 2]};
+            float c[3];
+            sample_probe(img, ph, pw, d, c);
+            float w = (c[0] + c[1] + c[2]) * (1.f / 3.f) * area[l];
+            w = w > 0.f ? w : 0.f;                    // (also a NaN radiance)
+            kl_w[l] = w;
+            part += w;
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) part += __shfl_xor(part, sh);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        float total = 0.f;
+#pragma unroll
+        for (int k = 0; k < TPB / 64; ++k) total += red[k];
+        for (int l = threadIdx.x; l < L; l += TPB) {
+            const float w = kl_w[l];
+            bool cand = total > 0.f && w * (float)L >= share * total;
+            if (cand) {
+                int rank = 0;
+                for (int j = 0; j < L; ++j) rank += (kl_w[j] > w) || (kl_w[j] == w && j < l);
+                cand = rank < kmax;
+            }
+            key[l] = (q == 0 && !accumulate) ? (unsigned char)cand : (unsigned char)(key[l] | (unsigned char)cand);
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ float srgb(float x) {                // relight_utils.py:179-192
@@ -854,12 +902,20 @@ void launch_surface_composite(const float* raw, int C, int S, const int* hit_cou
     hipLaunchKernelGGL(surface_composite_kernel, grid_for(P), dim3(TPB), 0, s, raw, C, S, hit_count, relight, cfg, m);
 }
 
+void launch_key_lights(const float* probes, int n, int ph, int pw, const float* ldir, const float* area, int L, float share, int kmax,
+                       int accumulate, unsigned char* key, hipStream_t s) {
+    hipLaunchKernelGGL(key_lights_kernel, dim3(1), dim3(TPB), (size_t)L * sizeof(float), s, probes, n, ph, pw, ldir, area, L, share, kmax, accumulate, key);
+}
+
 void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s) {
     hipLaunchKernelGGL(light_dirs_kernel, grid_for(L), dim3(TPB), 0, s, xyz, L, ldir);
 }
 
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s, bool counter_is_zero) {
-    if (!counter_is_zero) hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
+    if (!counter_is_zero) {
+        hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
+        if (g.key) hipMemsetAsync(g.k_ray_count, 0, sizeof(int), s);
+    }
     if (P <= 0) return;
     const long long groups = ((long long)P + 63) / 64;
     const int lchunks = (g.L + SG_LIGHTS - 1) / SG_LIGHTS;

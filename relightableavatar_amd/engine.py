@@ -69,7 +69,8 @@ class Engine:
                       clip_near=float(cfg.get('clip_near', 0.02)), clip_far=float(cfg.get('clip_far', 10.0)),
                       only_visibility=int(bool(cfg.get('only_visibility', False))),
                       vis_shade_map=2 if cfg.get('vis_ldot_map', False) else (1 if cfg.get('vis_lvis_map', False) else 0),
-                      use_geodesic_filter=int(bool(cfg.get('use_geodesic_filter', True))))
+                      use_geodesic_filter=int(bool(cfg.get('use_geodesic_filter', True))),
+                      key_light_share=float(cfg.get('key_light_share', 4.0)))
         assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None
@@ -237,6 +238,21 @@ class Engine:
             params.n_boxes, params.boxes, params.box_start = 0, None, None
         check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
                                               probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
+
+    def k3cc_enabled(self) -> bool:
+        """the cooperative small-launch distance kernel passed its on-device self-test and is in use (ra_k3cc_enabled)"""
+        return bool(self.lib.ra_k3cc_enabled(self.ctx))
+
+    def set_key_probes(self, probe_sets):
+        """name the frame's key lights (ra_config.key_light_share) from every probe its cached visibility will be shaded with:
+        probe_sets is a list of (n, h, w, 3) / (h, w, 3) tensors (one entry per probe size); an empty list returns to per-call key lights."""
+        if not probe_sets:
+            check(self.lib.ra_set_key_probes(self.ctx, None, 0, 0, 0, 0, self.stream), 'ra_set_key_probes')
+            return
+        for i, pr in enumerate(probe_sets):
+            pr = _f32(pr if pr.ndim == 4 else pr[None], self.device)
+            self._keep.append(pr)
+            check(self.lib.ra_set_key_probes(self.ctx, _ptr(pr), pr.shape[0], pr.shape[1], pr.shape[2], int(i > 0), self.stream), 'ra_set_key_probes')
 
     def reshade_ground(self, ray_d, albedo_map, lvis, ldot, probes, images=None, attach_envmap=True):
         """novel_light_sphere_tracing.render_ground (:70-99) for all probes at once: probes (n,h,w,3), optional images

@@ -19,22 +19,7 @@ class Renderer(sphere_tracing_renderer.Renderer):
         # the reference brackets the main pass with two device synchronisations to report its time as `diff` (:107-112); a caller
         # that does not read it (cfg.novel_light_timing = False) keeps the host running ahead of the GPU
         timing = bool(cfg.get('novel_light_timing', True))
-        if timing:
-            torch.cuda.synchronize()
-        tick = time.perf_counter()
-        main = super().render(batch)
-        if timing:
-            torch.cuda.synchronize()
-        diff = time.perf_counter() - tick if timing else float('nan')
-        visual = ['rgb_map', 'acc_map', 'norm_map', 'surf_map', 'bpts_map', 'cpts_map', 'spec_map', 'shade_map', 'depth_map',
-                  'albedo_map', 'roughness_map', 'envmap']
-        relight = dotdict()
-        grd = main.get('ground', None)
         eng = self.net.engine()
-        if 'main' in cfg.test_light:
-            relight.main = dotdict({k: main[k] for k in visual if k in main})
-            if grd is not None:
-                relight.main = self.blend_output_(grd.acc_map, grd.inds, grd, relight.main, eng)      # :160-161
         lights = batch.novel_lights
         if cfg.vis_rotate_light and len(lights):
             # rotating-light sequence (novel_light_sphere_tracing.py:163-171): every probe in rotate_ratio * env_w steps
@@ -45,9 +30,30 @@ class Renderer(sphere_tracing_renderer.Renderer):
                 rotated[name] = env
             lights = rotated
         names = list(lights.keys())
+        pr = lambda p: p[0] if p.ndim == 4 else p
+        probes = torch.stack([pr(lights[n].probe) for n in names]).to(eng.device) if names else None
+        # the frame is traced once and shaded under every probe: its key lights (cfg.key_light_share) are those of all of them
+        env0 = self._envmap(batch)
+        eng.set_key_probes(([env0.probe] if env0 is not None else []) + ([probes] if probes is not None else []))
+        if timing:
+            torch.cuda.synchronize()
+        tick = time.perf_counter()
+        try:
+            main = super().render(batch)
+        finally:
+            eng.set_key_probes([])
+        if timing:
+            torch.cuda.synchronize()
+        diff = time.perf_counter() - tick if timing else float('nan')
+        visual = ['rgb_map', 'acc_map', 'norm_map', 'surf_map', 'bpts_map', 'cpts_map', 'spec_map', 'shade_map', 'depth_map',
+                  'albedo_map', 'roughness_map', 'envmap']
+        relight = dotdict()
+        grd = main.get('ground', None)
+        if 'main' in cfg.test_light:
+            relight.main = dotdict({k: main[k] for k in visual if k in main})
+            if grd is not None:
+                relight.main = self.blend_output_(grd.acc_map, grd.inds, grd, relight.main, eng)      # :160-161
         if names:
-            pr = lambda p: p[0] if p.ndim == 4 else p
-            probes = torch.stack([pr(lights[n].probe) for n in names]).to(eng.device)
             rgb, shade, spec = eng.reshade(main.ray_o, main.surf_map, main.norm_map, main.albedo_map, main.roughness_map,
                                            main.lvis_map, main.ldot_map, probes)
             if grd is not None:

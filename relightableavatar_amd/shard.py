@@ -328,11 +328,27 @@ def shard_batch(batch, rank: int, world: int, render_chunk_size=None, plan=None,
     return out
 
 
+def _host_staged(x: torch.Tensor, group=None) -> bool:
+    """device tensors over a process group that cannot move them (gloo: N rank processes sharing ONE GPU — RCCL refuses two ranks on a
+    device —, the multi-process test of the rank program): the collective runs on pinned host copies"""
+    return x.is_cuda and dist.get_backend(group) == 'gloo'
+
+
 def _exchange(x: torch.Tensor, n_max: int, order, src, total: int, world: int, group=None) -> torch.Tensor:
     buf = x.new_zeros(n_max, x.shape[-1])
     buf[:x.shape[0]] = x
-    out = x.new_empty(world * n_max, x.shape[-1])
-    dist.all_gather_into_tensor(out, buf, group=group)
+    if _host_staged(x, group):
+        st = torch.cuda.current_stream(x.device)
+        hb = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+        hb.copy_(buf, non_blocking=True)
+        st.synchronize()                         # the frame's last kernel: a host-staged gather needs the data on the host
+        ho = torch.empty(world * n_max, x.shape[-1], dtype=x.dtype, pin_memory=True)
+        dist.all_gather_into_tensor(ho, hb, group=group)
+        out = ho.to(x.device, non_blocking=True)
+        out.record_stream(st)
+    else:
+        out = x.new_empty(world * n_max, x.shape[-1])
+        dist.all_gather_into_tensor(out, buf, group=group)
     full = x.new_empty(total, x.shape[-1])
     full[order] = out[src]                   # rank r, slot j  ->  the j-th item owned by r
     return full
@@ -343,18 +359,26 @@ def gather_maps_async(local: torch.Tensor, P: int, rank: int, world: int, plan, 
     collectives may be in flight in one process group — what frames in flight do on the GPU, where every frame's gather is queued on its
     replica's stream; the process group runs them in submission order, which must be the same on every rank.  (On the GPU the plain
     `gather_maps` is already asynchronous for the host: the collective is stream-ordered.)"""
+    if world == 1:
+        return lambda: local
     squeeze = local.ndim == 2
     x = local[0] if not squeeze else local[0, :, None]
     _use(plan)
     pl = plan.ground if ground else plan
     total = pl.F if ground else P
+    issued_on = torch.cuda.current_stream(x.device) if x.is_cuda else None
     buf = x.new_zeros(pl.n_max, x.shape[-1])
     buf[:x.shape[0]] = x
     out = x.new_empty(world * pl.n_max, x.shape[-1])
     work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
 
     def finish():
-        work.wait()
+        work.wait()          # on a device, this orders only the CURRENT stream behind the collective
+        if issued_on is not None:
+            cur = torch.cuda.current_stream(x.device)
+            if cur != issued_on:      # buffers of the issuing stream, read on this one: the caching allocator must not recycle them under it
+                out.record_stream(cur)
+                buf.record_stream(cur)
         full = x.new_empty(total, x.shape[-1])
         full[pl.order] = out[pl.src]
         full = full[None]

@@ -73,6 +73,10 @@ SHARP_RESD_GAIN = 16.0          # residual deformation of ~1.5 cm instead of the
 
 
 FRONT_LIGHT_DIR = (-0.80, -0.30, -0.52)
+# the hard-case body (tests/golden/make_golden.py `split_body`, bench.py --body split): the cap of the template around split_axis (cosine
+# to the axis > 0.8: ~260 vertices move fully, ~800 in the sleeve behind them) is pulled 0.57 m out, tangentially: a horn from the top of
+# the body over its shoulder towards the camera, with a gap between horn and body that make_state_dict(env='front')'s key light shines through
+SPLIT_BODY_KW = dict(split_axis=[-0.25, -0.94, -0.26], split_offset=[-0.45, 0.0, -0.35], split_cos=0.8, skin_sharpness=6.0)
 
 
 def _env_pixel(d, eh, ew):

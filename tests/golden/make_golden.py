@@ -163,7 +163,8 @@ SWITCH_VARIANTS = {
 #  * sharp_weights — trained-like weights (synthetic.SHARP_BANDS: live encoding columns up to 2^7, centimetre-scale surface detail,
 #    |grad sdf| = 1.3 +- 0.5, a 1.5 cm residual deformation) on the base window, with the distance field on 3 000 points around the body;
 #  * sharp_split — both, with white noise in the skinning logits (skin_noise 2.0: the world -> big-pose warp jumps between neighbours).
-SPLIT_BODY = {'@split_axis': [-0.25, -0.94, -0.26], '@split_offset': [-0.45, 0.0, -0.35], '@split_cos': 0.8, '@skin_sharpness': 6.0, '@env': 'front'}
+from relightableavatar_amd.synthetic import SPLIT_BODY_KW      # noqa: E402
+SPLIT_BODY = dict({'@' + k: v for k, v in SPLIT_BODY_KW.items()}, **{'@env': 'front'})
 SPLIT_WINDOW = {'@crop': 12, '@crop_at': [64, 46]}
 SWITCH_VARIANTS.update({
     'split_body': dict(SPLIT_BODY, **SPLIT_WINDOW, **{'obj_lvis.iter': 12}),

@@ -532,8 +532,8 @@ def test_frame_relight_smooth_meets_the_contract(golden):
 
 # ---- the hot path's configuration switches: the reference under each override (tests/golden/switches.npz, one process per variant;
 # tests/test_oracle_frames.py pins the oracle on the same file)
-from test_oracle_frames import (GROUND_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, novel_switch_case, switch_batch_kw,      # noqa: E402
-                                switch_cfg, switch_variants, volume_switch_cfg)
+from test_oracle_frames import (GROUND_SWITCH_NAMES, HARD_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, novel_switch_case,      # noqa: E402
+                                switch_batch, switch_batch_kw, switch_cfg, switch_state_dict, switch_variants, volume_switch_cfg)
 
 
 @pytest.mark.parametrize('name', SWITCH_NAMES)
@@ -548,9 +548,9 @@ def test_switch_matrix(golden, name):
     cfg = switch_cfg(switch_variants(ref)[name], mlp_dtype='f16')
     bkw = switch_batch_kw(switch_variants(ref)[name])
     net = make_network(cfg)
-    net.load_state_dict(synthetic.make_state_dict(bkw.pop('weights_seed', 0), relight=True, cfg=cfg))
+    net.load_state_dict(switch_state_dict(bkw, cfg))
     net = net.to(dev).eval()
-    batch = synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), **{**dict(seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), **bkw}), dev)
+    batch = synthetic.to_device(switch_batch(ref, bkw), dev)
     out = make_renderer(cfg, net).render(batch)
     sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
     for k in ('rgb_map', 'shade_map', 'spec_map'):      # maps_only: render_human's early return (:702-705) leaves none of them
@@ -587,11 +587,12 @@ def test_ground_switch_matrix(golden, name):
     ref = golden('switches.npz')
     dev = _dev()
     cfg = switch_cfg(switch_variants(ref)[name], mlp_dtype='f16')
+    bkw = switch_batch_kw(switch_variants(ref)[name])
     net = make_network(cfg)
-    net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg))
+    net.load_state_dict(switch_state_dict(bkw, cfg))
     net = net.to(dev).eval()
     H = int(ref['ground_H'])
-    batch = synthetic.to_device(synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['ground_crop']), skin_noise=0.0), dev)
+    batch = synthetic.to_device(switch_batch(ref, bkw, ground=True), dev)
     rend = make_renderer(cfg, net)
     m = batch.mask_at_box.reshape(1, -1).cpu()
     rend.ground_inds = m.int().topk(int(m.sum()), dim=-1, sorted=False)[1][0]   # the scatter order of the CPU reference run
@@ -600,11 +601,77 @@ def test_ground_switch_matrix(golden, name):
     np.testing.assert_allclose(batch.wbounds.cpu().numpy(), sub['wbounds_after'], atol=1e-6)
     assert_contract(out.rgb_map, sub['rgb_map'], 'switches.npz:ground', f'switches.npz / {name}', bad=torch.zeros(H * H, dtype=torch.bool))
     # hard shadows (visibility = clip(500 d / t)): one penumbra-less edge pixel of 576 lands at 7.8e-3
-    assert float((err(out.rgb_map, sub['rgb_map']) < 5e-3).float().mean()) > (0.995 if name == 'g_no_dfss' else 0.999)
+    # (g_split_body: one of 576 pixels at the edge of the horn's shadow on the ground: 6.3e-3)
+    assert float((err(out.rgb_map, sub['rgb_map']) < 5e-3).float().mean()) > (0.995 if name == 'g_no_dfss' else (0.998 if name == 'g_split_body' else 0.999))
     assert float(err(out.albedo_map, sub['albedo_map']).max()) < 1e-2
     assert float((err(out.shade_map, sub['shade_map']) < 5e-3).float().mean()) > 0.99
     assert float((err(out.spec_map, sub['spec_map']) < 5e-3).float().mean()) > 0.99
     assert float(err(out.acc_map, sub['acc_map']).max()) < 3e-2
+
+
+def _hard_case(ref, name, trace_precision, key_light_share):
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    dev = _dev()
+    cfg = switch_cfg(switch_variants(ref)[name], mlp_dtype='f16', trace_precision=trace_precision, key_light_share=key_light_share)
+    bkw = switch_batch_kw(switch_variants(ref)[name])
+    net = make_network(cfg)
+    net.load_state_dict(switch_state_dict(bkw, cfg))
+    net = net.to(dev).eval()
+    out = make_renderer(cfg, net).render(synthetic.to_device(switch_batch(ref, bkw), dev))
+    return cfg, net, dev, out
+
+
+# the tiers a hard case is rendered with: (label, cfg.trace_precision, cfg.key_light_share)
+HARD_CASE_TIERS = (('round-5 tiers (surface trace compensated, every shadow ray plain f16)', 1, 0.0),
+                   ('shipped tiers (+ the shadow rays towards the key lights compensated)', 1, 4.0),
+                   ('every distance query compensated', 2, 0.0))
+# round-5 tiers on the hard cases: (max |err| bound, rays over 1e-2) where SURVEY.md:409's max half is NOT met — measured on the GPU
+# (profiles/r06_hard_cases.txt): what the key-light tier is for
+HARD_CASE_ROUND5_MAX = {'split_body': (2e-2, 2), 'sharp_split': (3e-2, 2)}
+
+
+@pytest.mark.parametrize('name', HARD_SWITCH_NAMES)
+def test_hard_case_switch_matrix(golden, name):
+    """The reference's own hard cases (round 6; tests/golden/make_golden.py SPLIT_BODY / synthetic.SHARP_BANDS), made by the reference:
+    a body part that shadows another at distance under a key light (sphere_tracing_renderer.py:157-179, 265-344) with 12 and with the
+    default 4 shadow iterations, trained-like weights with live high-frequency encoding columns (net_utils.py:1303-1352), both on the
+    noisy skinning field.  Each is rendered in three tiers (HARD_CASE_TIERS) and the figures of all are printed.  SURVEY.md:409's contract
+    (PSNR >= 50 dB, max |err| <= 1e-2 on the rays fp32 pins) is asserted for the SHIPPED tiers and for the all-compensated tier on every
+    case; round 5's tiers (no key lights) keep the PSNR half and miss the max half on two cases by the documented amounts."""
+    ref = golden('switches.npz')
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    case = 'switches.npz:' + name
+    res = []
+    for label, tp, share in HARD_CASE_TIERS:
+        cfg, net, dev, out = _hard_case(ref, name, tp, share)
+        assert bool(((out.acc_map.cpu() > 0) == (T(sub['acc_map']) > 0)).all()), (name, label)
+        ok = ~unstable_rays(case, out.rgb_map.shape[1])
+        e = err(out.rgb_map, sub['rgb_map'])[0]
+        pe = e.amax(-1)
+        cnt = net.engine().counters()
+        r = dict(psnr=float(-10 * torch.log10((e[ok] ** 2).mean())), max=float(e[ok].max()), over=int((pe[ok] > 1e-2).sum()),
+                 surf=float(err(out.surf_map, sub['surf_map'])[0][ok].max()), norm=float(err(out.norm_map, sub['norm_map'])[0][ok].max()),
+                 albedo=float(err(out.albedo_map, sub['albedo_map'])[0][ok].max()), shade=psnr(out.shade_map, sub['shade_map']),
+                 comp_share=cnt.n_fine_sdf_comp / max(cnt.n_fine_sdf, 1))
+        res.append(r)
+        print(f'switches.npz / {name}, {label}: ' + ', '.join(f'{k} {v:.3g}' for k, v in r.items()) + f' ({int((~ok).sum())} fp32-unstable rays)')
+        assert r['surf'] < (5e-4 if 'sharp' in name else 1e-4), r          # the surface trace is compensated in every tier
+        assert r['albedo'] < 2e-3
+        assert r['psnr'] >= 50.0, (name, label, r)
+        if name + '.hdq_x' in ref and tp == 1 and share == 0.0:       # sharp_weights: the distance field all around the body, plain f16 operands
+            s = net.engine().hdq_sdf(T(ref[name + '.hdq_x']).to(dev), cfg.dist_th, True).cpu()
+            es = err(s.reshape(-1), ref[name + '.hdq_sdf'].reshape(-1))
+            print(f'   hdq_sdf on 3 000 points, sharp weights: max {float(es.max()):.2e}, mean {float(es.mean()):.2e} (near-initialisation weights: 3e-4 bound)')
+            assert float(es.max()) < 1e-3
+        if tp == 1 and share > 0:      # the shipped tiers: the contract, on every case
+            assert_contract(out.rgb_map, sub['rgb_map'], case, f'switches.npz / {name} ({label})')
+            # ... at a price of a few per cent: the key lights' rays are a small part of the frame's distance queries
+            assert r['comp_share'] < 0.25, r
+    assert_contract(out.rgb_map, sub['rgb_map'], case, f'switches.npz / {name} (every distance query compensated)')
+    lim = HARD_CASE_ROUND5_MAX.get(name, (1e-2, 0))
+    assert res[0]['max'] <= lim[0] and res[0]['over'] <= lim[1], (name, res[0], lim)
+    assert res[1]['max'] <= res[0]['max'] + 1e-3          # the key-light tier never makes a case worse
 
 
 @pytest.mark.parametrize('name', VOLUME_SWITCH_NAMES)
@@ -956,6 +1023,54 @@ def test_rccl_path_world1_under_torchrun():
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline']) and 'workload' in line['config']
 
 
+RANK_PROGRAM_CASES = {
+    # BASELINE config 4: 512 x 512 full relight, (rgb, acc) gathered
+    'config4': (['--mode', 'relight', '--size', '512'], (2, 4)),
+    # config 5: 1024 x 1024, 8 probes re-shaded per frame, the 24-channel payload
+    'config5': (['--mode', 'novel_light', '--size', '1024', '--probes', '8'], (4,)),
+    # the README's relight command (readme.md:64): novel lights + the ground-plane pass, full-frame maps blended per rank
+    'readme': (['--mode', 'novel_light', '--ground', '--size', '512', '--probes', '2'], (2,)),
+}
+
+
+@pytest.mark.parametrize('case', list(RANK_PROGRAM_CASES))
+def test_rank_program_as_processes_sharing_the_gpu(case, tmp_path):
+    """The REAL rank program with N > 1 (the reference's rendezvous convention train.py:116-122): bench.py started by its own
+    launcher (torch.distributed.run, env:// on 127.0.0.1) as N fresh rank processes that all render on GPU 0 — HIP engine, per-process
+    context creation, shard plan in C, pinned staging, launch-variant hints, gate, three frames in flight — with the frame all_gather
+    staged through pinned host memory over gloo (RCCL refuses two ranks on one device; RCCL itself runs at world 1 in
+    test_rccl_path_world1_under_torchrun).  The frame rank 0 assembled must equal the single-process frame BIT FOR BIT, and the JSON line
+    must show every rank took part with its share of the work.  Everything of an 8-GPU run except the xGMI transport."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags, worlds = RANK_PROGRAM_CASES[case]
+    common = ['--steps', '3', '--warmup', '1', '--soak', '0', '--no-cpu-baseline', '--no-sequential', '--frames-in-flight', '3']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+
+    def run(world):
+        out = str(tmp_path / f'{case}_w{world}.npy')
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--dump-frame', out] + flags + common
+        if world > 1:
+            cmd += ['--backend', 'gloo', '--share-gpu']
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert r.returncode == 0 and lines, (world, r.stdout[-3000:], r.stderr[-3000:])
+        return json.loads(lines[-1]), np.load(out)
+    line1, whole = run(1)
+    assert np.isfinite(whole).all() and float(np.abs(whole).max()) > 0
+    for world in worlds:
+        line, frame = run(world)
+        assert line['n_gpus'] == world and line['ranks_seen'] == world, line
+        hp = line['per_rank']['hit_pixels_per_frame']
+        assert len(hp) == world and min(hp) > 0 and abs(sum(hp) - line1['config']['hit_pixels_per_frame']) <= 1, (hp, line1['config']['hit_pixels_per_frame'])
+        assert max(hp) <= 1.25 * (sum(hp) / world)           # the 8 x 8 tile deal balances the expensive pixels
+        assert line['gather']['channels'] == whole.shape[-1] or case == 'config4'
+        assert frame.shape == whole.shape and np.array_equal(frame, whole), (case, world, float(np.abs(frame - whole).max()))
+        print(f'{case}: {world} rank processes on one GPU == the single-process frame bit for bit ({whole.shape}); per rank: {line["per_rank"]}')
+
+
 def test_ray_generation_on_device(golden, relight):
     """N2: ra_gen_rays vs the reference's get_rays_within_bounds outputs (golden rays.npz): same in-box
     pixels in the same order, directions within 1 ulp-ish (2e-7), near/far within 2e-6; then full-size properties."""
@@ -1201,16 +1316,22 @@ def test_rotating_light_sequence():
     """cfg.vis_rotate_light: every probe is re-shaded at rotate_ratio * env_w headings from ONE traced frame; heading 0 is the
     unrotated probe, and a constant probe is rotation invariant"""
     from relightableavatar_amd.renderer import make_renderer
-    cfg, net, dev = build('novel_light', vis_rotate_light=True, rotate_ratio=1, test_light=[])
-    batch = synthetic.make_batch(96, 96, seed=0, posed=True, crop=16, n_novel_lights=1)
     from relightableavatar_amd.base_utils import dotdict
-    batch.novel_lights['flat'] = dotdict(probe=torch.full((1, 16, 32, 3), 0.7))
-    out = make_renderer(cfg, net).render(synthetic.to_device(batch, dev))
-    names = [k for k in out if k != 'diff']
-    assert len(names) == 2 * 32 and 'probe00-0000' in names and 'flat-0031' in names
-    cfg2, net2, _ = build('novel_light', test_light=[])
-    ref = make_renderer(cfg2, net2).render(synthetic.to_device(synthetic.make_batch(96, 96, seed=0, posed=True, crop=16, n_novel_lights=1), dev))
-    assert float((out['probe00-0000'].rgb_map - ref['probe00'].rgb_map).abs().max()) < 1e-6
+    # The frame is traced ONCE for all headings; which of its shadow rays run in compensated arithmetic depends on the probes it will be
+    # shaded with (cfg.key_light_share: the key lights of every heading), so "heading 0 == the unrotated probe alone" is exact only
+    # without that tier, and holds to the tiers' own difference with it.
+    for share, tol in ((0.0, 1e-6), (4.0, 5e-3)):
+        cfg, net, dev = build('novel_light', vis_rotate_light=True, rotate_ratio=1, test_light=[], key_light_share=share)
+        batch = synthetic.make_batch(96, 96, seed=0, posed=True, crop=16, n_novel_lights=1)
+        batch.novel_lights['flat'] = dotdict(probe=torch.full((1, 16, 32, 3), 0.7))
+        out = make_renderer(cfg, net).render(synthetic.to_device(batch, dev))
+        names = [k for k in out if k != 'diff']
+        assert len(names) == 2 * 32 and 'probe00-0000' in names and 'flat-0031' in names
+        cfg2, net2, _ = build('novel_light', test_light=[], key_light_share=share)
+        ref = make_renderer(cfg2, net2).render(synthetic.to_device(synthetic.make_batch(96, 96, seed=0, posed=True, crop=16, n_novel_lights=1), dev))
+        d = float((out['probe00-0000'].rgb_map - ref['probe00'].rgb_map).abs().max())
+        print(f'rotating-light sequence, key_light_share {share}: heading 0 vs the unrotated probe alone: max |diff| {d:.2e}')
+        assert d < tol, (share, d)
     assert float((out['flat-0000'].rgb_map - out['flat-0017'].rgb_map).abs().max()) < 1e-5
     assert float((out['probe00-0000'].rgb_map - out['probe00-0016'].rgb_map).abs().max()) > 1e-3      # half a turn changes the picture
 
@@ -1625,7 +1746,9 @@ def test_full_size_properties_config5():
     render chunks, so the 2-shard merge exercises the per-chunk box growth (render_chunks); batched probes == one by one"""
     from relightableavatar_amd import shard
     from relightableavatar_amd.renderer import make_renderer
-    cfg, net, dev = build('novel_light', test_light=[])
+    # (key_light_share 0: which shadow rays run compensated depends on the SET of probes a frame is shaded with, so "one probe alone == inside
+    # the batch" is exact only without the key-light tier; test_config5_key_light_tier_at_full_size holds the tier itself at this size)
+    cfg, net, dev = build('novel_light', test_light=[], key_light_share=0.0)
     rend = make_renderer(cfg, net)
     base = synthetic.to_device(synthetic.make_batch(1024, 1024, seed=0, posed=True, n_novel_lights=8), dev)
     P = base.ray_o.shape[1]
@@ -1650,3 +1773,34 @@ def test_full_size_properties_config5():
     single.novel_lights = dotdict({names[3]: base.novel_lights[names[3]]})
     o1 = rend.render(single)
     assert float((o1[names[3]].rgb_map - out[names[3]].rgb_map).abs().max()) == 0.0
+
+
+def test_config5_key_light_tier_at_full_size():
+    """cfg.key_light_share at BASELINE config 5's size (1024 x 1024, 8 probes; the last one is OLAT-style: one light of 100 over an
+    ambient 0.25 — a key light if there ever was one): every probe's frame with round 5's tiers (all shadow rays plain f16), with the
+    shipped tiers (+ the rays towards the key lights of ALL probes compensated) and with every distance query compensated.  The surface
+    trace is the same arithmetic in all three (identical hit masks and surface points).  Against the all-compensated frame the shipped
+    tiers must meet SURVEY.md:409's max |err| <= 1e-2 on every pixel of every probe; round 5's tiers do not (measured: 1.9e-2 on the
+    OLAT probe), which is what the tier is for — at a few per cent of the frame's distance queries."""
+    from relightableavatar_amd.renderer import make_renderer
+    frames, comp = {}, {}
+    for label, tp, share in (('round5', 1, 0.0), ('shipped', 1, 4.0), ('all', 2, 0.0)):
+        cfg, net, dev = build('novel_light', test_light=[], trace_precision=tp, key_light_share=share, novel_light_timing=False)
+        out = make_renderer(cfg, net).render(synthetic.to_device(synthetic.make_batch(1024, 1024, seed=0, posed=True, n_novel_lights=8), dev))
+        names = [k for k in out if k != 'diff']
+        frames[label] = {n: out[n].rgb_map.clone() for n in names}
+        frames[label]['acc'] = out[names[0]].acc_map.clone()
+        c = net.engine().counters()
+        comp[label] = c.n_fine_sdf_comp / max(c.n_fine_sdf, 1)
+        del out, net
+    assert torch.equal(frames['round5']['acc'], frames['all']['acc']) and torch.equal(frames['shipped']['acc'], frames['all']['acc'])
+    hit = frames['all']['acc'][0] > 0
+    worst = {}
+    for label in ('round5', 'shipped'):
+        worst[label] = {n: float((frames[label][n] - frames['all'][n]).abs().max()) for n in names}
+        over = {n: int(((frames[label][n] - frames['all'][n]).abs()[0].amax(-1) > 1e-2).sum()) for n in names}
+        print(f'config 5, {label} tiers vs all-compensated, per probe: max |diff| ' + ', '.join(f'{n} {v:.2e}' for n, v in worst[label].items()) +
+              f'; pixels over 1e-2: {over} of {int(hit.sum())} hit pixels; compensated share of the fine queries {comp[label]:.3f}')
+    assert max(worst['shipped'].values()) <= 1e-2, worst['shipped']
+    assert comp['shipped'] < 0.12, comp            # 2 % (the surface trace) + the key lights' rays
+    assert max(worst['round5'].values()) > max(worst['shipped'].values())          # the tier does something at this size

@@ -468,7 +468,7 @@ def test_default_config_matches_the_python_defaults():
     cfg = make_cfg('relight')
     for k in ('xyz_res', 'sdf_res', 'view_res', 'n_bones', 'resd_limit', 'blend_radius', 'albedo_slope', 'albedo_bias', 'roughness_slope',
               'roughness_bias', 'fresnel_f0', 'shading_albedo', 'albedo_multiplier', 'bg_brightness', 'trace_precision',
-              'k4_batch_slots'):
+              'k4_batch_slots', 'key_light_share'):
         assert abs(float(getattr(c, k)) - float(cfg[k])) < 1e-6, k
     assert c.relight == 1 and c.mlp_f16 == 1 and c.query_skip == 1 and c.tonemapping == 1 and c.lambert_only == 0 and c.glossy_only == 0
     assert abs(c.clip_near - 0.02) < 1e-7 and c.clip_far == 10.0

@@ -52,6 +52,18 @@ CASES = {
     'switches.npz:all_shadowed': ('relight', lambda: MB(128, 128, seed=3, posed=False, crop=10, skin_noise=0.0, cam_dist=1.6), 'all_shadowed', 5),
     'switches.npz:smpl24': ('relight', lambda: MB(128, 128, seed=0, posed=True, crop=10, skin_noise=0.0, n_bones=24, n_verts=5023), 'smpl24'),
 }
+# round 6, the hard cases of tests/golden/switches.npz: batch arguments and synthetic weights come from the variant's own @-keys
+for _v in ('split_body', 'split_body_iter4', 'sharp_weights', 'sharp_split'):
+    CASES['switches.npz:' + _v] = ('relight', None, _v)
+
+
+def variant_batch_and_weights(variant):
+    """(batch factory, make_state_dict kwargs) of a variant that carries @-keys"""
+    import numpy as np
+    v = json.loads(str(np.load(os.path.join(ROOT, 'tests', 'golden', 'switches.npz'))['variants_json']))[variant]
+    bkw = {k[1:]: val for k, val in v.items() if k.startswith('@')}
+    wkw = dict(seed=bkw.pop('weights_seed', 0), kind=bkw.pop('weights_kind', 'init'), env=bkw.pop('env', 'back'))
+    return (lambda: MB(128, 128, **{**dict(seed=0, posed=True, crop=10, skin_noise=0.0), **bkw})), wkw
 
 
 def switch_overrides(cfg, variant):
@@ -81,7 +93,10 @@ def main():
         if len(CASES[name]) > 2:
             switch_overrides(cfg, CASES[name][2])
         relight = mode in ('relight', 'novel_light')
-        net = O.OracleNet(synthetic.make_state_dict(CASES[name][3] if len(CASES[name]) > 3 else 0, relight=relight, cfg=cfg), cfg)
+        wkw = dict(seed=CASES[name][3] if len(CASES[name]) > 3 else 0)
+        if mk is None:
+            mk, wkw = variant_batch_and_weights(CASES[name][2])
+        net = O.OracleNet(synthetic.make_state_dict(relight=relight, cfg=cfg, **wkw), cfg)
         t0 = time.time()
         b = mk()
         if probs_only and name in res:
