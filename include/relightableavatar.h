@@ -81,14 +81,14 @@ typedef struct ra_config {
                                                  signed distances, neighbours farther than dist_th from the closest one ON THE CANONICAL BODY
                                                  replaced by it; 0: knn_with_filter (:164-194) — distance sqrt(mean d^2) with the sign of
                                                  max_k sign((x - v_k) . n_k), the three neighbours as found */
-    float key_light_share;                    /* 4.0 (default); with trace_precision 1: the light-visibility rays towards the frame's KEY LIGHTS are
-                                                 traced in compensated arithmetic like the surface trace.  A light is a key light when its share of
-                                                 the probe's power (radiance x solid angle) is at least key_light_share x the mean share 1 / L (at most
-                                                 64 per probe).  A DFSS penumbra value is d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): it
+    float key_light_share;                    /* 0.015 (default); with trace_precision 1: the light-visibility rays towards the frame's KEY LIGHTS are
+                                                 traced in compensated arithmetic like the surface trace.  A light is a key light when it holds at
+                                                 least this fraction of the probe's power (radiance x solid angle) — and at least 4 / L (at most 64
+                                                 per probe).  A DFSS penumbra value is d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): it
                                                  amplifies the 5e-5 distance error of plain f16 operands up to 500 x per light.  Summed over 512 lights
                                                  of comparable power the errors average out; under a key light that holds most of the power they do
                                                  not (the reference-made hard cases of tests/golden/switches.npz: max |err| 1.2e-2 .. 4.4e-2).  The
-                                                 key lights are 2-3 % of the lights.  0: no key-light tier (round 5's behaviour) */
+                                                 key lights are 0-3 % of the lights (a sun, a window; none under an overcast sky).  0: no key-light tier (round 5's behaviour) */
 } ra_config;
 /* A zero-initialised ra_config is NOT the default configuration (trace_precision 0 = plain operands, clip_far 0, ...): start from
  * ra_default_config() — the values documented above — and override.  ra_set_config rejects trace_precision outside 0..2,
@@ -228,6 +228,17 @@ int ra_render_sphere_chunk(ra_ctx* ctx, const float* ray_o, const float* ray_d, 
                            const float* far_, int P, const float* bbox_host6,
                            const float* probe_dev, int probe_h, int probe_w,
                            const ra_sphere_params* p, const ra_render_out* out, void* stream);
+
+/* One rank's rays out of the frame's (pixels dealt in 8 x 8 tiles): out_*[i] = *[idx[i]] for the four per-ray arrays of a
+ * batch (ray_o / ray_d: 3 floats per ray; near / far: 1), idx: n int64 ray indices (device).  No context: any device, any time.
+ * Replaces the four index_select launches of the host framework in the per-frame path of a sharded job. */
+int ra_gather_rays(int device, const long long* idx_dev, int n, const float* ray_o, const float* ray_d, const float* near_, const float* far_,
+                   float* out_o, float* out_d, float* out_near, float* out_far, void* stream);
+
+/* ... and the un-interleave after the frame all_gather: dst[dst_idx[i]] = src[src_idx[i]] for n rows of C floats (rank r, slot j -> the
+ * j-th pixel owned by r; the index vectors are the shard plan's, ra_shard_plan). */
+int ra_scatter_rows(int device, const float* src_dev, const long long* src_idx_dev, const long long* dst_idx_dev, long long n, int C,
+                    float* dst_dev, void* stream);
 
 /* The key lights of the current frame (ra_config.key_light_share), named by the caller: n probes of probe_h x probe_w x 3 (device) — every
  * probe the frame's cached visibility will be shaded with.  ra_render_sphere_chunk / ra_render_ground_chunk derive the key lights from the

@@ -740,14 +740,14 @@ def fp32_flip_probability(net: OracleNet, batch, rays, noise: float, trials: int
 
 
 def key_lights(net: OracleNet, probes, share: float):
-    """the lights whose share of a probe's power (radiance x solid angle, channel mean) is at least `share` times the mean share 1 / L,
-    under any of `probes` (each (H, W, 3)): the rule of the key-light tier (csrc/ra_api.cpp key_light_mask)"""
+    """the lights that hold at least the fraction max(share, 4 / L) of a probe's power (radiance x solid angle, channel mean) under any of
+    `probes` (each (H, W, 3)): the rule of the key-light tier (csrc/ra_trace.hip key_lights_kernel)"""
     d = normalize(net.light_xyz.reshape(-1, 3))
     area = net.light_area.reshape(-1)
     key = torch.zeros(d.shape[0], dtype=torch.bool)
     for pr in probes:
         w = sample_envmap_image(pr, d).mean(-1) * area
-        key |= w * d.shape[0] >= share * w.sum()
+        key |= w >= max(share, 4.0 / d.shape[0]) * w.sum()
     return key
 
 

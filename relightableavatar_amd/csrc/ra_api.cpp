@@ -108,7 +108,7 @@ int ra_default_config(ra_config* o) {
     o->tonemapping = 1; o->bg_brightness = 0.f; o->mlp_f16 = 1; o->query_skip = 1; o->k4_batch_slots = 0;
     o->trace_precision = 1; o->clip_near = 0.02f; o->clip_far = 10.f;
     o->only_visibility = 0; o->vis_shade_map = 0; o->use_geodesic_filter = 1;
-    o->key_light_share = 4.f;
+    o->key_light_share = 0.015f;
     return 0;
 }
 
@@ -118,7 +118,7 @@ int ra_set_config(ra_ctx* c, const ra_config* cfg) {
     RA_CHECK(cfg->trace_precision >= 0 && cfg->trace_precision <= 2, "ra_set_config: trace_precision must be 0, 1 or 2 (a zero-initialised ra_config is not the default: ra_default_config)");
     RA_CHECK(cfg->clip_far > cfg->clip_near, "ra_set_config: clip_far must exceed clip_near (a zero-initialised ra_config is not the default: ra_default_config)");
     RA_CHECK(cfg->vis_shade_map >= 0 && cfg->vis_shade_map <= 2, "ra_set_config: vis_shade_map must be 0, 1 or 2");
-    RA_CHECK(cfg->key_light_share >= 0.f, "ra_set_config: key_light_share must be >= 0 (0 = no key-light tier)");
+    RA_CHECK(cfg->key_light_share >= 0.f && cfg->key_light_share <= 1.f, "ra_set_config: key_light_share must be a fraction in [0, 1] (0 = no key-light tier)");
     c->cfg = *cfg;
     c->have_cfg = true;
     return 0;
@@ -940,6 +940,23 @@ int ra_render_ground_chunk(ra_ctx* c, const float* ray_o, const float* ray_d, co
     launch_ground_shade(in, c->cfg, s);
     if (out->surf) RA_HIP(hipMemcpyAsync(out->surf, surf, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->depth) RA_HIP(hipMemcpyAsync(out->depth, depth, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_gather_rays(int device, const long long* idx, int n, const float* ray_o, const float* ray_d, const float* near_, const float* far_,
+                   float* out_o, float* out_d, float* out_near, float* out_far, void* stream) {
+    RA_CHECK(n >= 0 && (n == 0 || (idx && ray_o && ray_d && near_ && far_ && out_o && out_d && out_near && out_far)), "ra_gather_rays: bad arguments");
+    RA_HIP(hipSetDevice(device));
+    launch_gather_shard_rays(idx, n, ray_o, ray_d, near_, far_, out_o, out_d, out_near, out_far, (hipStream_t)stream);
+    RA_HIP(hipGetLastError());
+    return 0;
+}
+
+int ra_scatter_rows(int device, const float* src, const long long* src_idx, const long long* dst_idx, long long n, int C, float* dst, void* stream) {
+    RA_CHECK(n >= 0 && C > 0 && (n == 0 || (src && src_idx && dst_idx && dst)) && n * C < (1ll << 40), "ra_scatter_rows: bad arguments");
+    RA_HIP(hipSetDevice(device));
+    launch_scatter_rows(src, src_idx, dst_idx, n, C, dst, (hipStream_t)stream);
     RA_HIP(hipGetLastError());
     return 0;
 }

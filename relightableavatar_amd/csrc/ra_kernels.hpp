@@ -127,10 +127,13 @@ struct ShadowGen {
     float *k_near, *k_far;
     int* k_ray_count;
 };
-// key[l] = light l carries at least `share` x the mean share of a probe's power under any of the n probes (at most kmax per probe);
+// key[l] = light l holds at least the fraction max(share, 4 / L) of a probe's power under any of the n probes (at most kmax per probe);
 // accumulate: OR into the existing flags instead of replacing them
 void launch_key_lights(const float* probes, int n, int ph, int pw, const float* ldir, const float* area, int L, float share, int kmax,
                        int accumulate, unsigned char* key, hipStream_t s);
+void launch_gather_shard_rays(const long long* idx, int n, const float* ro, const float* rd, const float* nr, const float* fr, float* so, float* sd,
+                              float* sn, float* sf, hipStream_t s);
+void launch_scatter_rows(const float* src, const long long* src_idx, const long long* dst_idx, long long n, int C, float* dst, hipStream_t s);
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s, bool counter_is_zero = false);
 void launch_debug_aabb(const float* o, const float* d, int n, const float* bbox6, float* nr, float* fr, hipStream_t s);
 void launch_debug_brdf(const float* p2l, const float* p2c, const float* nrm, const float* alb, const float* rough, int L, int N, const ra_config& cfg,

@@ -210,6 +210,29 @@ __global__ void gather_rays_kernel(const int* __restrict__ perm, int P, const fl
     sf[i] = fminf(fr[r], far_max);      // -inf / +inf elsewhere
 }
 
+// a shard's rays out of the frame's (relightableavatar_amd/shard.py shard_batch): one launch instead of four index kernels of the host framework
+__global__ void gather_shard_rays_kernel(const long long* __restrict__ idx, int n, const float* __restrict__ ro, const float* __restrict__ rd,
+                                         const float* __restrict__ nr, const float* __restrict__ fr, float* __restrict__ so, float* __restrict__ sd,
+                                         float* __restrict__ sn, float* __restrict__ sf) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const long long r = idx[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { so[3 * i + c] = ro[3 * r + c]; sd[3 * i + c] = rd[3 * r + c]; }
+    sn[i] = nr[r];
+    sf[i] = fr[r];
+}
+
+// the un-interleave after the frame all_gather: dst[dst_idx[i]] = src[src_idx[i]], rows of C floats (shard.py _exchange)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const long long* __restrict__ src_idx, const long long* __restrict__ dst_idx,
+                                    long long n, int C, float* __restrict__ dst) {
+    const long long k = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (k >= n * C) return;
+    const long long i = k / C;
+    const int c = (int)(k - i * C);
+    dst[dst_idx[i] * C + c] = src[src_idx[i] * C + c];
+}
+
 __global__ void surface_samples_kernel(const float* __restrict__ surf, const float* __restrict__ rd, const int* __restrict__ hit_idx,
                                        const int* __restrict__ hit_count, int S, float range, float* __restrict__ x,
                                        float* __restrict__ v, int* __restrict__ n_out) {
@@ -498,8 +521,9 @@ __device__ __forceinline__ void sample_probe(const float* __restrict__ img, int 
     add(x1, y1, wx1 * wy1);
 }
 
-// The key lights of a frame: the lights whose share of a probe's power (radiance x solid angle, channel mean) is at least `share` times
-// the mean share 1 / L, under any of the n probes — at most kmax of them per probe, the strongest first.  The light-visibility rays towards
+// The key lights of a frame: the lights that hold at least the fraction `share` of a probe's power (radiance x solid angle, channel mean)
+// — and at least four times the mean share 1 / L: a small light set has no key lights just because it is small — under any of the n
+// probes; at most kmax of them per probe, the strongest first.  The light-visibility rays towards
 // them are traced in compensated arithmetic (ra_config.key_light_share): a DFSS penumbra value is d * sharp / (2 t), which amplifies
 // the 5e-5 distance error of plain f16 operands up to 500 x per light; summed over a probe's 512 lights those errors average out — unless a
 // few lights carry the probe's power, whose rays leave a pixel in nearly the same direction and err together.  One workgroup; L floats of LDS.
@@ -529,7 +553,7 @@ __global__ __launch_bounds__(TPB) void key_lights_kernel(const float* __restrict
         for (int k = 0; k < TPB / 64; ++k) total += red[k];
         for (int l = threadIdx.x; l < L; l += TPB) {
             const float w = kl_w[l];
-            bool cand = total > 0.f && w * (float)L >= share * total;
+            bool cand = total > 0.f && w >= fmaxf(share, 4.f / (float)L) * total;
             if (cand) {
                 int rank = 0;
                 for (int j = 0; j < L; ++j) rank += (kl_w[j] > w) || (kl_w[j] == w && j < l);
@@ -1448,6 +1472,17 @@ int launch_sort_rays(const float* ro, const float* rd, const float* nr, const fl
     if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, perm, P, 0, 32, s) != hipSuccess) return 1;
     hipLaunchKernelGGL(gather_rays_kernel, grid_for(P), dim3(TPB), 0, s, perm, P, ro, rd, nr, fr, so, sd, sn, sf, near_min, far_max);
     return 0;
+}
+
+void launch_gather_shard_rays(const long long* idx, int n, const float* ro, const float* rd, const float* nr, const float* fr, float* so, float* sd,
+                              float* sn, float* sf, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_shard_rays_kernel, grid_for(n), dim3(TPB), 0, s, idx, n, ro, rd, nr, fr, so, sd, sn, sf);
+}
+
+void launch_scatter_rows(const float* src, const long long* src_idx, const long long* dst_idx, long long n, int C, float* dst, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_rows_kernel, grid_for(n * C), dim3(TPB), 0, s, src, src_idx, dst_idx, n, C, dst);
 }
 
 void launch_accumulate(const int* count, unsigned long long* dst, hipStream_t s) {

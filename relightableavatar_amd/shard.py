@@ -310,8 +310,20 @@ def shard_batch(batch, rank: int, world: int, render_chunk_size=None, plan=None,
     _use(plan)
     idx = plan.idx[rank]
     out = dotdict(batch)
-    for k in RAY_KEYS:
-        out[k] = batch[k][:, idx].contiguous()
+    if batch.ray_o.is_cuda and all(batch[k].dtype == torch.float32 and batch[k].is_contiguous() for k in RAY_KEYS) and idx.dtype == torch.int64:
+        # on the device: the library's own gather, one launch for the four arrays (ra_gather_rays)
+        from . import _lib
+        import ctypes as C
+        n = int(idx.shape[0])
+        for k in RAY_KEYS:
+            out[k] = batch[k].new_empty((1, n) + tuple(batch[k].shape[2:]))
+        pt = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().ra_gather_rays(dev.index or 0, pt(idx), n, pt(batch.ray_o), pt(batch.ray_d), pt(batch.near), pt(batch.far),
+                                             pt(out.ray_o), pt(out.ray_d), pt(out.near), pt(out.far),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'ra_gather_rays')
+    else:
+        for k in RAY_KEYS:
+            out[k] = batch[k][:, idx].contiguous()
     out.wbounds = batch.wbounds.clone()      # the renderer grows it in place per chunk (quirk 1)
     if batch.get('wbounds_host', None) is not None and batch.get('wbounds_host_version', None) == batch.wbounds._version:
         out.wbounds_host, out.wbounds_host_version = batch.wbounds_host.clone(), out.wbounds._version      # its host mirror follows (no read-back)
@@ -326,6 +338,20 @@ def shard_batch(batch, rank: int, world: int, render_chunk_size=None, plan=None,
         out.ground_pix, out.ground_inds = g.idx[rank], g.inds[rank]
         out.ground_chunks = g.chunks[rank] if 'chunks' in g else _chunk_ranges(g.idx_host[rank], g.F, render_chunk_size or g.F)
     return out
+
+
+def _unshuffle(out: torch.Tensor, order: torch.Tensor, src: torch.Tensor, total: int) -> torch.Tensor:
+    """full[order] = out[src] (rank r, slot j -> the j-th item owned by r): on the device the library's own one-launch scatter"""
+    full = out.new_empty(total, out.shape[-1])
+    if out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and order.dtype == torch.int64 and src.dtype == torch.int64:
+        from . import _lib
+        import ctypes as C
+        pt = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().ra_scatter_rows(out.device.index or 0, pt(out), pt(src), pt(order), int(order.shape[0]), int(out.shape[-1]), pt(full),
+                                              C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), 'ra_scatter_rows')
+    else:
+        full[order] = out[src]
+    return full
 
 
 def _host_staged(x: torch.Tensor, group=None) -> bool:
@@ -349,9 +375,7 @@ def _exchange(x: torch.Tensor, n_max: int, order, src, total: int, world: int, g
     else:
         out = x.new_empty(world * n_max, x.shape[-1])
         dist.all_gather_into_tensor(out, buf, group=group)
-    full = x.new_empty(total, x.shape[-1])
-    full[order] = out[src]                   # rank r, slot j  ->  the j-th item owned by r
-    return full
+    return _unshuffle(out, order, src, total)          # rank r, slot j  ->  the j-th item owned by r
 
 
 def gather_maps_async(local: torch.Tensor, P: int, rank: int, world: int, plan, group=None, ground: bool = False):
@@ -379,9 +403,7 @@ def gather_maps_async(local: torch.Tensor, P: int, rank: int, world: int, plan, 
             if cur != issued_on:      # buffers of the issuing stream, read on this one: the caching allocator must not recycle them under it
                 out.record_stream(cur)
                 buf.record_stream(cur)
-        full = x.new_empty(total, x.shape[-1])
-        full[pl.order] = out[pl.src]
-        full = full[None]
+        full = _unshuffle(out, pl.order, pl.src, total)[None]
         return full[..., 0] if squeeze else full
     return finish
 
