@@ -81,10 +81,11 @@ typedef struct ra_config {
                                                  signed distances, neighbours farther than dist_th from the closest one ON THE CANONICAL BODY
                                                  replaced by it; 0: knn_with_filter (:164-194) — distance sqrt(mean d^2) with the sign of
                                                  max_k sign((x - v_k) . n_k), the three neighbours as found */
-    float key_light_share;                    /* 0.015 (default); with trace_precision 1: the light-visibility rays towards the frame's KEY LIGHTS are
-                                                 traced in compensated arithmetic like the surface trace.  A light is a key light when it holds at
-                                                 least this fraction of the probe's power (radiance x solid angle) — and at least 4 / L (at most 64
-                                                 per probe).  A DFSS penumbra value is d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): it
+    float key_light_share;                    /* 0.0078 (default: four times the mean share of 512 lights); with trace_precision 1: the
+                                                 light-visibility rays towards the frame's KEY LIGHTS are traced in compensated arithmetic like the
+                                                 surface trace.  A light is a key light when it holds at least this fraction of a probe's power
+                                                 (radiance x solid angle) — and at least 4 / L — under any of the frame's probes; the 24 lights with
+                                                 the largest share at most, which bounds the tier's cost at ~10 % of the shadow rays.  A DFSS penumbra value is d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): it
                                                  amplifies the 5e-5 distance error of plain f16 operands up to 500 x per light.  Summed over 512 lights
                                                  of comparable power the errors average out; under a key light that holds most of the power they do
                                                  not (the reference-made hard cases of tests/golden/switches.npz: max |err| 1.2e-2 .. 4.4e-2).  The

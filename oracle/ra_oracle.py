@@ -739,15 +739,20 @@ def fp32_flip_probability(net: OracleNet, batch, rays, noise: float, trials: int
     return [float(v) / trials for v in flips.reshape(-1)]
 
 
-def key_lights(net: OracleNet, probes, share: float):
+def key_lights(net: OracleNet, probes, share: float, kmax: int = 24):
     """the lights that hold at least the fraction max(share, 4 / L) of a probe's power (radiance x solid angle, channel mean) under any of
     `probes` (each (H, W, 3)): the rule of the key-light tier (csrc/ra_trace.hip key_lights_kernel)"""
     d = normalize(net.light_xyz.reshape(-1, 3))
     area = net.light_area.reshape(-1)
-    key = torch.zeros(d.shape[0], dtype=torch.bool)
+    smax = torch.zeros(d.shape[0])
     for pr in probes:
-        w = sample_envmap_image(pr, d).mean(-1) * area
-        key |= w >= max(share, 4.0 / d.shape[0]) * w.sum()
+        w = (sample_envmap_image(pr, d).mean(-1) * area).clamp_min(0)
+        smax = torch.maximum(smax, w / w.sum())
+    key = smax >= max(share, 4.0 / d.shape[0])
+    if int(key.sum()) > kmax:          # the kmax lights with the largest share
+        keep = torch.zeros_like(key)
+        keep[torch.topk(torch.where(key, smax, torch.zeros_like(smax)), kmax).indices] = True
+        key = keep
     return key
 
 

@@ -108,7 +108,7 @@ int ra_default_config(ra_config* o) {
     o->tonemapping = 1; o->bg_brightness = 0.f; o->mlp_f16 = 1; o->query_skip = 1; o->k4_batch_slots = 0;
     o->trace_precision = 1; o->clip_near = 0.02f; o->clip_far = 10.f;
     o->only_visibility = 0; o->vis_shade_map = 0; o->use_geodesic_filter = 1;
-    o->key_light_share = 0.015f;
+    o->key_light_share = 0.0078f;
     return 0;
 }
 
@@ -367,17 +367,16 @@ void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s, int grid_slots 
 // (Q_KEY: the light-visibility rays towards the frame's key lights, ra_config.key_light_share)
 enum { Q_OTHER = 0, Q_SURFACE = 1, Q_KEY = 2 };
 bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what != Q_OTHER); }
-constexpr int KEY_LIGHTS_MAX = 64;       // per probe; bounds the second ray list of a light-visibility stage (rays <= pixels x this)
+constexpr int KEY_LIGHTS_MAX = 24;       // per frame; bounds the second ray list of a light-visibility stage (rays <= pixels x this) and the tier's cost
 bool key_tier(const ra_ctx* c) { return c->cfg.trace_precision == 1 && c->cfg.key_light_share > 0.f && c->n_lights > 0; }
 // the frame's key-light flags from the probe a render call shades with — unless the caller named the frame's probes itself (ra_set_key_probes)
 int key_mask_from(ra_ctx* c, const float* probe, int ph, int pw, hipStream_t s) {
     if (c->key_external) return 0;
     c->key_valid = false;
-    c->key_probes = 1;
     if (!key_tier(c) || !probe) return 0;
-    if (c->key_mask.ensure((size_t)c->n_lights)) return 1;
+    if (c->key_mask.ensure((size_t)c->n_lights) || c->key_share.ensure((size_t)c->n_lights * sizeof(float))) return 1;
     launch_key_lights(probe, 1, ph, pw, c->light_dir.as<float>(), c->light_area.as<float>(), c->n_lights, c->cfg.key_light_share, KEY_LIGHTS_MAX, 0,
-                      c->key_mask.as<unsigned char>(), s);
+                      c->key_share.as<float>(), c->key_mask.as<unsigned char>(), s);
     c->key_valid = true;
     return 0;
 }
@@ -654,7 +653,7 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
     // the key-light tier: the rays towards the frame's key lights (at most KEY_LIGHTS_MAX per probe; flags on the device) form a second,
     // short list that is traced in compensated arithmetic
     const bool keyed = traced && key_tier(c) && c->key_valid;
-    const size_t NK = keyed ? (size_t)P * (size_t)(L < KEY_LIGHTS_MAX * c->key_probes ? L : KEY_LIGHTS_MAX * c->key_probes) : 0;
+    const size_t NK = keyed ? (size_t)P * (size_t)(L < KEY_LIGHTS_MAX ? L : KEY_LIGHTS_MAX) : 0;
     TraceState shk{};
     float* ksdf = nullptr;
     if (keyed) {
@@ -720,16 +719,15 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
 
 int ra_set_key_probes(ra_ctx* c, const float* probes, int n, int ph, int pw, int accumulate, void* stream) {
     RA_CHECK(c && n >= 0 && (n == 0 || (probes && ph > 0 && pw > 0)), "ra_set_key_probes: bad arguments");
-    if (n == 0) { c->key_external = false; c->key_valid = false; c->key_probes = 1; return 0; }
+    if (n == 0) { c->key_external = false; c->key_valid = false; return 0; }
     RA_CHECK(c->have_weights && c->n_lights > 0, "ra_set_key_probes: needs the relight network's light set (ra_finalize_weights)");
     RA_HIP(hipSetDevice(c->device));
     const bool acc = accumulate && c->key_external && c->key_valid;
     c->key_external = true;
     if (!key_tier(c)) { c->key_valid = false; return 0; }
-    if (c->key_mask.ensure((size_t)c->n_lights)) return 1;
+    if (c->key_mask.ensure((size_t)c->n_lights) || c->key_share.ensure((size_t)c->n_lights * sizeof(float))) return 1;
     launch_key_lights(probes, n, ph, pw, c->light_dir.as<float>(), c->light_area.as<float>(), c->n_lights, c->cfg.key_light_share, KEY_LIGHTS_MAX,
-                      acc ? 1 : 0, c->key_mask.as<unsigned char>(), (hipStream_t)stream);
-    c->key_probes = (acc ? c->key_probes : 0) + n;
+                      acc ? 1 : 0, c->key_share.as<float>(), c->key_mask.as<unsigned char>(), (hipStream_t)stream);
     c->key_valid = true;
     RA_HIP(hipGetLastError());
     return 0;

@@ -77,10 +77,9 @@ struct ra_ctx {
     DevBuf sarena, sarena_pairs, sarena_c, fwd_arena, bwd_arena, shead_row, barena, cond_r0, cond_r4, cond_c3, b_r0, b_r4, b_c3, light_xyz, light_area, light_sharp, light_dir;
     int n_lights = 0;
     // the key-light tier (ra_config.key_light_share): per-light flags of the current frame's probes, on the device
-    DevBuf key_mask;
+    DevBuf key_mask, key_share;   // (key_share: every light's largest share of a probe's power among the frame's probes)
     bool key_valid = false;       // the flags were computed for the probes this frame is shaded with
     bool key_external = false;    // ... by ra_set_key_probes (the novel-light renderer: every probe of the re-shade); else per render call
-    int key_probes = 1;           // how many probes the flags were made from (bounds the key lights: KEY_LIGHTS_MAX each)
     // frame
     FrameState fr{};
     DevBuf fR, fTh, fvertA, fpverts4, fpnorm, ftverts, fbias_r0, fbias_r4, fbias_c3, fcond, fbvh_pts, fbvh_pairs, fbvh_order;

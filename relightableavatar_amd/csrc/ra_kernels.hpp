@@ -127,10 +127,10 @@ struct ShadowGen {
     float *k_near, *k_far;
     int* k_ray_count;
 };
-// key[l] = light l holds at least the fraction max(share, 4 / L) of a probe's power under any of the n probes (at most kmax per probe);
-// accumulate: OR into the existing flags instead of replacing them
+// key[l] = light l holds at least the fraction max(share, 4 / L) of a probe's power under any of the frame's probes — the kmax lights with
+// the largest such share at most.  smax (L floats): every light's largest share so far; accumulate: the n probes join those of earlier calls
 void launch_key_lights(const float* probes, int n, int ph, int pw, const float* ldir, const float* area, int L, float share, int kmax,
-                       int accumulate, unsigned char* key, hipStream_t s);
+                       int accumulate, float* smax, unsigned char* key, hipStream_t s);
 void launch_gather_shard_rays(const long long* idx, int n, const float* ro, const float* rd, const float* nr, const float* fr, float* so, float* sd,
                               float* sn, float* sf, hipStream_t s);
 void launch_scatter_rows(const float* src, const long long* src_idx, const long long* dst_idx, long long n, int C, float* dst, hipStream_t s);

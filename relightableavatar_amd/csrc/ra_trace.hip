@@ -522,14 +522,15 @@ __device__ __forceinline__ void sample_probe(const float* __restrict__ img, int 
 }
 
 // The key lights of a frame: the lights that hold at least the fraction `share` of a probe's power (radiance x solid angle, channel mean)
-// — and at least four times the mean share 1 / L: a small light set has no key lights just because it is small — under any of the n
-// probes; at most kmax of them per probe, the strongest first.  The light-visibility rays towards
-// them are traced in compensated arithmetic (ra_config.key_light_share): a DFSS penumbra value is d * sharp / (2 t), which amplifies
-// the 5e-5 distance error of plain f16 operands up to 500 x per light; summed over a probe's 512 lights those errors average out — unless a
-// few lights carry the probe's power, whose rays leave a pixel in nearly the same direction and err together.  One workgroup; L floats of LDS.
+// — and at least four times the mean share 1 / L: a small light set has no key lights just because it is small — under ANY of the frame's
+// probes; at most kmax of them in all, those with the largest share (under the probe that favours them most) first.  The light-visibility
+// rays towards them are traced in compensated arithmetic (ra_config.key_light_share): a DFSS penumbra value is d * sharp / (2 t), which
+// amplifies the 5e-5 distance error of plain f16 operands up to 500 x per light; summed over a probe's 512 lights those errors average
+// out — unless a few lights carry the probe's power, whose rays leave a pixel in nearly the same direction and err together.
+// smax[l]: the largest share of light l so far (accumulate != 0: over the probes of earlier calls too).  One workgroup; L floats of LDS.
 __global__ __launch_bounds__(TPB) void key_lights_kernel(const float* __restrict__ probes, int n, int ph, int pw, const float* __restrict__ ldir,
                                                          const float* __restrict__ area, int L, float share, int kmax, int accumulate,
-                                                         unsigned char* __restrict__ key) {
+                                                         float* __restrict__ smax, unsigned char* __restrict__ key) {
     extern __shared__ float kl_w[];
     __shared__ float red[TPB / 64];
     for (int q = 0; q < n; ++q) {
@@ -552,16 +553,23 @@ __global__ __launch_bounds__(TPB) void key_lights_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < TPB / 64; ++k) total += red[k];
         for (int l = threadIdx.x; l < L; l += TPB) {
-            const float w = kl_w[l];
-            bool cand = total > 0.f && w >= fmaxf(share, 4.f / (float)L) * total;
-            if (cand) {
-                int rank = 0;
-                for (int j = 0; j < L; ++j) rank += (kl_w[j] > w) || (kl_w[j] == w && j < l);
-                cand = rank < kmax;
-            }
-            key[l] = (q == 0 && !accumulate) ? (unsigned char)cand : (unsigned char)(key[l] | (unsigned char)cand);
+            const float sh_l = total > 0.f ? kl_w[l] / total : 0.f;
+            smax[l] = (q == 0 && !accumulate) ? sh_l : fmaxf(smax[l], sh_l);      // each light is one thread's
         }
         __syncthreads();
+    }
+    for (int l = threadIdx.x; l < L; l += TPB) kl_w[l] = smax[l];
+    __syncthreads();
+    const float thr = fmaxf(share, 4.f / (float)L);
+    for (int l = threadIdx.x; l < L; l += TPB) {
+        const float w = kl_w[l];
+        bool cand = w >= thr;
+        if (cand) {
+            int rank = 0;
+            for (int j = 0; j < L; ++j) rank += (kl_w[j] > w) || (kl_w[j] == w && j < l);
+            cand = rank < kmax;
+        }
+        key[l] = (unsigned char)cand;
     }
 }
 
@@ -927,8 +935,8 @@ void launch_surface_composite(const float* raw, int C, int S, const int* hit_cou
 }
 
 void launch_key_lights(const float* probes, int n, int ph, int pw, const float* ldir, const float* area, int L, float share, int kmax,
-                       int accumulate, unsigned char* key, hipStream_t s) {
-    hipLaunchKernelGGL(key_lights_kernel, dim3(1), dim3(TPB), (size_t)L * sizeof(float), s, probes, n, ph, pw, ldir, area, L, share, kmax, accumulate, key);
+                       int accumulate, float* smax, unsigned char* key, hipStream_t s) {
+    hipLaunchKernelGGL(key_lights_kernel, dim3(1), dim3(TPB), (size_t)L * sizeof(float), s, probes, n, ph, pw, ldir, area, L, share, kmax, accumulate, smax, key);
 }
 
 void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s) {

@@ -70,7 +70,7 @@ class Engine:
                       only_visibility=int(bool(cfg.get('only_visibility', False))),
                       vis_shade_map=2 if cfg.get('vis_ldot_map', False) else (1 if cfg.get('vis_lvis_map', False) else 0),
                       use_geodesic_filter=int(bool(cfg.get('use_geodesic_filter', True))),
-                      key_light_share=float(cfg.get('key_light_share', 0.015)))
+                      key_light_share=float(cfg.get('key_light_share', 0.0078)))
         assert cfg.mlp_dtype in ('f16', 'bf16')
         check(self.lib.ra_set_config(self.ctx, C.byref(c)), 'ra_set_config')
         self._frame_key = None
