@@ -69,7 +69,12 @@ def freq_bands(multires: int) -> torch.Tensor:
 # at all: |grad| ~ 20 and sin^2 + cos^2 = 1 adds a constant 24 rho^2 under the root of the geometric init's |W x| — no zero set is left.
 SHARP_BANDS = (0.02, 0.02, 0.02, 0.05, 0.08, 0.06, 0.04, 0.03)
 SHARP_SDF_BIAS = -0.559         # keeps the zero set's mean radius at 0.42 m under SHARP_BANDS (the constant above moves it inwards)
-SHARP_RESD_GAIN = 16.0          # residual deformation of ~1.5 cm instead of the default init's ~1 mm
+# residual deformation: 2.5 cm instead of the default init's 1.7 mm, with the Jacobian of a smooth warp (|d resd / d bpts|_2 = 0.18 mean,
+# 0.38 max: wrinkles of centimetres over decimetres).  The gain alone (the first version of this kind) gives |J| = 0.87 mean / 1.7 max —
+# a warp that folds space, which no trained net has (the reference regularises resd) and which amplifies every rounding of the encoding
+# path 512 x: the encoding columns of the net's two input layers therefore fall off by 0.7 per band above 2^4
+SHARP_RESD_GAIN = 16.0
+SHARP_RESD_DECAY, SHARP_RESD_BAND0 = 0.7, 4
 
 
 FRONT_LIGHT_DIR = (-0.80, -0.30, -0.52)
@@ -114,6 +119,11 @@ def make_state_dict(seed: int = 0, relight: bool = True, cfg=None, kind: str = '
     sd[f'{p}.mlp.linears.8.bias'] = torch.zeros(3)
     if kind == 'sharp':
         sd[f'{p}.mlp.linears.8.weight'] = sd[f'{p}.mlp.linears.8.weight'] * SHARP_RESD_GAIN
+        for l, off in ((0, 0), (4, W)):
+            w = sd[f'{p}.mlp.linears.{l}.weight'].clone()
+            for k in range(cfg.xyz_res):
+                w[:, off + 3 + 6 * k: off + 9 + 6 * k] *= SHARP_RESD_DECAY ** max(0, k - SHARP_RESD_BAND0)
+            sd[f'{p}.mlp.linears.{l}.weight'] = w
     # signed distance net (net_utils.py:1276-1352), geometric init, weight-normed
     p = 'signed_distance_network'
     sd[p + '._beta'] = torch.tensor(float(cfg.sdf_beta_init_value))

@@ -8,7 +8,8 @@ from relightableavatar_amd.config import make_cfg
 from relightableavatar_amd.networks import make_network
 cfg = make_cfg('relight')
 dev = torch.device('cuda:0')
-sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+kind = sys.argv[2] if len(sys.argv) > 2 else 'init'
+sd = synthetic.make_state_dict(0, relight=True, cfg=cfg, kind=kind)
 net = make_network(cfg); net.load_state_dict(sd); net = net.to(dev).eval()
 body = synthetic.make_body(0, posed=True)
 eng = net.set_frame(synthetic.to_device(body, dev))
@@ -35,6 +36,9 @@ e = (grad - og).abs().nan_to_num(9.9)
 print('grad vs autograd(bpts): max %.3e mean %.3e' % (float(e.max()), float(e.mean())))
 e2 = (grad - gc).abs().nan_to_num(9.9)
 print('grad vs autograd(cpts): max %.3e mean %.3e' % (float(e2.max()), float(e2.mean())))
+nrm = lambda v: v / v.norm(dim=-1, keepdim=True)
+en = (nrm(grad) - nrm(og)).abs().nan_to_num(9.9)
+print(kind, 'unit normal (big-pose) err: max %.3e mean %.3e p99 %.3e; |grad| mean %.3f' % (float(en.max()), float(en.mean()), float(en.flatten().kthvalue(int(0.99 * en.numel())).values), float(og.norm(dim=-1).mean())))
 print('hip ', grad[:4].tolist())
 print('ref ', og[:4].tolist())
 print('gc  ', gc[:4].tolist())
