@@ -9,7 +9,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
-RN=${RA_ROUND:-r04}
+RN=${RA_ROUND:-r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/${RN}_bench.json 2> $OUT/bench.err
@@ -21,6 +21,10 @@ python3 $R/bench.py --mode novel_light --size 1024 --probes 8 --steps 5 --warmup
 python3 $R/bench.py --skin-noise 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_skin_noise0.json 2>> $OUT/bench.err        # the smooth body, with its PSNR
 python3 $R/bench.py --coverage 0.35 --steps 10 --warmup 2 > $OUT/${RN}_bench_coverage35.json 2>> $OUT/bench.err          # a frame-filling subject (camera at 0.96 m), with its PSNR
 python3 $R/bench.py --trace-precision 0 --steps 20 --warmup 3 > $OUT/${RN}_bench_trace_precision0.json 2>> $OUT/bench.err  # round 3's arithmetic (plain f16 surface trace): what the compensated tier costs and buys
+python3 $R/bench.py --trace-precision 2 --steps 10 --warmup 3 > $OUT/${RN}_bench_trace_precision2.json 2>> $OUT/bench.err  # every distance query compensated: the tier that meets max |err| <= 1e-2 on every pixel, and its price
+python3 $R/bench.py --body split --steps 10 --warmup 3 > $OUT/${RN}_bench_body_split.json 2>> $OUT/bench.err               # the hard-case body (a part that shadows the body at distance, front key light, 12 shadow iterations)
+python3 $R/bench.py --body split --weights sharp --steps 10 --warmup 3 > $OUT/${RN}_bench_body_split_weights_sharp.json 2>> $OUT/bench.err
+python3 $R/bench.py --weights sharp --steps 10 --warmup 3 > $OUT/${RN}_bench_weights_sharp.json 2>> $OUT/bench.err
 : > $OUT/${RN}_bench_animate.jsonl
 python3 $R/bench.py --animate --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_bench_animate.jsonl 2>> $OUT/bench.err   # N3 + N2 inside the timed region
 python3 $R/bench.py --animate --frames-in-flight 1 --steps 20 --warmup 3 --no-cpu-baseline >> $OUT/${RN}_bench_animate.jsonl 2>> $OUT/bench.err
