@@ -127,7 +127,8 @@ def psnr_vs_oracle(renderer, ref, H, skin_noise, dev, n_target=N_SAMPLE, cam_dis
     # (the shipped default), 2 = every distance query compensated (the tier that meets max <= 1e-2 on EVERY pixel of the full frame and
     # on the hard cases, at 2 x the frame time: tests/test_gpu_parity.py test_full_frame_shadow_tier_is_harmless, test_hard_case_switch_matrix)
     tp = int(renderer.cfg.get('trace_precision', 1))
-    res['contract_tier'] = {'trace_precision': tp, 'name': {0: 'plain f16 operands', 1: 'surface trace compensated, shadow rays plain f16', 2: 'all distance queries compensated'}[tp]}
+    res['contract_tier'] = {'trace_precision': tp, 'name': {0: 'plain f16 operands', 1: 'surface trace + shadow rays towards the key lights compensated, the other shadow rays plain f16', 2: 'all distance queries compensated'}[tp],
+                            'key_light_share': float(renderer.cfg.get('key_light_share', 0.0))}
     # every sampled ray over 1e-2, by name: its error, whether fp32 itself pins it, and (committed samples) how often the reference's own
     # arithmetic flips it at fp32's noise level (tests/golden/fp32_unstable_rays.json: a coin toss of the reference is not an error of this path)
     over = [int(i) for i in (per_ray > 1e-2).nonzero()[:, 0][:16]]
@@ -308,6 +309,7 @@ def main():
     ap.add_argument('--body', default='blob', choices=['blob', 'split'], help='split: the hard-case body of tests/golden/switches.npz `split_body` (synthetic.SPLIT_BODY_KW: a horn pulled 0.57 m out of the body, shadowing it at distance) under the front key light, 12 shadow iterations unless --shadow-iters says otherwise')
     ap.add_argument('--weights', default='init', choices=['init', 'sharp'], help='sharp: trained-like synthetic weights (synthetic.SHARP_BANDS: live high-frequency encoding columns, cm-scale surface detail)')
     ap.add_argument('--shadow-iters', type=int, default=0, help='cfg.obj_lvis.iter (0 = the reference default 4; --body split: 12)')
+    ap.add_argument('--key-light-share', type=float, default=-1.0, help='cfg.key_light_share (default: the configuration default 0.0078; 0 = no key-light tier: every shadow ray on plain f16 operands, round 5)')
     ap.add_argument('--skin-noise', type=float, default=2.0, help='synthetic body: per-vertex noise of the skinning logits (SURVEY.md 8d default 2.0; 0 = smooth, SMPL-like)')
     args = ap.parse_args()
 
@@ -350,6 +352,8 @@ def main():
     if args.mode == 'novel_light':
         kw['novel_light_timing'] = False     # nobody reads `diff` here: no host sync inside the frame
     kw['trace_precision'] = args.trace_precision
+    if args.key_light_share >= 0:
+        kw['key_light_share'] = args.key_light_share
     cfg = make_cfg(args.mode, mlp_dtype=args.dtype, **kw)
     if args.body == 'split':
         BODY_KW.update(synthetic.SPLIT_BODY_KW)
@@ -622,6 +626,8 @@ def main():
         line['config']['frames_in_flight'] = D
         line['config']['camera_distance_m'] = round(cam_dist, 4)
         line['config']['trace_precision'] = args.trace_precision
+        line['config']['key_light_share'] = float(cfg.get('key_light_share', 0.0))
+        line['config']['k3cc_enabled'] = bool(engs[0].k3cc_enabled())
         line['config']['body'], line['config']['weights'], line['config']['shadow_iters'] = args.body, args.weights, int(cfg.obj_lvis.iter) if 'obj_lvis' in cfg else None
         line['config']['fine_queries_compensated_per_frame'] = int(cnt.get('n_fine_sdf_comp', 0) / args.steps)
         if args.emulate_world > 1:

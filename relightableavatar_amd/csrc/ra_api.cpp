@@ -89,6 +89,7 @@ int ra_ctx_destroy(ra_ctx* c) {
                       &c->fbias_r0, &c->fbias_r4, &c->fbias_c3, &c->fcond, &c->dcounters, &c->fbvh_pts, &c->fbvh_pairs, &c->fbvh_order,
                       &c->adj_start, &c->adj_list, &c->adj_dfaces};
     for (DevBuf* b : bufs) b->release();
+    c->key_mask.release(); c->key_share.release();
     for (auto& kv : c->scratch) kv.second.release();
     for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int k = 0; k < PinRing::n; ++k) if (c->pin.ev[k]) hipEventDestroy(c->pin.ev[k]);
@@ -289,7 +290,7 @@ struct Timer {
 
 DevCounters* dcnt(ra_ctx* c) { return c->dcounters.as<DevCounters>(); }
 int* icnt(ra_ctx* c, int k) { return reinterpret_cast<int*>(c->dcounters.as<char>() + 128) + k; }   // small int counters
-enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_KRAYS = 4, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
+enum { CNT_HIT = 1, CNT_RAYS = 2, CNT_SAMP = 3, CNT_FC0 = 8, CNT_FC_SLOTS = 96, CNT_ALL = CNT_FC0 + CNT_FC_SLOTS };
 
 // Every hierarchical-distance pass compacts its fine points through a device counter that must start at zero.  Instead of one
 // 4-byte memset launch per pass (21 per relit chunk), the counters are a set that ONE memset zeroes per chunk; each pass takes
@@ -396,7 +397,10 @@ void fine_level(ra_ctx* c, const MlpIO& io, int n, bool comp, hipStream_t s, int
 }
 
 // one hierarchical distance query over the points of rs; writes sdf[n]
-int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s, int what = Q_OTHER) {
+// key / n_key (the key-light tier; shadow rays only): the fine points of rays towards lights with key[light] != 0 — at most n_key — form
+// a second fine list that the compensated kernel answers; the pass then is ONE coarse launch + K3 on the first list + K3C / K3CC on the second
+int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sdf, hipStream_t s, int what = Q_OTHER,
+             const unsigned char* key = nullptr, int n_key = 0) {
     if (n <= 0) return 0;
     int err = 0;
     int* fine_idx = c->buf<int>("fine_idx", n, &err);
@@ -405,12 +409,25 @@ int hdq_pass(ra_ctx* c, const RaySet& rs, int n, float th, int smooth, float* sd
     HdqOut out{};
     out.sdf = sdf; out.fine_count = next_fine_counter(c, s); out.fine_idx = fine_idx; out.bpts = bpts;
     const int hint = fine_hint(c, c->fc_next - 1);
+    int hint2 = -1;
+    if (key && n_key > 0) {
+        out.key = key;
+        out.fine_idx2 = c->buf<int>("fine_idx_k", n_key, &err);
+        out.bpts2 = c->buf<float>("fine_bpts_k", (size_t)n_key * 3, &err);
+        if (err) return 1;
+        out.fine_count2 = next_fine_counter(c, s);
+        hint2 = fine_hint(c, c->fc_next - 1);
+    }
     out.counters = dcnt(c);
     launch_hdq_coarse(c->fr, rs, n, th, c->cfg.blend_radius, out, s, c->cfg.use_geodesic_filter != 0);
     MlpIO io{};
     io.bpts = bpts; io.idx = fine_idx; io.count = out.fine_count; io.sdf = sdf; io.dist_th = th; io.smooth = smooth;
     io.resd_limit = c->cfg.resd_limit; io.counters = dcnt(c);
     fine_level(c, io, n, precise(c, what), s, hint);
+    if (out.key) {
+        io.bpts = out.bpts2; io.idx = out.fine_idx2; io.count = out.fine_count2;
+        fine_level(c, io, n_key, true, s, hint2);
+    }
     return 0;
 }
 
@@ -650,23 +667,10 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
         sh = alloc_trace(c, "sh_", (int)NR, shadow.soft_shadow != 0, &err);      // hard shadows (cfg.no_dfss) run the surface trace's state machine (:182-197)
         ssdf = c->buf<float>("sh_sdf", NR, &err);
     }
-    // the key-light tier: the rays towards the frame's key lights (at most KEY_LIGHTS_MAX per probe; flags on the device) form a second,
-    // short list that is traced in compensated arithmetic
+    // the key-light tier: the fine points of the rays towards the frame's key lights (at most KEY_LIGHTS_MAX; flags on the device) form a
+    // second fine list in every pass of the loop below, answered by the compensated kernel
     const bool keyed = traced && key_tier(c) && c->key_valid;
     const size_t NK = keyed ? (size_t)P * (size_t)(L < KEY_LIGHTS_MAX ? L : KEY_LIGHTS_MAX) : 0;
-    TraceState shk{};
-    float* ksdf = nullptr;
-    if (keyed) {
-        g.key = c->key_mask.as<unsigned char>();
-        g.k_ray_pix = c->buf<int>("lk_pix", NK, &err);
-        g.k_ray_light = c->buf<int>("lk_light", NK, &err);
-        g.k_ray_slot = c->buf<int>("lk_slot", NK, &err);
-        g.k_near = c->buf<float>("lk_near", NK, &err);
-        g.k_far = c->buf<float>("lk_far", NK, &err);
-        g.k_ray_count = icnt(c, CNT_KRAYS);
-        shk = alloc_trace(c, "shk_", (int)NK, shadow.soft_shadow != 0, &err);
-        ksdf = c->buf<float>("shk_sdf", NK, &err);
-    }
     if (err) return 1;
     // frames in flight: this stage (the frame's large launches) starts when the stage submitted before it through the same gate has ended
     if (c->gate && c->gate->armed) RA_HIP(hipStreamWaitEvent(s, c->gate->done, 0));
@@ -686,30 +690,11 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
             // first pass: a shadow ray starts next to its pixel's surface point, whose neighbours the surface trace's last query found
             r2.hint_src = it == 0 ? pix_nn : nullptr;
             r2.hint_src_index = it == 0 ? g.ray_pix : nullptr;
-            if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s)) return 1;
+            if (hdq_pass(c, r2, (int)NR, shadow.dist_th, 1, ssdf, s, Q_OTHER, keyed ? c->key_mask.as<unsigned char>() : nullptr, (int)NK)) return 1;
             launch_trace_update(sh, ssdf, (int)NR, g.ray_count, it, shadow, s);
         }
         launch_shadow_scatter(sh.occ, g.ray_slot, g.ray_count, (int)NR, lvis, s);
         launch_accumulate(g.ray_count, &dcnt(c)->n_shadow_rays, s);
-    }
-    if (keyed) {       // the same loop over the key lights' rays, distance queries compensated
-        shk.near_ = g.k_near; shk.far_ = g.k_far; shk.tan_i = c->light_sharp.as<float>(); shk.light = g.k_ray_light;
-        launch_trace_init(shk, (int)NK, g.k_ray_count, shadow, s);
-        RaySet r3{};
-        r3.mode = 2; r3.o = surf; r3.t = shk.t; r3.pix = g.k_ray_pix; r3.light = g.k_ray_light; r3.ldir = c->light_dir.as<float>();
-        r3.n_dev = g.k_ray_count;
-        r3.skip = c->cfg.query_skip ? shk.stuck : nullptr;
-        r3.nn_hint = c->buf<int>("lk_nn", NK * 3, &err);
-        if (err) return 1;
-        for (int it = 0; it < shadow.iters; ++it) {
-            r3.hint_valid = it > 0;
-            r3.hint_src = it == 0 ? pix_nn : nullptr;
-            r3.hint_src_index = it == 0 ? g.k_ray_pix : nullptr;
-            if (hdq_pass(c, r3, (int)NK, shadow.dist_th, 1, ksdf, s, Q_KEY)) return 1;
-            launch_trace_update(shk, ksdf, (int)NK, g.k_ray_count, it, shadow, s);
-        }
-        launch_shadow_scatter(shk.occ, g.k_ray_slot, g.k_ray_count, (int)NK, lvis, s);
-        launch_accumulate(g.k_ray_count, &dcnt(c)->n_shadow_rays, s);
     }
     if (c->gate) { RA_HIP(hipEventRecord(c->gate->done, s)); c->gate->armed = true; }
     *lvis_out = lvis;

@@ -578,21 +578,25 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
     }
     // compaction: one atomic per workgroup (same-address atomics serialise in L2: per wave they cost as much as the
     // whole post-processing), wave offsets through LDS
-    __shared__ int wcount[NT / 64 + 1];
-    const unsigned long long m = __ballot(fine);
+    // (with HdqOut::key, the fine points of rays towards key lights form a second list the same way)
+    __shared__ int wcount[NT / 64 + 1], wcount2[NT / 64 + 1];
+    const bool fine2 = fine && out.key != nullptr && out.key[rs.light[i]] != 0;
+    const unsigned long long m = __ballot(fine && !fine2), m2 = out.key ? __ballot(fine2) : 0ull;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wcount[wv] = __popcll(m);
+    if (lane == 0) { wcount[wv] = __popcll(m); wcount2[wv] = __popcll(m2); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = 0;
+        int tot = 0, tot2 = 0;
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) { const int cnt = wcount[w]; wcount[w] = tot; tot += cnt; }
+        for (int w = 0; w < NT / 64; ++w) { const int cnt = wcount[w]; wcount[w] = tot; tot += cnt; const int c2 = wcount2[w]; wcount2[w] = tot2; tot2 += c2; }
         wcount[NT / 64] = (dbg & 8) ? base : (tot ? atomicAdd(out.fine_count, tot) : 0);
+        wcount2[NT / 64] = tot2 ? atomicAdd(out.fine_count2, tot2) : 0;
     }
     __syncthreads();
     RA_CSTAMP(6);
     if (!fine || (dbg & 16)) return;
-    const int slot = wcount[NT / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
+    const int slot = fine2 ? wcount2[NT / 64] + wcount2[wv] + __popcll(m2 & ((1ull << lane) - 1ull))
+                           : wcount[NT / 64] + wcount[wv] + __popcll(m & ((1ull << lane) - 1ull));
     // gaussian-weighted blend of the per-vertex transforms (base_network.py:287-296)
     float w[3], ws = 0.f;
 #pragma unroll
@@ -620,6 +624,11 @@ __global__ __launch_bounds__(SPLIT == 1 ? KNN_THREADS : 64 * SPLIT) void hdq_coa
     for (int r = 0; r < 3; ++r) tp[r] = Ai[3 * r] * q[0] + Ai[3 * r + 1] * q[1] + Ai[3 * r + 2] * q[2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) bp[r] = M[12 + 4 * r] * tp[0] + M[12 + 4 * r + 1] * tp[1] + M[12 + 4 * r + 2] * tp[2] + M[12 + 4 * r + 3];
+    if (fine2) {
+        out.fine_idx2[slot] = i;
+        out.bpts2[3 * slot] = bp[0]; out.bpts2[3 * slot + 1] = bp[1]; out.bpts2[3 * slot + 2] = bp[2];
+        return;
+    }
     out.fine_idx[slot] = i;
     out.bpts[3 * slot] = bp[0]; out.bpts[3 * slot + 1] = bp[1]; out.bpts[3 * slot + 2] = bp[2];
     if (out.mats) {

@@ -33,6 +33,12 @@ struct HdqOut {
     int* fine_idx;        // slot -> point
     float* bpts;          // slot x 3
     float* mats;          // slot x 24 or nullptr
+    // optional second fine list (the key-light tier, ra_config.key_light_share): fine points of rays towards a light with key[light] != 0
+    // (RaySet mode 2) are compacted into fine_idx2 / bpts2 through fine_count2 instead — the list the compensated kernel answers
+    const unsigned char* key;   // nullable: n_lights flags
+    int* fine_count2;
+    int* fine_idx2;
+    float* bpts2;
     float* raw_zero;      // nullable: n x raw_C rows that non-fine points zero (Network.forward's zeros outside dist_th)
     int raw_C;
     // debug (nullable): per point
@@ -121,11 +127,6 @@ struct ShadowGen {
     int* ray_slot;        // ray -> slot*L + light (where occ lands)
     float *near_, *far_;
     int* ray_count;
-    // the key-light tier (ra_config.key_light_share): rays towards lights with key[l] != 0 go to a second list instead
-    const unsigned char* key;     // nullable: L flags
-    int *k_ray_pix, *k_ray_light, *k_ray_slot;
-    float *k_near, *k_far;
-    int* k_ray_count;
 };
 // key[l] = light l holds at least the fraction max(share, 4 / L) of a probe's power under any of the frame's probes — the kmax lights with
 // the largest such share at most.  smax (L floats): every light's largest share so far; accumulate: the n probes join those of earlier calls

@@ -364,7 +364,6 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
     constexpr int ROUNDS = SG_LIGHTS / (TPB / 64);
     constexpr int NL = ROUNDS * (TPB / 64);               // lights per workgroup (= SG_LIGHTS)
     __shared__ int cnt[2][NL + 1];                        // traced rays per light among slots 0..31 / 32..63 of the group, then their offsets
-    __shared__ int kflag[NL + 1];                         // the light is a key light: its rays go to the second list (kflag[NL]: that list's base)
     float nrv[ROUNDS], frv[ROUNDS];
     unsigned tmask = 0;
     // A group is 64 hit pixels that are neighbours in the Morton order of the surface points: a patch of a few centimetres in a whole frame.
@@ -416,29 +415,26 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
         nrv[round] = nr; frv[round] = fr;
         if (trace) tmask |= 1u << round;
         const unsigned long long m = __ballot(trace);
-        if (lane == 0) { cnt[0][ll] = __popcll(m & 0xffffffffull); cnt[1][ll] = __popcll(m >> 32); kflag[ll] = (g.key && l < g.L) ? g.key[l] : 0; }
+        if (lane == 0) { cnt[0][ll] = __popcll(m & 0xffffffffull); cnt[1][ll] = __popcll(m >> 32); }
     }
     __syncthreads();
     // ONE atomic per workgroup for the traced-ray list (same-address atomics serialise: per wave they were the whole kernel
     // time); a wave's rays (one light x 64 neighbouring slots — or, for a group in two places, 32) stay contiguous
-    // (the rays towards key lights — ShadowGen::key — form a second list of the same layout, traced in compensated arithmetic)
     if (threadIdx.x == 0) {
-        int tot[2] = {0, 0};
+        int tot = 0;
         if (halves) {
             for (int hf = 0; hf < 2; ++hf)
-                for (int k = 0; k < NL; ++k) { int& t = tot[kflag[k] ? 1 : 0]; const int c = cnt[hf][k]; cnt[hf][k] = t; t += c; }
+                for (int k = 0; k < NL; ++k) { const int c = cnt[hf][k]; cnt[hf][k] = tot; tot += c; }
         } else {
             for (int k = 0; k < NL; ++k) {
-                int& t = tot[kflag[k] ? 1 : 0];
                 const int c0 = cnt[0][k], c1 = cnt[1][k];
-                cnt[0][k] = t; cnt[1][k] = t + c0; t += c0 + c1;
+                cnt[0][k] = tot; cnt[1][k] = tot + c0; tot += c0 + c1;
             }
         }
-        cnt[0][NL] = tot[0] ? atomicAdd(g.ray_count, tot[0]) : 0;
-        kflag[NL] = tot[1] ? atomicAdd(g.k_ray_count, tot[1]) : 0;
+        cnt[0][NL] = tot ? atomicAdd(g.ray_count, tot) : 0;
     }
     __syncthreads();
-    const int gbase = cnt[0][NL], kbase = kflag[NL];
+    const int gbase = cnt[0][NL];
 #pragma unroll
     for (int round = 0; round < ROUNDS; ++round) {
         const int ll = round * (TPB / 64) + wv;
@@ -447,14 +443,13 @@ __global__ __launch_bounds__(TPB) void shadow_gen_kernel(ShadowGen g) {
         if (trace) {
             const int hf = lane >> 5;
             const unsigned mh = hf ? (unsigned)(m >> 32) : (unsigned)m;
-            const bool key = kflag[ll] != 0;                  // wave-uniform: a wave handles one light per round
-            const int s = (key ? kbase : gbase) + cnt[hf][ll] + __popc(mh & ((1u << (lane & 31)) - 1u));
+            const int s = gbase + cnt[hf][ll] + __popc(mh & ((1u << (lane & 31)) - 1u));
             const int l = lc * SG_LIGHTS + ll;
-            (key ? g.k_ray_pix : g.ray_pix)[s] = r;
-            (key ? g.k_ray_light : g.ray_light)[s] = l;
-            (key ? g.k_ray_slot : g.ray_slot)[s] = h * g.L + l;
-            (key ? g.k_near : g.near_)[s] = nrv[round];
-            (key ? g.k_far : g.far_)[s] = frv[round];
+            g.ray_pix[s] = r;
+            g.ray_light[s] = l;
+            g.ray_slot[s] = h * g.L + l;
+            g.near_[s] = nrv[round];
+            g.far_[s] = frv[round];
         }
     }
     // rows of 32 lights: thread t -> (row = t / 32 + 8 k, light = t % 32)
@@ -944,10 +939,7 @@ void launch_light_dirs(const float* xyz, int L, float* ldir, hipStream_t s) {
 }
 
 void launch_shadow_gen(const ShadowGen& g, int P, hipStream_t s, bool counter_is_zero) {
-    if (!counter_is_zero) {
-        hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
-        if (g.key) hipMemsetAsync(g.k_ray_count, 0, sizeof(int), s);
-    }
+    if (!counter_is_zero) hipMemsetAsync(g.ray_count, 0, sizeof(int), s);
     if (P <= 0) return;
     const long long groups = ((long long)P + 63) / 64;
     const int lchunks = (g.L + SG_LIGHTS - 1) / SG_LIGHTS;

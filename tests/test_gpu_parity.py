@@ -20,16 +20,15 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
       from 64 to 51 dB, which is why the all-ray PSNR is only a sanity bound there.
       * through assert_contract: frame_relight, frame_relight_smooth, frame_novel (three probes), frame_ground, the multi-chunk and
         other-pose cases, the full-size sample, the volume frames (> 80 dB);
-      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 42 configuration overrides, one process per variant):
+      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 42 configuration overrides + round 6's 5 hard cases, one process per variant):
         25 relit windows, 8 ground-pass frames, 3 volume frames, 2 rotating-light sequences; rgb through assert_contract over ALL rays
         (no fp32-unstable ray on these windows: 60-96 dB, max 1.5e-4 .. 7.8e-3), the other maps to their tolerances;
         test_box_structure_is_morton_sorted pins the per-frame vertex order of the box structure against numpy;
-      * NOT through it: frame_novel_ground (max <= 2e-2 and at most 3 elements over 1e-2: one interior pixel of `main` sits at 1.1e-2, the
-        plain-f16 shadow rays' error amplified by sharp / (2 t), see below) and the full 512 x 512 frame against its all-compensated twin
-        (test_full_frame_shadow_tier_is_harmless: 2 of 19 929 hit pixels over 1e-2, max 1.3e-2).  Round 5 built the adaptive re-query
-        of amplified penumbra candidates the round-4 verdict asked for and measured it (profiles/r05_shadow_requery.txt): 11-29 % of the
-        fine queries qualify, the evaluation error is only ~40 % of the pixel error (the rest is the rays' step positions, which a
-        re-evaluated candidate does not change), 2 -> 1 pixels over 1e-2 — not shipped; the two tests keep their documented bounds.
+      * round 6: frame_novel_ground (80.5-84.7 dB, max 1.9e-3 over all pixels; up to round 5: one pixel at 1.1e-2) and the full 512 x 512 frame
+        against its all-compensated twin (test_full_frame_shadow_tier_is_harmless: max 9.3e-3, no pixel over 1e-2; round 5: 1.3e-2, 2 pixels)
+        now hold the contract outright: the shadow rays towards the frame's key lights are traced in compensated arithmetic
+        (cfg.key_light_share, csrc/ra_trace.hip key_lights_kernel).  The reference-made hard cases (test_hard_case_switch_matrix: a body
+        part shadowing the body at distance under a key light, trained-like weights) are what showed the need: profiles/r06_hard_cases.txt.
       History: on the SURVEY 8d body (white noise in the skinning logits -> the world -> big-pose warp jumps by ~1 cm between neighbouring
       query points, the REFERENCE's trace ends in a limit cycle on ~9 % of the hit rays) plain 16-bit operands reach 50.6 dB / max 4.7e-2
       (tests/golden/precision_floor.json, tools/precision_floor.py); fp32 itself IS stable on all but ~0.5 % of those rays
@@ -100,6 +99,9 @@ def test_native_library_is_loaded(relight):
     """the path under test is the in-tree HIP extension, not a torch fallback"""
     maps = open('/proc/self/maps').read()
     assert 'librelightableavatar_hip.so' in maps
+    # ... and the cooperative small-launch distance kernel (K3CC) passed its on-device self-test: a miscompiled K3CC would silently degrade
+    # every small launch to K3C's 4-wave tiles (same results, slower)
+    assert relight[4].k3cc_enabled()
 
 
 def test_mlp_stage(ops, relight):
@@ -825,8 +827,9 @@ def test_full_size_properties():
 
 
 def test_full_frame_shadow_tier_is_harmless():
-    """The tier choice at FULL size, on every pixel: BASELINE's 512 x 512 frame with the shipped tiers (surface trace compensated, the 5 M
-    shadow rays on plain f16 operands: cfg.trace_precision 1) against the same frame with EVERY distance query compensated
+    """The tier choice at FULL size, on every pixel: BASELINE's 512 x 512 frame with the shipped tiers (surface trace and the shadow rays
+    towards the key lights compensated, the other 5 M shadow rays on plain f16 operands: cfg.trace_precision 1) against the same frame with
+    EVERY distance query compensated
     (trace_precision 2: fp32-accurate shadows, 3 x their MFMA work).  The surface trace is the same arithmetic in both, so the hit masks
     and surface points must be identical, and what plain f16 shadows cost must stay far inside the contract."""
     from relightableavatar_amd.renderer import make_renderer
@@ -847,10 +850,11 @@ def test_full_frame_shadow_tier_is_harmless():
     n2, n3 = int((pe > 1e-2).sum()), int((pe > 5e-3).sum())
     print(f'512 x 512, shadows plain f16 vs compensated: rgb PSNR {p:.1f} dB over all {e.shape[1]} in-box rays, {ph:.1f} dB over the {int(hit.sum())} hit pixels, '
           f'max |diff| {float(e.max()):.2e}, pixels over 1e-2: {n2}, over 5e-3: {n3}')
-    # measured: 64.3 dB over the 19 929 hit pixels, max 1.3e-2, ONE pixel over 1e-2 (a DFSS penumbra value is d * sharp / (2 t): near the
-    # surface, t ~ 5 cm and sharp <= 29 amplify the 6e-5 distance error of plain f16 operands ~300 x per light): the max <= 1e-2 half of the
-    # contract holds on 99.99 % of a full frame's pixels, not on every one; compensating the shadow rays too would cost 2 x the frame
-    assert ph >= 60.0 and float(e.max()) <= 2e-2 and n2 <= 0.0005 * int(hit.sum()) and n3 <= 0.005 * int(hit.sum())
+    # Round 6, with the key-light tier (cfg.key_light_share: the learned map's lobes make 3 of its 512 lights key lights): 64.5 dB over the
+    # 19 929 hit pixels, max 9.3e-3, NO pixel over 1e-2 — SURVEY.md:409's max half holds on every pixel of BASELINE's frame against the
+    # all-compensated frame.  Round 5 (every shadow ray plain f16): 64.3 dB, max 1.3e-2, 2 pixels over 1e-2 (a DFSS penumbra value is
+    # d * sharp / (2 t): near the surface, t ~ 5 cm and sharp <= 29 amplify the 6e-5 distance error of plain f16 operands ~300 x per light).
+    assert ph >= 60.0 and float(e.max()) <= 1e-2 and n2 == 0 and n3 <= 0.005 * int(hit.sum())
 
 
 def test_full_size_sample_meets_the_contract():
@@ -1631,9 +1635,10 @@ def test_frame_novel_ground(golden):
         assert o.rgb_map.shape == (1, H * H, 3)
         p, mx = psnr(o.rgb_map, sub['rgb_map']), float(err(o.rgb_map, sub['rgb_map']).max())
         print(f'frame_novel_ground {name}: rgb PSNR {p:.1f} dB, max {mx:.2e}')
-        # 100 human pixels at 1.7 cm per pixel: one interior pixel whose brightest light grazes the body sits at 1.1e-2 in `main`
-        # (a single light's visibility changing by 0.2 moves the tone-mapped value that far); everything else is below 3e-3
-        assert p >= 60.0 and mx <= 2e-2 and int((err(o.rgb_map, sub['rgb_map']) > 1e-2).sum()) <= 3
+        # SURVEY.md:409's contract over ALL pixels.  Round 6: 80.5-84.7 dB, max 1.1e-3 .. 1.9e-3.  Up to round 5 one interior pixel of `main`
+        # sat at 1.1e-2 (its brightest light grazes the body: that light's visibility off by 0.2 on plain f16 operands) and this test
+        # asserted max <= 2e-2, <= 3 elements over 1e-2; the brightest lights are key lights now (cfg.key_light_share)
+        assert p >= 60.0 and mx <= 1e-2
         assert psnr(o.shade_map, sub['shade_map']) >= 50.0 and float(err(o.spec_map, sub['spec_map']).max()) < 1e-2
         assert float(err(o.albedo_map, sub['albedo_map']).max()) < 2e-3 and float(err(o.acc_map, sub['acc_map']).max()) < 2e-2
     assert float((out.probe00.rgb_map - out.probe01.rgb_map).abs().max()) > 0.05
