@@ -193,6 +193,7 @@ SWITCH_VARIANTS.update({
     'v_bg': {'bg_brightness': 0.5},
     'v_clip': {'clip_near': 1.7, 'clip_far': 2.4},
     'v_s16_chunks': {'n_samples': 16, 'render_chunk_size': 24},
+    'v_sharp_weights': {'@weights_kind': 'sharp'},      # round 6: the trained-like weights through the volume path (every sample a full query: normals + colour net)
 })
 VOLUME_H, VOLUME_CROP = 128, 8
 # and the novel-light renderer's rotating-light sequence (novel_light_sphere_tracing.py:163-171, relight_utils.py:55-110): names start with
@@ -443,7 +444,7 @@ def gen_switch(cfg, synthetic, variant, out_path):
         return
     if variant.startswith('v_'):
         my_cfg = make_cfg('anisdf', n_samples=64)
-        sd = synthetic.make_state_dict(0, relight=False, cfg=my_cfg)
+        sd = synthetic.make_state_dict(0, relight=False, cfg=my_cfg, kind=SWITCH_VARIANTS[variant].get('@weights_kind', 'init'))
         from lib.networks.deform.base_network import Network
         from lib.networks.renderer import base_renderer
         net = Network()

@@ -269,7 +269,7 @@ def test_ground_switch_matrix(golden, name):
     assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > 60
 
 
-VOLUME_SWITCH_NAMES = ['v_bg', 'v_clip', 'v_s16_chunks']
+VOLUME_SWITCH_NAMES = ['v_bg', 'v_clip', 'v_s16_chunks', 'v_sharp_weights']
 NOVEL_SWITCH_NAMES = ['n_rotate', 'n_rotate_ground', 'n_only_visibility']
 
 
@@ -315,7 +315,7 @@ def test_novel_switch_matrix(golden, name):
 
 def volume_switch_cfg(overrides, **kw):
     cfg = make_cfg('anisdf', n_samples=64, **kw)
-    cfg.update(overrides)
+    cfg.update({k: v for k, v in overrides.items() if not k.startswith('@')})
     return cfg
 
 
@@ -325,7 +325,7 @@ def test_volume_switch_matrix(golden, name):
     count over several render chunks"""
     ref = golden('switches.npz')
     cfg = volume_switch_cfg(switch_variants(ref)[name])
-    net = O.OracleNet(synthetic.make_state_dict(0, relight=False, cfg=cfg), cfg)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=False, cfg=cfg, kind=switch_variants(ref)[name].get('@weights_kind', 'init')), cfg)
     H = int(ref['volume_H'])
     batch = synthetic.make_batch(H, H, seed=0, posed=True, crop=int(ref['volume_crop']), skin_noise=0.0)
     out = O.render_volume(net, batch)
