@@ -458,6 +458,30 @@ def test_no_unsafe_packed_fp32_in_the_shipped_objects():
     assert 'ra_hdq.o' in report           # the scan sees device code at all (the coarse level's hand-written packed fp32)
 
 
+def test_packed_fp32_gate_fails_closed(tmp_path):
+    """the link-time gate must not pass when it could not look (advisor, round 5): something that is no object file, a host-only object that
+    claims a .hip source, an architecture the objects hold no code for — each is an error, not 'no unsafe instruction found'"""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import check_packed_fp32 as C
+    junk = tmp_path / 'junk.o'
+    junk.write_bytes(b'not an object file')
+    with pytest.raises(C.CheckError):
+        C.check([str(junk)])
+    objs = sorted(__import__('glob').glob(os.path.join(REPO, 'relightableavatar_amd', 'csrc', 'ra_image.o')))
+    if not objs:
+        pytest.skip('library objects not built in-tree')
+    with pytest.raises(C.CheckError, match='no device code object for gfx90a'):
+        C.check(objs, arch='gfx90a')
+    # a host-only object next to a .hip source of the same name: device code is missing, not absent by design
+    import subprocess
+    src = tmp_path / 'k.hip'
+    src.write_text('int f() { return 1; }\n')
+    obj = tmp_path / 'k.o'
+    subprocess.run(['g++', '-x', 'c++', '-c', str(src), '-o', str(obj)], check=True)
+    with pytest.raises(C.CheckError, match='holds no device code'):
+        C.check([str(obj)])
+
+
 def test_default_config_matches_the_python_defaults():
     """ra_default_config() (no ctx, no GPU) hands a C caller the documented defaults — a zero-initialised ra_config is NOT the default
     (trace_precision 0, clip_far 0: rejected by ra_set_config) — and they are the values make_cfg('relight') sends through the binding."""
