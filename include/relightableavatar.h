@@ -241,6 +241,12 @@ int ra_gather_rays(int device, const long long* idx_dev, int n, const float* ray
 int ra_scatter_rows(int device, const float* src_dev, const long long* src_idx_dev, const long long* dst_idx_dev, long long n, int C,
                     float* dst_dev, void* stream);
 
+/* Marks the start of one top-level render (Renderer.render: every chunk call of one frame follows).  The library numbers a frame's render
+ * calls from ra_set_frame to match each with the counts the same call found in an earlier frame (launch-variant hints: a pure speed aid);
+ * a caller that renders the SAME frame state again and again without ra_set_frame (a cached frame, a turntable of cameras) calls this
+ * instead, or its calls run out of numbered slots after 64 and lose their hints.  Optional; never changes results. */
+int ra_begin_render(ra_ctx* ctx);
+
 /* The key lights of the current frame (ra_config.key_light_share), named by the caller: n probes of probe_h x probe_w x 3 (device) — every
  * probe the frame's cached visibility will be shaded with.  ra_render_sphere_chunk / ra_render_ground_chunk derive the key lights from the
  * probe they shade with; a renderer that traces once and re-shades under OTHER probes afterwards (novel_light_sphere_tracing.py:163-213:

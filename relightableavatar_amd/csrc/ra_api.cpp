@@ -702,6 +702,12 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
     return 0;
 }
 
+int ra_begin_render(ra_ctx* c) {
+    RA_CHECK(c, "ra_begin_render: null ctx");
+    c->call_no = 0;          // render calls are numbered from here (launch-variant hints: the k-th call of a frame reads the k-th call's counts of an earlier one)
+    return 0;
+}
+
 int ra_set_key_probes(ra_ctx* c, const float* probes, int n, int ph, int pw, int accumulate, void* stream) {
     RA_CHECK(c && n >= 0 && (n == 0 || (probes && ph > 0 && pw > 0)), "ra_set_key_probes: bad arguments");
     if (n == 0) { c->key_external = false; c->key_valid = false; return 0; }

@@ -239,6 +239,10 @@ class Engine:
         check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
                                               probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
 
+    def begin_render(self):
+        """one top-level render starts: its chunk calls are numbered from here (launch-variant hints; ra_begin_render)"""
+        check(self.lib.ra_begin_render(self.ctx), 'ra_begin_render')
+
     def k3cc_enabled(self) -> bool:
         """the cooperative small-launch distance kernel passed its on-device self-test and is in use (ra_k3cc_enabled)"""
         return bool(self.lib.ra_k3cc_enabled(self.ctx))

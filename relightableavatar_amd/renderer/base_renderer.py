@@ -19,6 +19,7 @@ class Renderer(nn.Module):
     def render(self, batch):
         cfg = self.cfg
         eng = self.net.set_frame(batch)
+        eng.begin_render()
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
         ray_o, ray_d = f(batch.ray_o), f(batch.ray_d)

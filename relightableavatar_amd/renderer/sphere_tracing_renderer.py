@@ -68,6 +68,7 @@ class Renderer(nn.Module):
                                       'the novel-light re-shade (the reference fails there too)')
         only_vis = bool(cfg.get('only_visibility', False)) and bool(cfg.relighting)
         eng = self.net.set_frame(batch)
+        eng.begin_render()
         dev = eng.device
         f = lambda t: t[0].to(dev, torch.float32).contiguous()
         ray_o, ray_d, near, far = f(batch.ray_o), f(batch.ray_d), f(batch.near), f(batch.far)
