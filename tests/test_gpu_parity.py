@@ -1267,6 +1267,37 @@ def test_launch_variant_hints_change_speed_only():
     assert wide[0] + narrow[0] == wide[-1] + narrow[-1]            # ... and nothing else changed
 
 
+def test_stale_hints_cost_no_rays_and_no_cliff():
+    """Launch-variant hints come from an EARLIER frame.  After a camera cut (here: three 64 x 64 frames, then a 512 x 512 one through the
+    same context) the counts are two orders of magnitude too small: the frame must be bit-identical to the one a context with matching
+    hints renders, and — since round 6 the hint picks the workgroup WIDTH only, the grid is made for at least an eighth of the host-side
+    bound (csrc/ra_common.hpp mlp_grid) — it costs the narrow variants' lower rate, not a handful of workgroups on millions of points."""
+    from relightableavatar_amd.renderer import make_renderer
+    cfg, net, dev = build('relight')
+    rend = make_renderer(cfg, net)
+    big = lambda: synthetic.to_device(synthetic.make_batch(512, 512, seed=0, posed=True), dev)
+    small = lambda: synthetic.to_device(synthetic.make_batch(64, 64, seed=0, posed=True), dev)
+
+    def timed(batch):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = rend.render(batch)
+        b.record()
+        torch.cuda.synchronize()
+        return {k: out[k].clone() for k in ('rgb_map', 'acc_map', 'shade_map')}, a.elapsed_time(b)
+    timed(big())                                   # allocations, first launches
+    timed(big())
+    want, t_good = timed(big())                    # hints of a frame like itself
+    for _ in range(3):
+        timed(small())                             # the same call slots now hold a 64 x 64 frame's counts
+    got, t_stale = timed(big())
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    print(f'512 x 512 frame with matching hints {t_good:.1f} ms, with the hints of a 64 x 64 frame {t_stale:.1f} ms')
+    assert t_stale < 4.0 * t_good, (t_good, t_stale)
+
+
 def test_frames_in_flight_are_bit_identical():
     """relightableavatar_amd/pipeline.py: frames rendered two at a time on two HIP streams (contexts sharing a gate that serialises
     their light-visibility stages) equal the frames rendered one after the other, bit for bit — alternating poses, so that a frame
