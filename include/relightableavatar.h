@@ -463,6 +463,8 @@ int ra_map_to_image(ra_ctx* ctx, const ra_image_params* p, const float* a_dev, c
 
 /* ---- test hooks: stage outputs for the parity tests (tests/test_gpu_*.py); not used by renderers ---- */
 /* resd + sdf MLPs on given big-pose points: resd n x 3, sdf n, feat n x 256 (any may be NULL) */
+/* the current frame's key lights (ra_config.key_light_share): n_lights flags and every light's largest share of a probe's power */
+int ra_debug_key_lights(ra_ctx* ctx, unsigned char* key_dev, float* share_dev, void* stream);
 int ra_debug_mlp(ra_ctx* ctx, const float* bpts_dev, int n, float* resd, float* sdf, float* feat, void* stream);
 /* full kernel with identity warp: d sdf/d bpts n x 3, sdf n, feat n x 256, raw n x C */
 int ra_debug_full(ra_ctx* ctx, const float* bpts_dev, int n, float* grad, float* sdf, float* feat, float* raw, void* stream);

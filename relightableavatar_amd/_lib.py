@@ -116,6 +116,7 @@ SYMBOLS = {
     'ra_reshade': (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
     'ra_k3cc_enabled': (C.c_int, [C.c_void_p]),
     'ra_begin_render': (C.c_int, [C.c_void_p]),
+    'ra_debug_key_lights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ra_scatter_rows': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     'ra_gather_rays': (C.c_int, [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9),
     'ra_set_key_probes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

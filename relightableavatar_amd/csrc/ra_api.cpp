@@ -365,9 +365,9 @@ void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s, int grid_slots 
 }
 
 // which distance queries run in compensated arithmetic (ra_config.trace_precision): the surface trace from 1 on, everything at 2
-// (Q_KEY: the light-visibility rays towards the frame's key lights, ra_config.key_light_share)
-enum { Q_OTHER = 0, Q_SURFACE = 1, Q_KEY = 2 };
-bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what != Q_OTHER); }
+// (the light-visibility rays towards the frame's key lights join them through hdq_pass's second fine list: ra_config.key_light_share)
+enum { Q_OTHER = 0, Q_SURFACE = 1 };
+bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what == Q_SURFACE); }
 constexpr int KEY_LIGHTS_MAX = 24;       // per frame; bounds the second ray list of a light-visibility stage (rays <= pixels x this) and the tier's cost
 bool key_tier(const ra_ctx* c) { return c->cfg.trace_precision == 1 && c->cfg.key_light_share > 0.f && c->n_lights > 0; }
 // the frame's key-light flags from the probe a render call shades with — unless the caller named the frame's probes itself (ra_set_key_probes)
@@ -699,6 +699,15 @@ static int light_visibility_stage(ra_ctx* c, const float* surf, const float* nor
     if (c->gate) { RA_HIP(hipEventRecord(c->gate->done, s)); c->gate->armed = true; }
     *lvis_out = lvis;
     *ldot_out = ldot;
+    return 0;
+}
+
+int ra_debug_key_lights(ra_ctx* c, unsigned char* key_dev, float* share_dev, void* stream) {
+    RA_CHECK(c && key_dev && share_dev, "ra_debug_key_lights: null argument");
+    RA_CHECK(c->key_valid && c->n_lights > 0, "ra_debug_key_lights: no key lights have been computed (ra_set_key_probes, or a render call with a probe)");
+    RA_HIP(hipSetDevice(c->device));
+    RA_HIP(hipMemcpyAsync(key_dev, c->key_mask.p, (size_t)c->n_lights, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    RA_HIP(hipMemcpyAsync(share_dev, c->key_share.p, (size_t)c->n_lights * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 

@@ -239,6 +239,13 @@ class Engine:
         check(self.lib.ra_render_ground_chunk(self.ctx, _ptr(ray_o), _ptr(ray_d), _ptr(acc), P, bb, _ptr(probe), probe.shape[0],
                                               probe.shape[1], C.byref(params), C.byref(go), self.stream), 'ra_render_ground_chunk')
 
+    def debug_key_lights(self, n_lights):
+        """(bool mask, share) of the frame's key lights (test hook)"""
+        key = torch.empty(n_lights, dtype=torch.uint8, device=self.device)
+        share = torch.empty(n_lights, dtype=torch.float32, device=self.device)
+        check(self.lib.ra_debug_key_lights(self.ctx, _ptr(key), _ptr(share), self.stream), 'ra_debug_key_lights')
+        return key.bool(), share
+
     def begin_render(self):
         """one top-level render starts: its chunk calls are numbered from here (launch-variant hints; ra_begin_render)"""
         check(self.lib.ra_begin_render(self.ctx), 'ra_begin_render')

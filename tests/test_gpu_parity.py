@@ -1896,6 +1896,52 @@ def test_full_size_properties_config5():
     assert float((o1[names[3]].rgb_map - out[names[3]].rgb_map).abs().max()) == 0.0
 
 
+def test_key_lights_match_the_rule(relight):
+    """csrc/ra_trace.hip key_lights_kernel against the rule's restatement (oracle.key_lights): a light is a key light when it holds >=
+    max(key_light_share, 4 / L) of a probe's power under ANY of the frame's probes, the 24 lights with the largest such share at most;
+    probes of two sizes accumulate (the learned 32 x 64 map + novel 16 x 32 probes), and n = 0 returns to per-call key lights"""
+    from oracle import ra_oracle as O
+    cfg, net, dev, body, eng = relight
+    sd = synthetic.make_state_dict(0, relight=True, cfg=cfg)
+    on = O.OracleNet(sd, cfg)
+    L = cfg.env_h * cfg.env_w
+    lights = synthetic.make_novel_lights(8, 0)
+    novel = torch.stack([lights[k].probe[0] for k in lights])                 # 7 lognormal + 1 OLAT-style
+    front = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg, env='front'), cfg).global_env_map
+    for probes_sets in ([on.global_env_map], [front], [on.global_env_map, novel], [novel[-1:]]):
+        eng.set_key_probes([p.to(dev) for p in probes_sets])
+        key, share = eng.debug_key_lights(L)
+        flat = [p if p.ndim == 3 else None for p in probes_sets]
+        allp = [p for p in probes_sets if p.ndim == 3] + [q for p in probes_sets if p.ndim == 4 for q in p]
+        want = O.key_lights(on, allp, cfg.key_light_share)
+        d = normalize_rows(on.light_xyz.reshape(-1, 3))
+        smax = torch.zeros(L)
+        for pr in allp:
+            w = (O.sample_envmap_image(pr, d).mean(-1) * on.light_area.reshape(-1)).clamp_min(0)
+            smax = torch.maximum(smax, w / w.sum())
+        assert float((share.cpu() - smax).abs().max()) < 1e-6 * float(smax.max()) + 1e-9
+        thr = max(cfg.key_light_share, 4.0 / L)
+        clear = (smax - thr).abs() > 1e-5 * thr                               # lights not sitting on the threshold itself
+        got = key.cpu()
+        if int(want.sum()) < 24:                                              # below the cap the rule is a plain threshold
+            assert bool((got == want)[clear].all()), (int(got.sum()), int(want.sum()))
+        else:                                                                 # at the cap: the 24 largest shares
+            assert int(got.sum()) == 24 and float(smax[got].min()) >= float(smax[~got].max()) - 1e-7
+        print(f'{len(allp)} probe(s): {int(got.sum())} key lights, largest share {float(smax.max()):.3f}')
+    eng.set_key_probes([])
+    with pytest.raises(_lib_error()):
+        eng.debug_key_lights(L)
+
+
+def _lib_error():
+    from relightableavatar_amd import _lib
+    return _lib.RaError
+
+
+def normalize_rows(v):
+    return v / (v.norm(dim=-1, keepdim=True) + 1e-8)
+
+
 def test_config5_key_light_tier_at_full_size():
     """cfg.key_light_share at BASELINE config 5's size (1024 x 1024, 8 probes on the smooth body: seven heavy-tailed lognormal ones and an
     OLAT-style one, a light of 100 over an ambient 0.25): every probe's frame with round 5's tiers (all shadow rays plain f16), with the
