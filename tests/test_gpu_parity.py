@@ -1919,7 +1919,7 @@ def test_key_lights_match_the_rule(relight):
         for pr in allp:
             w = (O.sample_envmap_image(pr, d).mean(-1) * on.light_area.reshape(-1)).clamp_min(0)
             smax = torch.maximum(smax, w / w.sum())
-        assert float((share.cpu() - smax).abs().max()) < 1e-6 * float(smax.max()) + 1e-9
+        assert float((share.cpu() - smax).abs().max()) < 1e-5 * float(smax.max()) + 1e-9          # fp32 sums in another order
         thr = max(cfg.key_light_share, 4.0 / L)
         clear = (smax - thr).abs() > 1e-5 * thr                               # lights not sitting on the threshold itself
         got = key.cpu()
