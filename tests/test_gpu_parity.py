@@ -858,7 +858,7 @@ def test_full_frame_shadow_tier_is_harmless():
     n2, n3 = int((pe > 1e-2).sum()), int((pe > 5e-3).sum())
     print(f'512 x 512, shadows plain f16 vs compensated: rgb PSNR {p:.1f} dB over all {e.shape[1]} in-box rays, {ph:.1f} dB over the {int(hit.sum())} hit pixels, '
           f'max |diff| {float(e.max()):.2e}, pixels over 1e-2: {n2}, over 5e-3: {n3}')
-    # Round 6, with the key-light tier (cfg.key_light_share: the learned map's lobes make 3 of its 512 lights key lights): 64.5 dB over the
+    # Round 6, with the key-light tier (cfg.key_light_share: the learned map's lobes make 5 of its 512 lights key lights): 64.5 dB over the
     # 19 929 hit pixels, max 9.3e-3, NO pixel over 1e-2 — SURVEY.md:409's max half holds on every pixel of BASELINE's frame against the
     # all-compensated frame.  Round 5 (every shadow ray plain f16): 64.3 dB, max 1.3e-2, 2 pixels over 1e-2 (a DFSS penumbra value is
     # d * sharp / (2 t): near the surface, t ~ 5 cm and sharp <= 29 amplify the 6e-5 distance error of plain f16 operands ~300 x per light).
