@@ -202,6 +202,9 @@ SWITCH_VARIANTS.update({
     'n_rotate': {'vis_novel_light': True, 'vis_rotate_light': True, 'rotate_ratio': 1, 'test_light': ['main']},
     'n_only_visibility': {'vis_novel_light': True, 'only_visibility': True, 'test_light': ['main']},      # the cached cosines become 1 (:720-722, :758-759)
     'n_rotate_ground': dict(GROUND_BASE, **{'vis_novel_light': True, 'vis_rotate_light': True, 'rotate_ratio': 2, 'test_light': []}),
+    # round 6: the hard-case body through the novel-light renderer — traced once under the learned map, re-shaded under a lognormal probe and
+    # an OLAT-style one (a single light of 100 over an ambient 0.25): the key lights of ALL the frame's probes matter for the ONE trace
+    'n_split_body': dict(SPLIT_BODY, **SPLIT_WINDOW, **{'vis_novel_light': True, 'test_light': ['main'], 'obj_lvis.iter': 12, '@n_novel_lights': 2}),
 })
 NOVEL_H, NOVEL_CROP, NOVEL_GROUND_H = 128, 6, 16
 NOVEL_HEADINGS = (0, 5, 16, 31)
@@ -416,6 +419,27 @@ def gen_switch(cfg, synthetic, variant, out_path):
     """one relit frame of the reference under SWITCH_VARIANTS[variant] (cfg already carries the overrides; nothing of the reference's
     hot path is imported yet, so values bound as default arguments see them too)"""
     from relightableavatar_amd.config import make_cfg
+    if variant == 'n_split_body':
+        from lib.networks.renderer import novel_light_sphere_tracing
+        from lib.networks.relight.relight_network import Network
+        my_cfg = make_cfg('novel_light')
+        bkw = {k[1:]: v for k, v in SWITCH_VARIANTS[variant].items() if k.startswith('@')}
+        net = Network()
+        missing, unexpected = net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=my_cfg, env=bkw.pop('env', 'back')), strict=False)
+        assert not unexpected and not [m for m in missing if 'embedder' not in m], (missing, unexpected)
+        net.eval()
+        batch = to_ref_batch(synthetic.make_batch(SWITCH_H, SWITCH_H, **{**dict(seed=0, posed=True, crop=SWITCH_CROP, skin_noise=0.0), **bkw}))
+        with torch.no_grad():
+            out = novel_light_sphere_tracing.Renderer(net).render(batch)
+        names = [k for k in out if k != 'diff']
+        arrs = {'names': np.asarray(json.dumps(names))}
+        for name in names:
+            for k in ('rgb_map', 'shade_map', 'spec_map', 'albedo_map', 'acc_map', 'norm_map', 'surf_map'):
+                if k in out[name]:
+                    arrs[f'{name}/{k}'] = out[name][k].detach().cpu().numpy()
+        np.savez_compressed(out_path, **arrs)
+        print('switch', variant, names, {k: a.shape for k, a in arrs.items() if k.startswith('probe01')})
+        return
     if variant.startswith('n_'):
         from lib.networks.renderer import novel_light_sphere_tracing
         from lib.networks.relight.relight_network import Network

@@ -562,7 +562,7 @@ def test_frame_relight_smooth_meets_the_contract(golden):
 
 # ---- the hot path's configuration switches: the reference under each override (tests/golden/switches.npz, one process per variant;
 # tests/test_oracle_frames.py pins the oracle on the same file)
-from test_oracle_frames import (GROUND_SWITCH_NAMES, HARD_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, novel_switch_case,      # noqa: E402
+from test_oracle_frames import (GROUND_SWITCH_NAMES, HARD_NOVEL_NAMES, HARD_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, hard_novel_case, novel_switch_case,      # noqa: E402
                                 switch_batch, switch_batch_kw, switch_cfg, switch_state_dict, switch_variants, volume_switch_cfg)
 
 
@@ -702,6 +702,38 @@ def test_hard_case_switch_matrix(golden, name):
     lim = HARD_CASE_ROUND5_MAX.get(name, (1e-2, 0))
     assert res[0]['max'] <= lim[0] and res[0]['over'] <= lim[1], (name, res[0], lim)
     assert res[1]['max'] <= res[0]['max'] + 1e-3          # the key-light tier never makes a case worse
+
+
+@pytest.mark.parametrize('name', HARD_NOVEL_NAMES)
+def test_hard_case_novel_light(golden, name):
+    """The hard-case body through the novel-light renderer, against the reference's own frames: ONE trace under the learned map, re-shaded
+    under a lognormal probe and an OLAT-style one (a light of 100 over an ambient 0.25).  The frame's key lights are those of ALL its probes
+    (ra_set_key_probes, called by the renderer's mirror before the trace): with round 5's tiers the OLAT probe's frame is where plain-f16
+    shadow rays show; SURVEY.md:409's contract is asserted for the shipped tiers on every output."""
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('switches.npz')
+    dev = _dev()
+    case = 'switches.npz:split_body'          # the same window and surface trace as split_body
+    res = {}
+    for label, tp, share in HARD_CASE_TIERS:
+        cfg, env, mk, want, names = hard_novel_case(ref, name, mlp_dtype='f16', trace_precision=tp, key_light_share=share)
+        net = make_network(cfg)
+        net.load_state_dict(synthetic.make_state_dict(0, relight=True, cfg=cfg, env=env))
+        net = net.to(dev).eval()
+        out = make_renderer(cfg, net).render(synthetic.to_device(mk(), dev))
+        assert [k for k in out if k != 'diff'] == names
+        for out_name, maps in want.items():
+            ok = ~unstable_rays(case, out[out_name].rgb_map.shape[1])
+            e = err(out[out_name].rgb_map, maps['rgb_map'])[0]
+            r = dict(psnr=float(-10 * torch.log10((e[ok] ** 2).mean())), max=float(e[ok].max()), over=int((e[ok].amax(-1) > 1e-2).sum()))
+            res[(label, out_name)] = r
+            print(f'switches.npz / {name} / {out_name}, {label}: ' + ', '.join(f'{k} {v:.3g}' for k, v in r.items()))
+            assert r['psnr'] >= 50.0, (label, out_name, r)
+            if share > 0 or tp == 2:
+                assert_contract(out[out_name].rgb_map, maps['rgb_map'], case, f'switches.npz / {name} / {out_name} ({label})')
+    shipped, round5 = HARD_CASE_TIERS[1][0], HARD_CASE_TIERS[0][0]
+    assert max(res[(shipped, n)]['max'] for n in names) <= max(res[(round5, n)]['max'] for n in names) + 1e-3
 
 
 @pytest.mark.parametrize('name', VOLUME_SWITCH_NAMES)

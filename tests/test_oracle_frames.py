@@ -271,6 +271,7 @@ def test_ground_switch_matrix(golden, name):
 
 VOLUME_SWITCH_NAMES = ['v_bg', 'v_clip', 'v_s16_chunks', 'v_sharp_weights']
 NOVEL_SWITCH_NAMES = ['n_rotate', 'n_rotate_ground', 'n_only_visibility']
+HARD_NOVEL_NAMES = ['n_split_body']
 
 
 def novel_switch_case(ref, name):
@@ -340,7 +341,7 @@ def test_volume_switch_matrix(golden, name):
 def test_switch_matrix(golden, name):
     ref = golden('switches.npz')
     variants = switch_variants(ref)
-    assert sorted(variants) == sorted(SWITCH_NAMES + HARD_SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES)
+    assert sorted(variants) == sorted(SWITCH_NAMES + HARD_SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES + HARD_NOVEL_NAMES)
     cfg = switch_cfg(variants[name])
     bkw = switch_batch_kw(variants[name])
     net = O.OracleNet(switch_state_dict(bkw, cfg), cfg)
@@ -413,3 +414,44 @@ def test_hard_case_switch_matrix(golden, name):
         assert (sh < 0.02 * sh.max()).mean() > 0.1 and (sh > 0.5 * sh.max()).mean() > 0.05 and ((sh > 0.1 * sh.max()) & (sh < 0.5 * sh.max())).mean() > 0.1, name
     if name == 'split_body':         # ... and the long shadow rays matter: the default 4 iterations give another frame
         assert float(np.abs(sub['shade_map'] - ref['split_body_iter4.shade_map']).max()) > 0.05
+
+
+def hard_novel_case(ref, name, **kw):
+    """(cfg, batch factory, {output name: {map: array}}, names) of the novel-light hard case"""
+    import json
+    ov = switch_variants(ref)[name]
+    cfg = make_cfg('novel_light', vis_specular_map=True, **kw)
+    for k, v in ov.items():
+        if k.startswith('@'):
+            continue
+        node = cfg
+        parts = k.split('.')
+        for q in parts[:-1]:
+            node = node[q]
+        node[parts[-1]] = v
+    bkw = switch_batch_kw(ov)
+    env = bkw.pop('env', 'back')
+    mk = lambda: synthetic.make_batch(int(ref['H']), int(ref['H']), **{**dict(seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), **bkw})
+    want = {}
+    for k, v in ref.items():
+        if k.startswith(name + '.') and '/' in k:
+            out_name, key = k[len(name) + 1:].split('/')
+            want.setdefault(out_name, {})[key] = v
+    return cfg, env, mk, want, json.loads(str(ref[name + '.names']))
+
+
+@pytest.mark.parametrize('name', HARD_NOVEL_NAMES)
+def test_hard_case_novel_light(golden, name):
+    """the hard-case body through the novel-light renderer (novel_light_sphere_tracing.py:103-221): one trace under the learned map,
+    re-shaded under a lognormal and an OLAT-style probe"""
+    ref = golden('switches.npz')
+    cfg, env, mk, want, names = hard_novel_case(ref, name)
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=True, cfg=cfg, env=env), cfg)
+    out = O.render_novel_light(net, mk())
+    assert [k for k in out if not k.startswith('_')] == names == ['main', 'probe00', 'probe01']
+    for out_name, maps in want.items():
+        for k, tol in (('rgb_map', 3e-4), ('shade_map', 1e-3), ('spec_map', 2e-3), ('albedo_map', 2e-4), ('surf_map', 1e-4)):
+            if k in maps:
+                _cmp(out[out_name], maps, k, tol)
+        assert O.psnr(out[out_name].rgb_map, T(maps['rgb_map'])) > 90
+    assert float(np.abs(want['probe00']['rgb_map'] - want['probe01']['rgb_map']).max()) > 0.05
