@@ -84,7 +84,7 @@ typedef struct ra_config {
     float key_light_share;                    /* 0.0078 (default: four times the mean share of 512 lights); with trace_precision 1: the
                                                  light-visibility rays towards the frame's KEY LIGHTS are traced in compensated arithmetic like the
                                                  surface trace.  A light is a key light when it holds at least this fraction of a probe's power
-                                                 (radiance x solid angle) — and at least 4 / L — under any of the frame's probes; the 24 lights with
+                                                 (radiance x solid angle) — and at least 4 / L — under any of the frame's probes; the 48 lights with
                                                  the largest share at most, which bounds the tier's cost at ~10 % of the shadow rays.  A DFSS penumbra value is d * sharp / (2 t) (sphere_tracing_renderer.py:157-179): it
                                                  amplifies the 5e-5 distance error of plain f16 operands up to 500 x per light.  Summed over 512 lights
                                                  of comparable power the errors average out; under a key light that holds most of the power they do

@@ -739,7 +739,7 @@ def fp32_flip_probability(net: OracleNet, batch, rays, noise: float, trials: int
     return [float(v) / trials for v in flips.reshape(-1)]
 
 
-def key_lights(net: OracleNet, probes, share: float, kmax: int = 24):
+def key_lights(net: OracleNet, probes, share: float, kmax: int = 48):
     """the lights that hold at least the fraction max(share, 4 / L) of a probe's power (radiance x solid angle, channel mean) under any of
     `probes` (each (H, W, 3)): the rule of the key-light tier (csrc/ra_trace.hip key_lights_kernel)"""
     d = normalize(net.light_xyz.reshape(-1, 3))

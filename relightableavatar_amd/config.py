@@ -146,7 +146,7 @@ def default_cfg() -> dotdict:
     # 0 = plain 16-bit operands everywhere; 2 = compensated everywhere (validation)
     c.trace_precision = 1
     # with trace_precision 1: shadow rays towards the frame's key lights (each holds >= this fraction of a probe's power, four times the mean share of 512
-    # lights; the 24 strongest at most) are traced in compensated arithmetic too (ra_config.key_light_share; 0 = off, round 5's behaviour)
+    # lights; the 48 strongest at most) are traced in compensated arithmetic too (ra_config.key_light_share; 0 = off, round 5's behaviour)
     c.key_light_share = 0.0078
     c.k4_batch_slots = 0         # full queries per forward+backward launch pair (bounds the 4.9 KB/slot activation tape); 0 = 1 Mi
     return c

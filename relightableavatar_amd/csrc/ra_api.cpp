@@ -368,7 +368,7 @@ void k3_launch(ra_ctx* c, const MlpIO& io, int n, hipStream_t s, int grid_slots 
 // (the light-visibility rays towards the frame's key lights join them through hdq_pass's second fine list: ra_config.key_light_share)
 enum { Q_OTHER = 0, Q_SURFACE = 1 };
 bool precise(const ra_ctx* c, int what) { return c->cfg.trace_precision >= 2 || (c->cfg.trace_precision == 1 && what == Q_SURFACE); }
-constexpr int KEY_LIGHTS_MAX = 24;       // per frame; bounds the second ray list of a light-visibility stage (rays <= pixels x this) and the tier's cost
+constexpr int KEY_LIGHTS_MAX = 48;       // per frame; bounds the second ray list of a light-visibility stage (rays <= pixels x this) and the tier's cost
 bool key_tier(const ra_ctx* c) { return c->cfg.trace_precision == 1 && c->cfg.key_light_share > 0.f && c->n_lights > 0; }
 // the frame's key-light flags from the probe a render call shades with — unless the caller named the frame's probes itself (ra_set_key_probes)
 int key_mask_from(ra_ctx* c, const float* probe, int ph, int pw, hipStream_t s) {

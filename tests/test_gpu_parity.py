@@ -730,15 +730,12 @@ def test_hard_case_novel_light(golden, name):
             res[(label, out_name)] = r
             print(f'switches.npz / {name} / {out_name}, {label}: ' + ', '.join(f'{k} {v:.3g}' for k, v in r.items()))
             assert r['psnr'] >= 50.0, (label, out_name, r)
-            if tp == 2:
+            if share > 0 or tp == 2:
                 assert_contract(out[out_name].rgb_map, maps['rgb_map'], case, f'switches.npz / {name} / {out_name} ({label})')
     shipped, round5 = HARD_CASE_TIERS[1][0], HARD_CASE_TIERS[0][0]
-    # `main` (the learned map with its key light) and the OLAT probe: the contract with the shipped tiers; the lognormal probe has no key
-    # light to speak of — its power is spread over ~60 lights at 2-6 x the mean — and keeps ONE ray of 142 at 1.05e-2 in both 16-bit tiers
-    # (all-compensated: see the printed line): a measured miss of the max half by 5e-4, named here rather than hidden in a tolerance
-    for n_ in names:
-        lim = (1.1e-2, 1) if n_ == 'probe00' else (1e-2, 0)
-        assert res[(shipped, n_)]['max'] <= lim[0] and res[(shipped, n_)]['over'] <= lim[1], (n_, res[(shipped, n_)])
+    # measured (profiles/r06_hard_cases.txt): round 5's tiers main 58.2 dB / 1.16e-2, the lognormal probe 57.1 / 1.01e-2, OLAT 65.9 / 3.0e-3;
+    # shipped 71.0 / 2.5e-3, 63.7 / 4.5e-3, 68.1 / 1.8e-3.  (With at most 24 key lights per frame the lognormal probe, whose power is spread
+    # over ~60 lights at 2-6 x the mean, kept one ray at 1.05e-2: the learned map's key light had taken 14 of the 24; hence 48.)
     assert res[(shipped, 'main')]['max'] < 0.5 * res[(round5, 'main')]['max']
 
 
@@ -1975,7 +1972,7 @@ def test_full_size_properties_config5():
 
 def test_key_lights_match_the_rule(relight):
     """csrc/ra_trace.hip key_lights_kernel against the rule's restatement (oracle.key_lights): a light is a key light when it holds >=
-    max(key_light_share, 4 / L) of a probe's power under ANY of the frame's probes, the 24 lights with the largest such share at most;
+    max(key_light_share, 4 / L) of a probe's power under ANY of the frame's probes, the 48 lights with the largest such share at most;
     probes of two sizes accumulate (the learned 32 x 64 map + novel 16 x 32 probes), and n = 0 returns to per-call key lights"""
     from oracle import ra_oracle as O
     cfg, net, dev, body, eng = relight
@@ -2000,10 +1997,10 @@ def test_key_lights_match_the_rule(relight):
         thr = max(cfg.key_light_share, 4.0 / L)
         clear = (smax - thr).abs() > 1e-5 * thr                               # lights not sitting on the threshold itself
         got = key.cpu()
-        if int(want.sum()) < 24:                                              # below the cap the rule is a plain threshold
+        if int(want.sum()) < 48:                                              # below the cap the rule is a plain threshold
             assert bool((got == want)[clear].all()), (int(got.sum()), int(want.sum()))
-        else:                                                                 # at the cap: the 24 largest shares
-            assert int(got.sum()) == 24 and float(smax[got].min()) >= float(smax[~got].max()) - 1e-7
+        else:                                                                 # at the cap: the 48 largest shares
+            assert int(got.sum()) == 48 and float(smax[got].min()) >= float(smax[~got].max()) - 1e-7
         print(f'{len(allp)} probe(s): {int(got.sum())} key lights, largest share {float(smax.max()):.3f}')
     eng.set_key_probes([])
     with pytest.raises(_lib_error()):
@@ -2022,13 +2019,13 @@ def normalize_rows(v):
 def test_config5_key_light_tier_at_full_size():
     """cfg.key_light_share at BASELINE config 5's size (1024 x 1024, 8 probes on the smooth body: seven heavy-tailed lognormal ones and an
     OLAT-style one, a light of 100 over an ambient 0.25): every probe's frame with round 5's tiers (all shadow rays plain f16), with the
-    shipped tiers (+ the rays towards the frame's <= 24 key lights compensated) and with every distance query compensated.  The surface
+    shipped tiers (+ the rays towards the frame's <= 48 key lights compensated) and with every distance query compensated.  The surface
     trace is the same arithmetic in all three (identical hit masks).  What this size shows (profiles/r06_hard_cases.txt):
       * the DFSS state machine has discontinuities of its own (the accept conditions of the claybook estimate, :157-172; occ == 0 ends a
         ray): a 5e-5 distance error flips a few of a frame's 18 M shadow rays outright, and a flipped ray towards a light that holds 1-2 %
         of a heavy-tailed probe's power moves its pixel by 2e-2 .. 2e-1 — 14-35 of 71 492 hit pixels per probe with round 5's tiers;
-      * the key lights remove the flips that matter most: the OLAT probe goes from 21 pixels / 0.23 to <= 2 / 0.03, the others lose a
-        fifth of theirs on average (13-27 left), at 7 % of the fine queries compensated;
+      * the key lights (48 at most) remove the flips that matter most: the OLAT probe goes from 21 pixels / 0.23 to <= 2 / 0.03, the others
+        lose two fifths of theirs (9-17 left), at 11 % of the fine queries compensated;
       * max |err| <= 1e-2 on EVERY pixel of a heavy-tailed probe needs every ray compensated (trace_precision 2): per pixel the bound holds
         on >= 99.95 % of the hit pixels in both tiers, asserted below."""
     from relightableavatar_amd.renderer import make_renderer
@@ -2054,5 +2051,5 @@ def test_config5_key_light_tier_at_full_size():
     olat = names[-1]
     assert over['shipped'][olat] <= 3 and over['round5'][olat] >= 3 * max(over['shipped'][olat], 1), (over['round5'][olat], over['shipped'][olat])
     assert sum(over['shipped'].values()) < sum(over['round5'].values())
-    assert all(v <= 5e-4 * nh for v in over['shipped'].values()) and all(v <= 7e-4 * nh for v in over['round5'].values())      # measured: <= 27 / <= 35 of 71 492
-    assert comp['shipped'] < 0.12, comp            # 2 % (the surface trace) + the key lights' rays (24 lights at most)
+    assert all(v <= 4e-4 * nh for v in over['shipped'].values()) and all(v <= 7e-4 * nh for v in over['round5'].values())      # measured: <= 17 / <= 35 of 71 492
+    assert comp['shipped'] < 0.16, comp            # 2 % (the surface trace) + the key lights' rays (48 lights at most)
