@@ -195,6 +195,10 @@ SWITCH_VARIANTS.update({
     'v_s16_chunks': {'n_samples': 16, 'render_chunk_size': 24},
     'v_sharp_weights': {'@weights_kind': 'sharp'},      # round 6: the trained-like weights through the volume path (every sample a full query: normals + colour net)
 })
+# ... and through the sphere-tracing fast path of the AniSDF network (config 3: surface trace + full query + colour net, no relighting): s_
+SWITCH_VARIANTS.update({
+    's_sharp_weights': {'@weights_kind': 'sharp'},
+})
 VOLUME_H, VOLUME_CROP = 128, 8
 # and the novel-light renderer's rotating-light sequence (novel_light_sphere_tracing.py:163-171, relight_utils.py:55-110): names start with
 # n_; one probe with a full-resolution image, rotate_ratio * env_w headings re-shaded from one traced frame, four of them stored
@@ -300,7 +304,7 @@ def main():
     if mode == 'visual':
         gen_visual(cfg, synthetic)
         return
-    set_cfg(cfg, ('anisdf' if args.variant.startswith('v_') else 'relight') if mode == 'switch' else mode)
+    set_cfg(cfg, ('anisdf' if args.variant.startswith('v_') else ('sphere' if args.variant.startswith('s_') else 'relight')) if mode == 'switch' else mode)
     if mode == 'switch':
         cfg.vis_specular_map = True
         apply_overrides(cfg, SWITCH_VARIANTS[args.variant])
@@ -465,6 +469,22 @@ def gen_switch(cfg, synthetic, variant, out_path):
             arrs[f'{name}/probe'] = out[name].envmap.probe.detach().cpu().numpy()
         np.savez_compressed(out_path, **arrs)
         print('switch', variant, len(names), 'outputs;', {k: a.shape for k, a in arrs.items() if k.startswith('probe00-0005')})
+        return
+    if variant.startswith('s_'):
+        my_cfg = make_cfg('sphere_tracing')
+        sd = synthetic.make_state_dict(0, relight=False, cfg=my_cfg, kind=SWITCH_VARIANTS[variant].get('@weights_kind', 'init'))
+        from lib.networks.deform.base_network import Network
+        from lib.networks.renderer import sphere_tracing_renderer
+        net = Network()
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected and not [m for m in missing if 'embedder' not in m], (missing, unexpected)
+        net.eval()
+        batch = to_ref_batch(synthetic.make_batch(SWITCH_H, SWITCH_H, seed=0, posed=True, crop=SWITCH_CROP, skin_noise=0.0))
+        with torch.no_grad():
+            out = sphere_tracing_renderer.Renderer(net).render(batch)
+        arrs = {k: out[k].detach().cpu().numpy() for k in ('rgb_map', 'acc_map', 'depth_map', 'norm_map', 'surf_map', 'cpts_map', 'resd_map')}
+        np.savez_compressed(out_path, **arrs)
+        print('switch', variant, {k: a.shape for k, a in arrs.items()})
         return
     if variant.startswith('v_'):
         my_cfg = make_cfg('anisdf', n_samples=64)

@@ -562,7 +562,8 @@ def test_frame_relight_smooth_meets_the_contract(golden):
 
 # ---- the hot path's configuration switches: the reference under each override (tests/golden/switches.npz, one process per variant;
 # tests/test_oracle_frames.py pins the oracle on the same file)
-from test_oracle_frames import (GROUND_SWITCH_NAMES, HARD_NOVEL_NAMES, HARD_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES, hard_novel_case, novel_switch_case,      # noqa: E402
+from test_oracle_frames import (GROUND_SWITCH_NAMES, HARD_NOVEL_NAMES, HARD_SWITCH_NAMES, NOVEL_SWITCH_NAMES, SPHERE_SWITCH_NAMES, SWITCH_NAMES, VOLUME_SWITCH_NAMES,      # noqa: E402
+                                hard_novel_case, novel_switch_case,
                                 switch_batch, switch_batch_kw, switch_cfg, switch_state_dict, switch_variants, volume_switch_cfg)
 
 
@@ -737,6 +738,28 @@ def test_hard_case_novel_light(golden, name):
     # shipped 71.0 / 2.5e-3, 63.7 / 4.5e-3, 68.1 / 1.8e-3.  (With at most 24 key lights per frame the lognormal probe, whose power is spread
     # over ~60 lights at 2-6 x the mean, kept one ray at 1.05e-2: the learned map's key light had taken 14 of the 24; hence 48.)
     assert res[(shipped, 'main')]['max'] < 0.5 * res[(round5, 'main')]['max']
+
+
+@pytest.mark.parametrize('name', SPHERE_SWITCH_NAMES)
+def test_sphere_switch_matrix(golden, name):
+    """config 3's path (sphere tracing of the AniSDF network: surface trace, full query, colour net on the traced normals; no relighting)
+    with the trained-like weights, against the reference's frame: SURVEY.md:409's contract over all rays"""
+    from relightableavatar_amd.networks import make_network
+    from relightableavatar_amd.renderer import make_renderer
+    ref = golden('switches.npz')
+    dev = _dev()
+    ov = switch_variants(ref)[name]
+    cfg = make_cfg('sphere_tracing', mlp_dtype='f16')
+    net = make_network(cfg)
+    net.load_state_dict(synthetic.make_state_dict(0, relight=False, cfg=cfg, kind=ov.get('@weights_kind', 'init')))
+    net = net.to(dev).eval()
+    out = make_renderer(cfg, net).render(synthetic.to_device(synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0), dev))
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    assert bool(((out.acc_map.cpu() > 0) == (T(sub['acc_map']) > 0)).all())
+    p, mx = psnr(out.rgb_map, sub['rgb_map']), float(err(out.rgb_map, sub['rgb_map']).max())
+    print(f'switches.npz / {name}: rgb PSNR {p:.1f} dB, max {mx:.2e}; surf max {float(err(out.surf_map, sub["surf_map"]).max()):.2e}, normals max {float(err(out.norm_map, sub["norm_map"]).max()):.2e}')
+    assert p >= 50.0 and mx <= 1e-2
+    assert float(err(out.surf_map, sub['surf_map']).max()) < 1e-4 and float((err(out.norm_map, sub['norm_map']) < 2e-2).float().mean()) > 0.99
 
 
 @pytest.mark.parametrize('name', VOLUME_SWITCH_NAMES)

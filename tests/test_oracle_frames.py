@@ -272,6 +272,7 @@ def test_ground_switch_matrix(golden, name):
 VOLUME_SWITCH_NAMES = ['v_bg', 'v_clip', 'v_s16_chunks', 'v_sharp_weights']
 NOVEL_SWITCH_NAMES = ['n_rotate', 'n_rotate_ground', 'n_only_visibility']
 HARD_NOVEL_NAMES = ['n_split_body']
+SPHERE_SWITCH_NAMES = ['s_sharp_weights']
 
 
 def novel_switch_case(ref, name):
@@ -341,7 +342,7 @@ def test_volume_switch_matrix(golden, name):
 def test_switch_matrix(golden, name):
     ref = golden('switches.npz')
     variants = switch_variants(ref)
-    assert sorted(variants) == sorted(SWITCH_NAMES + HARD_SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES + HARD_NOVEL_NAMES)
+    assert sorted(variants) == sorted(SWITCH_NAMES + HARD_SWITCH_NAMES + GROUND_SWITCH_NAMES + VOLUME_SWITCH_NAMES + NOVEL_SWITCH_NAMES + HARD_NOVEL_NAMES + SPHERE_SWITCH_NAMES)
     cfg = switch_cfg(variants[name])
     bkw = switch_batch_kw(variants[name])
     net = O.OracleNet(switch_state_dict(bkw, cfg), cfg)
@@ -455,3 +456,22 @@ def test_hard_case_novel_light(golden, name):
                 _cmp(out[out_name], maps, k, tol)
         assert O.psnr(out[out_name].rgb_map, T(maps['rgb_map'])) > 90
     assert float(np.abs(want['probe00']['rgb_map'] - want['probe01']['rgb_map']).max()) > 0.05
+
+
+@pytest.mark.parametrize('name', SPHERE_SWITCH_NAMES)
+def test_sphere_switch_matrix(golden, name):
+    """the sphere-tracing fast path of the AniSDF network (config 3: sphere_tracing_renderer.py without relighting: surface trace, full query,
+    colour net on the traced normals) with the trained-like weights"""
+    ref = golden('switches.npz')
+    ov = switch_variants(ref)[name]
+    cfg = make_cfg('sphere_tracing')
+    net = O.OracleNet(synthetic.make_state_dict(0, relight=False, cfg=cfg, kind=ov.get('@weights_kind', 'init')), cfg)
+    batch = synthetic.make_batch(int(ref['H']), int(ref['H']), seed=0, posed=True, crop=int(ref['crop']), skin_noise=0.0)
+    out = O.render_sphere_tracing(net, batch)
+    sub = {k[len(name) + 1:]: v for k, v in ref.items() if k.startswith(name + '.')}
+    assert bool(((out.acc_map > 0) == (T(sub['acc_map']) > 0)).all())
+    for k in ('surf_map', 'cpts_map', 'resd_map'):
+        _cmp(out, sub, k, 1e-4)
+    _cmp(out, sub, 'norm_map', 2e-3)
+    _cmp(out, sub, 'rgb_map', 1e-4)
+    assert O.psnr(out.rgb_map, T(sub['rgb_map'])) > 80
