@@ -20,7 +20,7 @@ Tolerances (f16 MFMA operands, fp32 accumulate; everything outside the MLPs is f
       from 64 to 51 dB, which is why the all-ray PSNR is only a sanity bound there.
       * through assert_contract: frame_relight, frame_relight_smooth, frame_novel (three probes), frame_ground, the multi-chunk and
         other-pose cases, the full-size sample, the volume frames (> 80 dB);
-      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 42 configuration overrides + round 6's 5 hard cases, one process per variant):
+      * the switch matrix (round 5; tests/golden/switches.npz: the reference under 42 configuration overrides + round 6's 8 hard cases, one process per variant):
         25 relit windows, 8 ground-pass frames, 3 volume frames, 2 rotating-light sequences; rgb through assert_contract over ALL rays
         (no fp32-unstable ray on these windows: 60-96 dB, max 1.5e-4 .. 7.8e-3), the other maps to their tolerances;
         test_box_structure_is_morton_sorted pins the per-frame vertex order of the box structure against numpy;
