@@ -592,7 +592,7 @@ def main():
             'metric': 'rays_per_sec', 'value': H * H * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'xuzhen_12v_geo_fix_mat-shaped full relight, {H}x{H}, 16x32 light probe, DFSS visibility (4 iters), '
+            'config': {'workload': f'xuzhen_12v_geo_fix_mat-shaped full relight, {H}x{H}, 16x32 light probe, DFSS visibility ({int(cfg.obj_lvis.iter) if "obj_lvis" in cfg else 4} iters), '
                                    f'16-iter surface trace, synthetic weights/body' + (f', {args.probes} novel probes re-shaded' if args.mode == 'novel_light' else '') + (', + ground-plane pass' if args.ground else '') if relight else f'{args.mode} {H}x{H}',
                        'rays_per_frame': H * H, 'rays_in_bbox': P, 'hit_pixels_per_frame': int(cnts[3].item() / args.steps),
                        'fine_queries_per_frame': int(cnts[0].item() / args.steps), 'full_queries_per_frame': int(cnts[1].item() / args.steps),
